@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: fused Chambolle-Pock iterations on a synthetic (Nz, M, N, N) fp32 volume.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is ONE Chambolle-Pock iteration (README.md:145-157 of the reference: fidelity-dual update,
+D + prox dual update, D^T primal update, loss) over the whole volume, state resident in HBM.  With
+N > 1 the SAME volume is split into N contiguous z-slabs (strong scaling), one process per GPU, one
+boundary plane per neighbour exchanged over RCCL/xGMI before each of the two kernels and hidden behind
+the interior planes.  Rank 0 prints ONE JSON line.
+
+Workloads (--workload):
+  northstar  (256, 8, 1024, 1024) hybrid, reg_z = reg_time = 1   <- default; the shape BASELINE.json's
+             60 %-of-HBM-peak target is quoted on (fits one GPU: x,x0,p 24 GiB + q 64 GiB)
+  config1    (256, 1, 512, 512)   3-D hybrid        (BASELINE.json configs[1])
+  config2    (128, 8, 512, 512)   4-D hybrid        (BASELINE.json configs[2])
+  small      (16, 4, 256, 256)    quick functional run
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "pytv-4d_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+WORKLOADS = {
+    "northstar": dict(shape=(256, 8, 1024, 1024), reg_z=1.0, reg_time=1.0),
+    "config1": dict(shape=(256, 1, 512, 512), reg_z=1.0, reg_time=0.0),
+    "config2": dict(shape=(128, 8, 512, 512), reg_z=1.0, reg_time=1.0),
+    "small": dict(shape=(16, 4, 256, 256), reg_z=1.0, reg_time=1.0),
+}
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def synth_slab(shape, z0, nz, device, seed=1234):
+    """Noisy piecewise-constant phantom, generated per global plane so that any slab of
+    it is identical no matter how many ranks share the volume."""
+    import torch
+    Nz, M, Ny, Nx = shape
+    x = torch.zeros((nz, M, Ny, Nx), dtype=torch.float32, device=device)
+    rng = np.random.RandomState(seed)
+    for _ in range(32):
+        c = rng.rand(3)
+        h = 0.05 + 0.25 * rng.rand(3)
+        amp = float(rng.rand() * 255.0 / 4.0)
+        za, zb = int(np.floor((c[0] - h[0]) * Nz)), int(np.ceil((c[0] + h[0]) * Nz))
+        ya, yb = max(0, int((c[1] - h[1]) * Ny)), min(Ny, int((c[1] + h[1]) * Ny))
+        la, lb = max(za, z0) - z0, min(zb, z0 + nz) - z0
+        if lb <= la or yb <= ya:
+            continue
+        for t in range(M):
+            xa, xb = max(0, int((c[2] - h[2]) * Nx) + t), min(Nx, int((c[2] + h[2]) * Nx) + t)
+            if xb > xa:
+                x[la:lb, t, ya:yb, xa:xb] += amp
+    gen = torch.Generator(device=device)
+    for k in range(nz):
+        gen.manual_seed(seed * 100003 + z0 + k)
+        x[k] += 100.0 * torch.rand((M, Ny, Nx), dtype=torch.float32, device=device, generator=gen)
+    return x
+
+
+def cpu_baseline(shape, reg_z, reg_time, nd):
+    """The NumPy oracle (a single-threaded restatement of pytv.tv_CPU / tv_operators_CPU, pinned to
+    the reference by tests/golden) timed on a bounded z-sub-slab of the same workload."""
+    from oracle import tv_oracle as orc
+    Nz, M, Ny, Nx = shape
+    nz_cpu = max(2, min(Nz, int(round(1.6e7 / (M * Ny * Nx)))))
+    sub = (nz_cpu, M, Ny, Nx)
+    rng = np.random.default_rng(0)
+    x0 = (100.0 * rng.random(sub)).astype(np.float32)
+    n_it = 2
+    t0 = time.perf_counter()
+    orc.chambolle_pock(x0, n_it, 25.0, scheme="hybrid", reg_z_over_reg=reg_z, reg_time=reg_time)
+    dt = (time.perf_counter() - t0) / n_it
+    vox = float(np.prod(sub))
+    mvox_s = vox / dt / 1e6
+    full = float(np.prod(shape))
+    return {"value": mvox_s * 1e6 / full, "unit": "it/s", "cores": 1, "kind": "port",
+            "mvox_per_s": mvox_s,
+            "sample": "oracle.chambolle_pock (NumPy, single-threaded like the reference) on a %s z-sub-slab, "
+                      "%d iterations, %.1f s/iteration; it/s extrapolated linearly in Nz to %s" % (sub, n_it, dt, tuple(shape)),
+            "host_cpus": os.cpu_count(), "numpy": np.__version__}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="northstar", choices=sorted(WORKLOADS))
+    ap.add_argument("--scheme", default="hybrid", choices=["upwind", "downwind", "central", "hybrid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pytv
+    from pytv.slab import Slab
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    wl = WORKLOADS[args.workload]
+    shape = wl["shape"]
+    slab = Slab(shape[0], rank=rank, world=world)
+    x0 = synth_slab(shape, slab.z0, slab.nz, device)
+    cp = pytv.solvers.ChambollePock(x0, 25.0, scheme=args.scheme, reg_z_over_reg=wl["reg_z"], reg_time=wl["reg_time"],
+                                    slab=slab, overlap=not args.no_overlap)
+    nd = cp.geo.nd
+    K, W = args.steps, args.warmup
+    hist = torch.zeros((K + W, 6), dtype=torch.float64, device=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(W):
+        cp.step(hist[it])
+    # per-kernel HIP events on the launch stream (torch's current stream) -- unsharded launches only
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)] if not cp.overlap else None
+    orig_dual, orig_primal = cp._dual, cp._primal
+    if ev is not None:
+        state = {"it": 0}
+
+        def dual_timed(*a):
+            ev[state["it"]][0].record()
+            orig_dual(*a)
+            ev[state["it"]][1].record()
+
+        def primal_timed(*a):
+            orig_primal(*a)
+            ev[state["it"]][2].record()
+            state["it"] += 1
+        cp._dual, cp._primal = dual_timed, primal_timed
+
+    barrier()
+    t0 = time.perf_counter()
+    for it in range(K):
+        cp.step(hist[W + it])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cp._dual, cp._primal = orig_dual, orig_primal
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    h = hist.cpu().numpy()
+    loss = h[:, 3:6].sum(axis=1) + 25.0 * h[:, 0:3].sum(axis=1)
+
+    V = float(np.prod(shape))
+    V_local = float(slab.nz * shape[1] * shape[2] * shape[3])
+    it_s = K / elapsed
+    bytes_iter_algo = 4.0 * (8 + 3 * nd) * V            # the README's un-fused iteration
+    bytes_iter_fused = 4.0 * (6 + 3 * nd) * V           # what the two fused kernels must move
+    out = {
+        "metric": "chambolle_pock_iters_per_sec", "value": it_s, "unit": "it/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %s fp32 %s CP" % (args.workload, "x".join(str(s) for s in shape), args.scheme),
+                   "shape": list(shape), "scheme": args.scheme, "nd": nd, "reg_z_over_reg": wl["reg_z"], "reg_time": wl["reg_time"],
+                   "lambda": 25.0, "sigma_D": cp.sigma_D, "sigma_A": cp.sigma_A, "tau": cp.tau,
+                   "parallelism": "z-slab x%d%s" % (world, " (halo overlapped)" if cp.overlap else "")},
+        "voxel_iterations_per_sec": it_s * V,
+        "hbm_gbps_iteration": {"algorithmic_unfused_(8+3Nd)": bytes_iter_algo * it_s / 1e9 / world,
+                               "fused_(6+3Nd)": bytes_iter_fused * it_s / 1e9 / world, "per": "GPU"},
+        "loss_first_last": [float(loss[W]), float(loss[-1])],
+    }
+    if ev is not None:
+        torch.cuda.synchronize()
+        t_dual = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+        t_primal = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+        b_dual = 4.0 * (1 + 2 * nd) * V_local
+        b_primal = 4.0 * (nd + 5) * V_local
+        out["roofline"] = {"bound": "hbm", "kernel": "k_D<hybrid,float,4,CpDual> (tv_cp_dual)", "achieved": b_dual / t_dual / 1e9,
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_dual / t_dual / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                           "bytes_per_launch": b_dual, "ms_per_launch": 1e3 * t_dual,
+                           "note": "algorithmic bytes (1+2Nd)*4 per voxel; HIP events on the launch stream, includes the two tiny partial-sum kernels"}
+        out["roofline_primal"] = {"bound": "hbm", "kernel": "k_DT<hybrid,float,4,CpPrimal> (tv_cp_primal)",
+                                  "achieved": b_primal / t_primal / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": b_primal / t_primal / 1e9 / HBM_PEAK_GBPS, "bytes_per_launch": b_primal,
+                                  "ms_per_launch": 1e3 * t_primal,
+                                  "note": "algorithmic bytes (Nd+5)*4 per voxel: reads q,x,x0,p; writes x,p (fidelity dual fused in)"}
+    else:
+        b_it = bytes_iter_fused / world
+        out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_dual + tv_cp_primal (interior + 2 edge launches each, halo overlapped)",
+                           "achieved": b_it * it_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_it * it_s / 1e9 / HBM_PEAK_GBPS,
+                           "traffic": None, "note": "per-GPU, whole iteration incl. halo exchange"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del cp, x0
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(shape, wl["reg_z"], wl["reg_time"], nd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

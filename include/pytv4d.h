@@ -1,0 +1,133 @@
+/* pytv4d.h -- C-ABI of the MI355X-native PyTV-4D hot path (libpytv4d_hip.so).
+ *
+ * Drop-in boundary: these entry points are what a binding of the reference's L2/L3 Python API
+ * (pytv/tv_operators_GPU.py, pytv/tv_GPU.py) calls instead of torch.nn.functional.conv3d +
+ * slice-assign.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless the
+ * comment says otherwise; every function enqueues on the caller's hipStream_t (passed as
+ * void*, NULL = default stream) and returns without synchronising.
+ *
+ * Return value: 0 = ok, <0 = argument error (TV_E_*), >0 = hipError_t of a failed HIP call.
+ * tv_last_error() gives a human readable message for the calling thread.
+ *
+ * Layouts (C-contiguous, cols fastest; pytv/tv_operators_CPU.py:82-83,96-97):
+ *   image     x : (nz, m, ny, nx)
+ *   gradient  d : (nz, nd, m, ny, nx)      channel axis between z and time
+ * Channel order: rows, cols, [z], [t]; hybrid: row-up, col-up, row-down, col-down,
+ * [z-up, z-down], [t-up, t-down]  (pytv/tv_operators_CPU.py:117-152).
+ *
+ * z-slab sharding: a rank holds planes [z0, z0+nz) of a volume of nz_global planes.  Halo
+ * arguments point to the neighbouring ranks' boundary planes (m*ny*nx elements each); they may be
+ * NULL when the corresponding global plane does not exist or is not needed by the scheme.
+ */
+#ifndef PYTV4D_H
+#define PYTV4D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TV_UPWIND   0
+#define TV_DOWNWIND 1
+#define TV_CENTRAL  2
+#define TV_HYBRID   3
+
+#define TV_F32 0
+#define TV_F64 1
+
+#define TV_E_ARG      (-1)   /* NULL / negative size / unknown enum            */
+#define TV_E_HALO     (-2)   /* a halo plane the scheme needs was not supplied */
+#define TV_E_CHANNELS (-3)   /* nd does not match scheme and active axes       */
+
+/* Geometry and weights of one z-slab.  Mirrors the keyword arguments every reference operator
+ * takes: reg_z_over_reg, reg_time, mask_static, factor_reg_static
+ * (pytv/tv_operators_GPU.py:134,253,362,471,583,719,828,938; pytv/tv_GPU.py:47,142,217,290). */
+typedef struct tv_geom {
+    int64_t nz;                 /* planes held by this rank                                  */
+    int64_t m, ny, nx;          /* time frames, rows, cols                                   */
+    int64_t nz_global;          /* planes of the whole volume (== nz when not sharded)       */
+    int64_t z0;                 /* global index of local plane 0                             */
+    int32_t scheme;             /* TV_UPWIND .. TV_HYBRID                                    */
+    int32_t dtype;              /* TV_F32 / TV_F64                                           */
+    double  reg_z_over_reg;     /* z weight; z axis active iff nz_global > 1 and this > 0    */
+    double  reg_time;           /* time weight; time axis active iff m > 1 and this > 0      */
+    double  factor_reg_static;  /* time channels scaled by sqrt(this) where mask_static != 0 */
+    const uint8_t* mask_static; /* device, ny*nx bytes, or NULL (the reference's `False`)    */
+} tv_geom;
+
+/* ---- housekeeping ------------------------------------------------------------------------ */
+const char* tv_last_error(void);
+int         tv_version(void);                         /* 10000*major + 100*minor + patch     */
+/* Number of gradient channels nd for this geometry (pytv/tv_operators_GPU.py:170-174,
+ * 290-294,399-403,507-511), or TV_E_ARG. */
+int         tv_num_channels(const tv_geom* g);
+/* Bytes of device scratch the reducing entry points need in `ws` for this geometry. */
+size_t      tv_workspace_bytes(const tv_geom* g);
+
+/* ---- operators: replace pytv.tv_operators_GPU.D_* / D_T_* / compute_L21_norm ---------------- */
+/* d = D x.  x_prev / x_next: the plane z0-1 / z0+nz of the image (or NULL).
+ * Replaces D_hybrid/D_downwind/D_upwind/D_central (pytv/tv_operators_GPU.py:134-581). */
+int tv_D(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* d, void* stream);
+
+/* out = D^T y.  y_prev: plane z0-1 of the z channel whose adjoint looks backwards (upwind /
+ * central z channel; hybrid: z-up channel); y_next: plane z0+nz of the channel whose adjoint
+ * looks forwards (downwind / central z channel; hybrid: z-down channel).
+ * Replaces D_T_hybrid/D_T_downwind/D_T_upwind/D_T_central (pytv/tv_operators_GPU.py:583-1052). */
+int tv_DT(const tv_geom* g, const void* y, const void* y_prev, const void* y_next, void* out, void* stream);
+
+/* *result (device, fp64) = sum_p sqrt(sum_c d[p,c]^2); norms (nz,m,ny,nx) optional (NULL = skip).
+ * Replaces compute_L21_norm (pytv/tv_operators_GPU.py:46-90). */
+int tv_l21(const tv_geom* g, const void* d, int32_t nd, void* norms, double* result, void* ws, void* stream);
+
+/* ---- direct TV API: replaces pytv.tv_GPU.tv_* ------------------------------------------------ */
+/* *tv (device fp64) = TV of the local planes; G = the reference's sub-gradient
+ * (pytv/tv_GPU.py:47-375).  norms_ext: REQUIRED scratch/output of (nz + 2) planes; on return
+ * plane k+1 holds |D x| of local plane k with zeros replaced by +inf (pytv/tv_GPU.py:88), i.e.
+ * the reference's grad_norms is norms_ext + one plane.  x_prev / x_next: TWO planes each
+ * (z0-2, z0-1) / (z0+nz, z0+nz+1) when sharded, else NULL. */
+int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* x_next,
+               void* G, void* norms_ext, double* tv, void* ws, void* stream);
+
+/* ---- fused Chambolle-Pock inner loop (README.md:141-157) ----------------------------------- */
+/* q <- proj_{|.|_2 <= lambda}(q + sigma_D * D x); *tv (device fp64) = |D x|_{2,1} of local planes. */
+int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* q,
+               double sigma_D, double lambda, double* tv, void* ws, void* stream);
+/* p <- (p + sigma_A (x - x0)) / (1 + sigma_A);  x <- x - tau p - tau D^T q;
+ * *fid (device fp64) = 1/2 |x_new - x0|^2 of local planes.  q_prev/q_next as y_prev/y_next in tv_DT. */
+int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x,
+                 const void* x0, void* p, double tau, double sigma_A, double* fid, void* ws, void* stream);
+
+/* ---- fused ADMM updates (not in the reference; README.md:26,135 mention only) --------------- */
+/* v = D x + u; z = v * max(0, 1 - thresh/|v|_2); u = v - z; *tv (device fp64) = |D x|_{2,1}. */
+int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* z, void* u,
+               double thresh, double* tv, void* ws, void* stream);
+/* out = base + alpha * D^T (a - b)   (b and/or base may be NULL).  ab_prev / ab_next: halo planes
+ * of (a - b) for the channels named in tv_DT. */
+int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_prev, const void* ab_next,
+               const void* base, double alpha, void* out, void* stream);
+/* out = x + rho * D^T D x, computed from x alone (radius-2 stencil); *dot (device fp64) = <x, out>
+ * over local planes.  x_prev / x_next: TWO planes each as in tv_subgrad. */
+int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho,
+                 void* out, double* dot, void* ws, void* stream);
+/* Conjugate-gradient vector updates with device-resident scalars (no host round trip):
+ *   tv_cg_step1: alpha = rs/dAd;  x += alpha d;  r -= alpha Ad;  *rs_new = <r, r>
+ *   tv_cg_step2: beta = rs_new/rs; d = r + beta d                                            */
+int tv_cg_step1(const tv_geom* g, void* x, void* r, const void* d, const void* Ad, const double* rs,
+                const double* dAd, double* rs_new, void* ws, void* stream);
+int tv_cg_step2(const tv_geom* g, void* d, const void* r, const double* rs_new, const double* rs, void* stream);
+
+/* ---- small vector helpers on (nz,m,ny,nx) arrays -------------------------------------------- */
+/* out = a - b (used for ADMM halos and residuals) */
+int tv_sub(int32_t dtype, int64_t n, const void* a, const void* b, void* out, void* stream);
+/* *result (device fp64) = <a, b> */
+int tv_dot(const tv_geom* g, const void* a, const void* b, double* result, void* ws, void* stream);
+/* x <- x - step * ((x - x0) + lambda * G); *fid = 1/2 |x_new - x0|^2  (README.md:122-123) */
+int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, double step, double lambda,
+                    double* fid, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYTV4D_H */

@@ -1,0 +1,168 @@
+"""ctypes binding of libpytv4d_hip.so (C-ABI: include/pytv4d.h).
+
+The HIP library is the ONLY compute path of this package.  If it cannot be loaded the import
+fails loudly -- there is no CPU or PyTorch fallback.  PyTorch is used for device memory, the
+current HIP stream and (in ``slab.py``) ``torch.distributed``; it is imported BEFORE the library
+so that the library binds to the same ``libamdhip64`` runtime PyTorch already loaded (one HIP
+runtime per process).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch  # noqa: F401  (must come first: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpytv4d_hip.so")
+
+SCHEMES = {"upwind": 0, "downwind": 1, "central": 2, "hybrid": 3}
+TV_F32, TV_F64 = 0, 1
+
+_c_void_p = ctypes.c_void_p
+_c_double_p = ctypes.c_void_p   # device pointers to fp64 scalars are passed as raw addresses
+
+
+class TvGeom(ctypes.Structure):
+    """struct tv_geom of include/pytv4d.h"""
+    _fields_ = [
+        ("nz", ctypes.c_int64), ("m", ctypes.c_int64), ("ny", ctypes.c_int64), ("nx", ctypes.c_int64),
+        ("nz_global", ctypes.c_int64), ("z0", ctypes.c_int64),
+        ("scheme", ctypes.c_int32), ("dtype", ctypes.c_int32),
+        ("reg_z_over_reg", ctypes.c_double), ("reg_time", ctypes.c_double), ("factor_reg_static", ctypes.c_double),
+        ("mask_static", ctypes.c_void_p),
+    ]
+
+
+_G = ctypes.POINTER(TvGeom)
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "tv_last_error": (ctypes.c_char_p, []),
+    "tv_version": (ctypes.c_int, []),
+    "tv_num_channels": (ctypes.c_int, [_G]),
+    "tv_workspace_bytes": (ctypes.c_size_t, [_G]),
+    "tv_D": (ctypes.c_int, [_G] + [_c_void_p] * 5),
+    "tv_DT": (ctypes.c_int, [_G] + [_c_void_p] * 5),
+    "tv_l21": (ctypes.c_int, [_G, _c_void_p, ctypes.c_int32, _c_void_p, _c_double_p, _c_void_p, _c_void_p]),
+    "tv_subgrad": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [_c_double_p, _c_void_p, _c_void_p]),
+    "tv_cp_dual": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [ctypes.c_double, ctypes.c_double, _c_double_p, _c_void_p, _c_void_p]),
+    "tv_cp_primal": (ctypes.c_int, [_G] + [_c_void_p] * 6 + [ctypes.c_double, ctypes.c_double, _c_double_p, _c_void_p, _c_void_p]),
+    "tv_admm_zu": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double, _c_double_p, _c_void_p, _c_void_p]),
+    "tv_DT_axpy": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double, _c_void_p, _c_void_p]),
+    "tv_normal_op": (ctypes.c_int, [_G] + [_c_void_p] * 3 + [ctypes.c_double, _c_void_p, _c_double_p, _c_void_p, _c_void_p]),
+    "tv_cg_step1": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [_c_double_p] * 3 + [_c_void_p, _c_void_p]),
+    "tv_cg_step2": (ctypes.c_int, [_G] + [_c_void_p] * 2 + [_c_double_p] * 2 + [_c_void_p]),
+    "tv_sub": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64] + [_c_void_p] * 4),
+    "tv_dot": (ctypes.c_int, [_G, _c_void_p, _c_void_p, _c_double_p, _c_void_p, _c_void_p]),
+    "tv_subgrad_step": (ctypes.c_int, [_G, _c_void_p, _c_void_p, _c_void_p, ctypes.c_double, ctypes.c_double,
+                                       _c_double_p, _c_void_p, _c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "pytv: native HIP library %s is missing. Build it with "
+                "`python pytv-4d_amd/build.py` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Map a C-ABI status to a Python exception (0 ok, <0 argument error, >0 hipError_t)."""
+    if rc == 0:
+        return
+    msg = lib().tv_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError("pytv native: %s (code %d)" % (msg, rc))
+    raise RuntimeError("pytv native: HIP error %d: %s" % (rc, msg))
+
+
+def dtype_code(torch_dtype):
+    if torch_dtype == torch.float32:
+        return TV_F32
+    if torch_dtype == torch.float64:
+        return TV_F64
+    raise ValueError("pytv native: only float32 / float64 arrays are supported, got %s" % torch_dtype)
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Geometry:
+    """Python-side owner of a ``tv_geom``: keeps the device mask alive and caches the workspace."""
+
+    def __init__(self, shape, scheme, dtype, device, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
+                 factor_reg_static=0.0, nz_global=None, z0=0):
+        if scheme not in SCHEMES:
+            raise ValueError("unknown TV scheme %r" % (scheme,))
+        if len(shape) != 4:
+            raise ValueError("image must be 4-D (Nz, M, N, N), got shape %s" % (tuple(shape),))
+        nz, m, ny, nx = (int(v) for v in shape)
+        self.shape = (nz, m, ny, nx)
+        self.scheme = scheme
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.mask_dev = None
+        if not isinstance(mask_static, bool):
+            mk = torch.as_tensor(np.asarray(mask_static.detach().cpu()) if isinstance(mask_static, torch.Tensor)
+                                 else np.asarray(mask_static))
+            mk = torch.broadcast_to(mk.to(torch.bool), (1, 1, ny, nx)).reshape(ny, nx)
+            self.mask_dev = mk.to(torch.uint8).contiguous().to(self.device)
+        g = TvGeom()
+        g.nz, g.m, g.ny, g.nx = nz, m, ny, nx
+        g.nz_global = nz if nz_global is None else int(nz_global)
+        g.z0 = int(z0)
+        g.scheme = SCHEMES[scheme]
+        g.dtype = dtype_code(dtype)
+        g.reg_z_over_reg = float(reg_z_over_reg)
+        g.reg_time = float(reg_time)
+        g.factor_reg_static = float(factor_reg_static)
+        g.mask_static = ptr(self.mask_dev)
+        self.c = g
+        nd = lib().tv_num_channels(ctypes.byref(g))
+        if nd < 0:
+            check(nd)
+        self.nd = nd
+        self.z_active = g.nz_global > 1 and g.reg_z_over_reg > 0
+        self.t_active = m > 1 and g.reg_time > 0
+        self._ws = None
+        self._scalars = None
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.c)
+
+    @property
+    def grad_shape(self):
+        nz, m, ny, nx = self.shape
+        return (nz, self.nd, m, ny, nx)
+
+    @property
+    def plane(self):
+        return self.shape[1] * self.shape[2] * self.shape[3]
+
+    def workspace(self):
+        if self._ws is None:
+            nbytes = lib().tv_workspace_bytes(self.ref)
+            self._ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
+        return self._ws
+
+    def scalar(self):
+        """A fresh device fp64 scalar (0-d tensor)."""
+        return torch.zeros((), dtype=torch.float64, device=self.device)

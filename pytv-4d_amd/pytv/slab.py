@@ -1,0 +1,139 @@
+"""z-slab sharding of an (Nz, M, N, N) volume over the GPUs of one node.
+
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU
+for the tests).  The reference has no multi-GPU code at all; its layout remark
+(README.md:235: "(Nz, M, N, N) ... can be decomposed easily along z") is what this module acts on:
+rank r owns the contiguous planes [z0, z0 + nz) of both the image and the gradient/dual arrays, and
+every operator apply needs ONE boundary plane (M*N*N elements, contiguous) from each neighbour.
+Traffic is nearest-neighbour only -- a chain, not a ring: ncclSend/ncclRecv grouped in one
+``batch_isend_irecv`` per exchange, plus an fp64 all-reduce of a few scalars for TV / loss / CG dots.
+"""
+import torch
+import torch.distributed as dist
+
+
+def partition(nz_global, world):
+    """Contiguous, balanced split of nz_global planes: list of (z0, nz) per rank."""
+    base, rem = divmod(int(nz_global), int(world))
+    out, z0 = [], 0
+    for r in range(world):
+        nz = base + (1 if r < rem else 0)
+        out.append((z0, nz))
+        z0 += nz
+    return out
+
+
+class Slab:
+    """This rank's share of the volume and its neighbour exchange."""
+
+    def __init__(self, nz_global, group=None, rank=None, world=None):
+        self.group = group
+        if rank is None or world is None:
+            if dist.is_available() and dist.is_initialized():
+                rank, world = dist.get_rank(group), dist.get_world_size(group)
+            else:
+                rank, world = 0, 1
+        self.rank, self.world = int(rank), int(world)
+        self.nz_global = int(nz_global)
+        if self.nz_global < self.world:
+            raise ValueError("cannot split %d planes over %d ranks" % (self.nz_global, self.world))
+        parts = partition(self.nz_global, self.world)
+        self.z0, self.nz = parts[self.rank]
+        self.parts = parts
+        self.prev = self.rank - 1 if self.rank > 0 else None
+        self.next = self.rank + 1 if self.rank + 1 < self.world else None
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def sharded(self):
+        return self.world > 1
+
+    def _global_rank(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def exchange(self, send_prev=None, send_next=None, recv_prev=None, recv_next=None):
+        """Start one neighbour exchange.  Each argument is a contiguous tensor or None; sends/recvs
+        towards a neighbour that does not exist are dropped.  Returns the list of work handles
+        (``wait()`` orders the current stream behind the transfer on RCCL; it blocks on gloo)."""
+        if not self.sharded:
+            return []
+        ops = []
+        if self.prev is not None:
+            if recv_prev is not None:
+                ops.append(dist.P2POp(dist.irecv, recv_prev, self._global_rank(self.prev), self.group))
+            if send_prev is not None:
+                ops.append(dist.P2POp(dist.isend, send_prev, self._global_rank(self.prev), self.group))
+        if self.next is not None:
+            if send_next is not None:
+                ops.append(dist.P2POp(dist.isend, send_next, self._global_rank(self.next), self.group))
+            if recv_next is not None:
+                ops.append(dist.P2POp(dist.irecv, recv_next, self._global_rank(self.next), self.group))
+        if not ops:
+            return []
+        return dist.batch_isend_irecv(ops)
+
+    @staticmethod
+    def wait(handles):
+        for h in handles:
+            h.wait()
+
+    def allreduce_sum_(self, t):
+        """In-place sum over ranks of a (small, fp64) tensor."""
+        if self.sharded:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def local(self, full):
+        """This rank's planes of a full array whose axis 0 is z."""
+        return full[self.z0:self.z0 + self.nz]
+
+
+class HaloPlan:
+    """Which boundary planes a scheme needs from / owes to its z-neighbours.
+
+    Image halos (forward operator D):  upwind reads plane z0+nz (next), downwind plane z0-1 (prev),
+    central and hybrid both.  Gradient halos (transposed operator): the adjoint of a forward
+    difference looks BACKWARDS (needs the previous rank's last plane of the z channel), the adjoint
+    of a backward difference looks FORWARDS; hybrid has one channel of each kind (z-up, z-down),
+    central reads the same channel on both sides.  A rank sends the mirror image of what its
+    neighbour needs.  Only the z channel plane(s) travel: M*N*N elements per message."""
+
+    def __init__(self, slab, scheme, z_active):
+        self.slab = slab
+        on = bool(slab.sharded and z_active)
+        has_p, has_n = slab.prev is not None, slab.next is not None
+        self.x_need_prev = on and scheme != "upwind" and has_p
+        self.x_need_next = on and scheme != "downwind" and has_n
+        self.x_send_prev = on and scheme != "downwind" and has_p     # my first plane is prev's "next"
+        self.x_send_next = on and scheme != "upwind" and has_n       # my last plane is next's "prev"
+        self.g_need_prev = on and scheme != "downwind" and has_p
+        self.g_need_next = on and scheme != "upwind" and has_n
+        self.g_send_next = on and scheme != "downwind" and has_n     # my last backward-looking plane
+        self.g_send_prev = on and scheme != "upwind" and has_p       # my first forward-looking plane
+        per = 2 if scheme == "hybrid" else 1
+        self.ch_back = 2 * per                                       # z channel whose adjoint looks backwards
+        self.ch_fwd = 2 * per + (1 if scheme == "hybrid" else 0)     # z channel whose adjoint looks forwards
+        self.on = on
+
+    def exchange_image(self, x, recv_prev, recv_next):
+        """One-plane image halos: x is (nz, M, N, N); recv_* are (1, M, N, N) buffers or None."""
+        nz = x.shape[0]
+        return self.slab.exchange(send_prev=x[0:1] if self.x_send_prev else None,
+                                  send_next=x[nz - 1:nz] if self.x_send_next else None,
+                                  recv_prev=recv_prev if self.x_need_prev else None,
+                                  recv_next=recv_next if self.x_need_next else None)
+
+    def exchange_image2(self, x, recv_prev, recv_next):
+        """Two-plane image halos for the radius-2 kernels (sub-gradient, normal operator)."""
+        if not self.on:
+            return []
+        nz = x.shape[0]
+        return self.slab.exchange(send_prev=x[0:2], send_next=x[nz - 2:nz], recv_prev=recv_prev, recv_next=recv_next)
+
+    def exchange_grad(self, q, recv_prev, recv_next):
+        """Gradient halos: q is (nz, Nd, M, N, N); recv_* are (M, N, N)-shaped buffers or None."""
+        nz = q.shape[0]
+        return self.slab.exchange(send_prev=q[0, self.ch_fwd] if self.g_send_prev else None,
+                                  send_next=q[nz - 1, self.ch_back] if self.g_send_next else None,
+                                  recv_prev=recv_prev if self.g_need_prev else None,
+                                  recv_next=recv_next if self.g_need_next else None)

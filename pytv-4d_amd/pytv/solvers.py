@@ -1,0 +1,298 @@
+"""Device-resident drivers of the reference's user-level loops.
+
+The reference ships its solvers as README snippets that round-trip numpy <-> GPU four times per
+iteration (README.md:118-124 sub-gradient descent, :141-157 Chambolle-Pock; ADMM is only mentioned,
+:26,135).  Here the state lives on the GPU(s) for the whole run and every iteration is a handful of
+fused HIP kernels (include/pytv4d.h):
+
+    ChambollePock       tv_cp_dual  (D + sigma-step + projection, TV partial)        (1+2Nd) words/voxel
+                        tv_cp_primal(fidelity dual + D^T + primal step, loss partial) (Nd+5) words/voxel
+    ADMM                tv_DT_axpy, tv_normal_op (I + rho D^T D from x alone), tv_cg_step1/2, tv_admm_zu
+    SubgradientDescent  tv_subgrad + tv_subgrad_step
+
+With a ``Slab`` (one process per GPU) each rank holds a contiguous z-slab; one boundary plane per
+neighbour is exchanged per operator apply (two for the radius-2 kernels) and, for Chambolle-Pock,
+hidden behind the interior planes' kernel.  Scalars (TV, fidelity, CG dots) stay on the device as
+fp64 and are all-reduced there; nothing synchronises with the host inside the loop.
+"""
+import numpy as np
+import torch
+
+from . import _native as _nv
+from .slab import HaloPlan, Slab
+
+__all__ = ["ChambollePock", "ADMM", "SubgradientDescent", "cp_step_size"]
+
+
+def cp_step_size(nz_global, m, reg_z_over_reg, reg_time):
+    """tau = 1 / (1 + L^2) with L^2 = 4 (2 + reg_z [z active] + reg_time [t active]) >= |D|^2.
+    Reduces to the reference's 1/(8+1) in 2-D (README.md:143)."""
+    z = nz_global > 1 and reg_z_over_reg > 0
+    t = m > 1 and reg_time > 0
+    return 1.0 / (1.0 + 4.0 * (2.0 + (reg_z_over_reg if z else 0.0) + (reg_time if t else 0.0)))
+
+
+class _SlabProblem:
+    """Common state: local slab geometry (and sub-slab geometries for interior / edge launches)."""
+
+    def __init__(self, x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab):
+        if not isinstance(x0, torch.Tensor) or not x0.is_cuda:
+            raise ValueError("x0 must be a device tensor (this rank's z-slab of the volume)")
+        if x0.dim() != 4:
+            raise ValueError("x0 must be 4-D (Nz_local, M, N, N)")
+        self.x0 = x0.contiguous()
+        self.device = x0.device
+        self.dtype = x0.dtype
+        self.scheme = scheme
+        self.slab = slab if slab is not None else Slab(x0.shape[0], rank=0, world=1)
+        if self.slab.nz != x0.shape[0]:
+            raise ValueError("x0 has %d planes but this rank's slab has %d" % (x0.shape[0], self.slab.nz))
+        self.kw = dict(reg_z_over_reg=reg_z_over_reg, reg_time=reg_time, mask_static=mask_static,
+                       factor_reg_static=factor_reg_static)
+        self._geoms = {}
+        self.geo = self.geom(0, self.slab.nz)
+        self.lib = _nv.lib()
+
+    def geom(self, a, b):
+        """Geometry of local planes [a, b) seen as a slab of the global volume."""
+        key = (a, b)
+        if key not in self._geoms:
+            nz, m, ny, nx = self.x0.shape
+            self._geoms[key] = _nv.Geometry((b - a, m, ny, nx), self.scheme, self.dtype, self.device,
+                                            nz_global=self.slab.nz_global, z0=self.slab.z0 + a, **self.kw)
+        return self._geoms[key]
+
+    @property
+    def stream(self):
+        return _nv.current_stream(self.device)
+
+    def new_plane(self, n=1):
+        _, m, ny, nx = self.x0.shape
+        return torch.empty((n, m, ny, nx), dtype=self.dtype, device=self.device)
+
+
+# =================================================================================================
+class ChambollePock(_SlabProblem):
+    """min_x 1/2 |x - x0|^2 + regularization * TV(x), README.md:141-157 with the state on the GPU.
+
+    x0 : this rank's slab (device tensor).  ``step()`` enqueues one iteration; ``run(n)`` enqueues n
+    and returns the loss history (one host synchronisation at the end)."""
+
+    def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
+                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True):
+        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
+        self.reg = float(regularization)
+        self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
+        self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time)
+        self.x = self.x0.clone()
+        self.p = torch.zeros_like(self.x0)
+        self.q = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
+        self.ws = self.geo.workspace()
+        self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
+        pl = self.plan
+        sh = pl.on
+        self.ch_back, self.ch_fwd = pl.ch_back, pl.ch_fwd
+        self.xh_prev = self.new_plane() if pl.x_need_prev else None
+        self.xh_next = self.new_plane() if pl.x_need_next else None
+        self.qh_prev = self.new_plane() if pl.g_need_prev else None
+        self.qh_next = self.new_plane() if pl.g_need_next else None
+        self.overlap = bool(overlap) and sh and self.slab.nz >= 3
+        self.hist = None
+        self.it = 0
+        self._scratch = torch.zeros(6, dtype=torch.float64, device=self.device)
+
+    # ---- one phase on local planes [a, b) -----------------------------------------------------
+    def _dual(self, a, b, xp, xn, out):
+        g = self.geom(a, b)
+        _nv.check(self.lib.tv_cp_dual(g.ref, _nv.ptr(self.x[a:b]), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.q[a:b]),
+                                      self.sigma_D, self.reg, out.data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def _primal(self, a, b, qp, qn, out):
+        g = self.geom(a, b)
+        _nv.check(self.lib.tv_cp_primal(g.ref, _nv.ptr(self.q[a:b]), _nv.ptr(qp), _nv.ptr(qn), _nv.ptr(self.x[a:b]),
+                                        _nv.ptr(self.x0[a:b]), _nv.ptr(self.p[a:b]), self.tau, self.sigma_A,
+                                        out.data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def step(self, out=None):
+        """Enqueue one iteration.  out: fp64 device tensor of 6 slots receiving the TV parts [0:3]
+        and fidelity parts [3:6] of this rank (summed later); defaults to an internal scratch."""
+        out = self._scratch if out is None else out
+        nz, s = self.slab.nz, self.slab
+        x, q = self.x, self.q
+        # ---------------- dual: q <- proj(q + sigma D x) -----------------------------------------
+        h = self.plan.exchange_image(x, self.xh_prev, self.xh_next)
+        if self.overlap:
+            self._dual(1, nz - 1, x[0:1], x[nz - 1:nz], out[0:1])
+            s.wait(h)
+            self._dual(0, 1, self.xh_prev, x[1:2], out[1:2])
+            self._dual(nz - 1, nz, x[nz - 2:nz - 1], self.xh_next, out[2:3])
+        else:
+            s.wait(h)
+            self._dual(0, nz, self.xh_prev, self.xh_next, out[0:1])
+        # ---------------- primal: x <- x - tau p - tau D^T q ---------------------------------------
+        h = self.plan.exchange_grad(q, self.qh_prev[0] if self.qh_prev is not None else None,
+                                    self.qh_next[0] if self.qh_next is not None else None)
+        if self.overlap:
+            self._primal(1, nz - 1, q[0, self.ch_back], q[nz - 1, self.ch_fwd], out[3:4])
+            s.wait(h)
+            self._primal(0, 1, self.qh_prev, q[1, self.ch_fwd], out[4:5])
+            self._primal(nz - 1, nz, q[nz - 2, self.ch_back], self.qh_next, out[5:6])
+        else:
+            s.wait(h)
+            self._primal(0, nz, self.qh_prev, self.qh_next, out[3:4])
+        self.it += 1
+
+    def run(self, n_iter, record_loss=True):
+        """n_iter iterations; returns the README's loss history (README.md:157) as a numpy array
+        (global over all ranks), or None."""
+        hist = torch.zeros((n_iter, 6), dtype=torch.float64, device=self.device)
+        for it in range(n_iter):
+            self.step(hist[it])
+        if not record_loss:
+            return None
+        self.slab.allreduce_sum_(hist)
+        h = hist.cpu().numpy()
+        return h[:, 3:6].sum(axis=1) + self.reg * h[:, 0:3].sum(axis=1)
+
+    def result(self):
+        return self.x
+
+
+# =================================================================================================
+class SubgradientDescent(_SlabProblem):
+    """README.md:118-124 with the state on the GPU: x <- x - step ((x - x0) + reg * G(x))."""
+
+    def __init__(self, x0, regularization, step_size, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
+                 mask_static=False, factor_reg_static=0, slab=None):
+        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
+        self.reg, self.step_size = float(regularization), float(step_size)
+        self.x = self.x0.clone()
+        nz, m, ny, nx = self.x0.shape
+        self.G = torch.empty_like(self.x0)
+        self.norms_ext = torch.empty((nz + 2, m, ny, nx), dtype=self.dtype, device=self.device)
+        self.ws = self.geo.workspace()
+        self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
+        sh = self.plan.on
+        if sh and min(nz_r for _, nz_r in self.slab.parts) < 2:
+            raise ValueError("the sub-gradient needs two halo planes: every rank must hold >= 2 planes")
+        self.xh_prev = self.new_plane(2) if sh and self.slab.prev is not None else None
+        self.xh_next = self.new_plane(2) if sh and self.slab.next is not None else None
+        self.sh = sh
+
+    def step(self, out):
+        nz, s, x = self.slab.nz, self.slab, self.x
+        s.wait(self.plan.exchange_image2(x, self.xh_prev, self.xh_next))
+        g = self.geo
+        _nv.check(self.lib.tv_subgrad(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.G),
+                                      _nv.ptr(self.norms_ext), out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        _nv.check(self.lib.tv_subgrad_step(g.ref, _nv.ptr(x), _nv.ptr(self.x0), _nv.ptr(self.G), self.step_size, self.reg,
+                                           out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def run(self, n_iter):
+        hist = torch.zeros((n_iter, 2), dtype=torch.float64, device=self.device)
+        for it in range(n_iter):
+            self.step(hist[it])
+        self.slab.allreduce_sum_(hist)
+        h = hist.cpu().numpy()
+        return h[:, 1] + self.reg * h[:, 0]
+
+    def result(self):
+        return self.x
+
+
+# =================================================================================================
+class ADMM(_SlabProblem):
+    """Scaled-form ADMM for min 1/2|x-x0|^2 + reg |z|_{2,1} s.t. Dx = z  (the
+    reference names ADMM, README.md:26,135, but ships no code -- parity is pinned against
+    oracle/tv_oracle.py::admm and, op by op, against the reference's D / D^T).
+
+      x-step : (I + rho D^T D) x = x0 + rho D^T (z - u)   n_cg CG steps, warm start
+      z-step : z = shrink(Dx + u, reg/rho);  u-step: u += Dx - z          (one fused kernel)
+    """
+
+    def __init__(self, x0, regularization, rho, n_cg=10, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
+                 mask_static=False, factor_reg_static=0, slab=None):
+        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
+        self.reg, self.rho, self.n_cg = float(regularization), float(rho), int(n_cg)
+        self.x = self.x0.clone()
+        self.z = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
+        self.u = torch.zeros_like(self.z)
+        self.b = torch.empty_like(self.x0)
+        self.r = torch.empty_like(self.x0)
+        self.d = torch.empty_like(self.x0)
+        self.Ad = torch.empty_like(self.x0)
+        self.ws = self.geo.workspace()
+        self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
+        pl, s_ = self.plan, self.slab
+        sh = pl.on
+        if sh and min(nz_r for _, nz_r in s_.parts) < 2:
+            raise ValueError("the normal operator needs two halo planes: every rank must hold >= 2 planes")
+        self.sh = sh
+        self.h2_prev = self.new_plane(2) if sh and s_.prev is not None else None
+        self.h2_next = self.new_plane(2) if sh and s_.next is not None else None
+        self.ch_back, self.ch_fwd = pl.ch_back, pl.ch_fwd
+        self.wh_prev = self.new_plane() if pl.g_need_prev else None
+        self.wh_next = self.new_plane() if pl.g_need_next else None
+        self.ws_prev = self.new_plane() if pl.g_send_prev else None
+        self.ws_next = self.new_plane() if pl.g_send_next else None
+        self.sc = torch.zeros(4, dtype=torch.float64, device=self.device)   # rs, dAd, rs_new, spare
+
+    def _halo2(self, v):
+        self.slab.wait(self.plan.exchange_image2(v, self.h2_prev, self.h2_next))
+        return self.h2_prev, self.h2_next
+
+    def _normal(self, v, out, dot):
+        hp, hn = self._halo2(v)
+        _nv.check(self.lib.tv_normal_op(self.geo.ref, _nv.ptr(v), _nv.ptr(hp), _nv.ptr(hn), self.rho, _nv.ptr(out),
+                                        dot.data_ptr(), _nv.ptr(self.ws), self.stream))
+        self.slab.allreduce_sum_(dot)
+
+    def step(self, out):
+        """One outer iteration; out: fp64 device tensor [tv, fid] of this rank."""
+        g, lib, s, nz = self.geo, self.lib, self.slab, self.slab.nz
+        code = _nv.dtype_code(self.dtype)
+        plane = g.plane
+        # ---- rhs b = x0 + rho D^T (z - u), halos of (z - u) differenced on the boundary planes ----
+        if self.plan.g_send_next:
+            _nv.check(lib.tv_sub(code, plane, _nv.ptr(self.z[nz - 1, self.ch_back]), _nv.ptr(self.u[nz - 1, self.ch_back]),
+                                 _nv.ptr(self.ws_next), self.stream))
+        if self.plan.g_send_prev:
+            _nv.check(lib.tv_sub(code, plane, _nv.ptr(self.z[0, self.ch_fwd]), _nv.ptr(self.u[0, self.ch_fwd]),
+                                 _nv.ptr(self.ws_prev), self.stream))
+        s.wait(s.exchange(send_prev=self.ws_prev, send_next=self.ws_next, recv_prev=self.wh_prev, recv_next=self.wh_next))
+        _nv.check(lib.tv_DT_axpy(g.ref, _nv.ptr(self.z), _nv.ptr(self.u), _nv.ptr(self.wh_prev), _nv.ptr(self.wh_next),
+                                 _nv.ptr(self.x0), self.rho, _nv.ptr(self.b), self.stream))
+        # ---- CG on (I + rho D^T D) x = b -----------------------------------------------------------
+        rs, dAd, rs_new, spare = self.sc[0:1], self.sc[1:2], self.sc[2:3], self.sc[3:4]
+        self._normal(self.x, self.Ad, spare)
+        _nv.check(lib.tv_sub(code, self.x.numel(), _nv.ptr(self.b), _nv.ptr(self.Ad), _nv.ptr(self.r), self.stream))
+        self.d.copy_(self.r)
+        _nv.check(lib.tv_dot(g.ref, _nv.ptr(self.r), _nv.ptr(self.r), rs.data_ptr(), _nv.ptr(self.ws), self.stream))
+        s.allreduce_sum_(rs)
+        for _ in range(self.n_cg):
+            self._normal(self.d, self.Ad, dAd)
+            _nv.check(lib.tv_cg_step1(g.ref, _nv.ptr(self.x), _nv.ptr(self.r), _nv.ptr(self.d), _nv.ptr(self.Ad),
+                                      rs.data_ptr(), dAd.data_ptr(), rs_new.data_ptr(), _nv.ptr(self.ws), self.stream))
+            s.allreduce_sum_(rs_new)
+            _nv.check(lib.tv_cg_step2(g.ref, _nv.ptr(self.d), _nv.ptr(self.r), rs_new.data_ptr(), rs.data_ptr(), self.stream))
+            rs.copy_(rs_new)
+        # ---- z / u update (needs one x halo plane per side: reuse the two-plane exchange) ---------------
+        hp, hn = self._halo2(self.x)
+        xp = hp[1:2] if hp is not None else None      # plane z0-1
+        xn = hn[0:1] if hn is not None else None      # plane z0+nz
+        _nv.check(lib.tv_admm_zu(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.z), _nv.ptr(self.u),
+                                 self.reg / self.rho, out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        # fidelity 1/2 |x - x0|^2 = 1/2 <x-x0, x-x0>: r is free now
+        _nv.check(lib.tv_sub(code, self.x.numel(), _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(self.r), self.stream))
+        _nv.check(lib.tv_dot(g.ref, _nv.ptr(self.r), _nv.ptr(self.r), out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def run(self, n_outer):
+        hist = torch.zeros((n_outer, 2), dtype=torch.float64, device=self.device)
+        for k in range(n_outer):
+            self.step(hist[k])
+        self.slab.allreduce_sum_(hist)
+        h = hist.cpu().numpy()
+        return 0.5 * h[:, 1] + self.reg * h[:, 0]
+
+    def result(self):
+        return self.x

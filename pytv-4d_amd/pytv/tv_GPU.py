@@ -1,0 +1,81 @@
+"""Drop-in replacement of ``pytv.tv_GPU`` (PyTV-4D v1.1.2) on AMD MI355X.
+
+``tv_<scheme>(img, ...)`` returns the total variation of ``img`` and the reference's sub-gradient
+(pytv/tv_GPU.py:47,142,217,290).  The reference materialises D(img) (Nd x the image), then runs
+3..14 sliced ``G[...] += +-D/norm`` updates; here one fused HIP pass writes |D img| per voxel and the
+TV partial sums, a second one gathers G straight from ``img`` and the norms -- the gradient array is
+never stored (C-ABI ``tv_subgrad``, include/pytv4d.h).
+
+Conventions kept: ``mask`` zeroes the caller's array in place; the TV
+value is always a 0-d numpy array; G (and grad_norms) are numpy unless ``return_pytorch_tensor``;
+grad_norms has zeros replaced by +inf; the sub-gradient uses unit weights in the adjoint.
+"""
+import numpy as np
+import torch
+
+from . import _native as _nv
+from .tv_operators_GPU import _to_device
+
+__all__ = ["tv_hybrid", "tv_downwind", "tv_upwind", "tv_central"]
+
+
+def _has_mask(mask):
+    # the reference tests ``mask != []`` (tv_GPU.py:79), which raises for ndarray masks under NumPy 2
+    return mask is not None and not isinstance(mask, bool) and len(mask) > 0
+
+
+def tv_subgradient_device(x, scheme, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0):
+    """Device-resident core: x is a contiguous fp32/fp64 device tensor (Nz, M, Ny, Nx).
+    Returns (tv 0-d fp64 device tensor, G, grad_norms view) without any host synchronisation."""
+    geo = _nv.Geometry(tuple(x.shape), scheme, x.dtype, x.device, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
+    nz, m, ny, nx = geo.shape
+    G = torch.empty_like(x)
+    norms_ext = torch.empty((nz + 2, m, ny, nx), dtype=x.dtype, device=x.device)
+    tv = geo.scalar()
+    _nv.check(_nv.lib().tv_subgrad(geo.ref, _nv.ptr(x), None, None, _nv.ptr(G), _nv.ptr(norms_ext), _nv.ptr(tv),
+                                   _nv.ptr(geo.workspace()), _nv.current_stream(x.device)))
+    return tv, G, norms_ext[1:nz + 1]
+
+
+def _tv(scheme, img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_static, return_pytorch_tensor,
+        return_grad_norms):
+    if _has_mask(mask):
+        img[~mask] = 0                      # in place on the caller's array, as the reference does
+    x, _ = _to_device(img)
+    if x.dim() != 4:
+        raise ValueError("img must be 4-D (Nz, M, N, N), got shape %s" % (tuple(x.shape),))
+    tv, G, gn = tv_subgradient_device(x, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
+    tv = tv.detach().cpu().numpy()          # 0-d numpy, always (tv_GPU.py:85 via compute_L21_norm)
+    if not return_grad_norms:
+        return (tv, G) if return_pytorch_tensor else (tv, G.detach().cpu().numpy())
+    if return_pytorch_tensor:
+        return tv, G, gn
+    return tv, G.detach().cpu().numpy(), gn.detach().cpu().numpy()
+
+
+def tv_hybrid(img, mask=[], reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0,
+              return_pytorch_tensor=False, return_grad_norms=False):
+    """TV and sub-gradient, hybrid discretisation.  Reference: tv_GPU.py:47-139."""
+    return _tv("hybrid", img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_static,
+               return_pytorch_tensor, return_grad_norms)
+
+
+def tv_downwind(img, mask=[], reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0,
+                return_pytorch_tensor=False, return_grad_norms=False):
+    """TV and sub-gradient, downwind discretisation.  Reference: tv_GPU.py:142-215."""
+    return _tv("downwind", img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_static,
+               return_pytorch_tensor, return_grad_norms)
+
+
+def tv_upwind(img, mask=[], reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0,
+              return_pytorch_tensor=False, return_grad_norms=False):
+    """TV and sub-gradient, upwind discretisation.  Reference: tv_GPU.py:217-288."""
+    return _tv("upwind", img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_static,
+               return_pytorch_tensor, return_grad_norms)
+
+
+def tv_central(img, mask=[], reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0,
+               return_pytorch_tensor=False, return_grad_norms=False):
+    """TV and sub-gradient, central discretisation.  Reference: tv_GPU.py:290-375."""
+    return _tv("central", img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_static,
+               return_pytorch_tensor, return_grad_norms)

@@ -39,3 +39,15 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_library():
+    """Make sure the HIP library exists (hipcc cross-compiles gfx950 without a GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pytv4d_build", os.path.join(PKG, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not mod.up_to_date():
+        mod.build(verbose=False)
+    yield

@@ -1,0 +1,434 @@
+"""GPU parity: the HIP path (through the Python shim -> C-ABI) against the CPU oracle and the golden
+vectors captured from the reference.  Everything here needs an MI355X (``-m gpu``).
+
+Tolerances: fp64 kernels 1e-11 (same arithmetic up to FMA contraction and summation order); fp32
+kernels ``rtol = atol = 1e-5`` against the fp64 oracle evaluated on the same (up-cast) fp32 input --
+the reference's own bar (pytv/tests.py:88-109) and BASELINE.json's north_star tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SCHEMES
+from oracle import tv_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+F64 = dict(rtol=1e-11, atol=1e-11)
+F32 = dict(rtol=1e-5, atol=1e-5)
+
+
+def _tol(dtype):
+    return F32 if np.dtype(dtype) == np.float32 else F64
+
+
+@pytest.fixture(scope="module")
+def pytv():
+    import pytv
+    return pytv
+
+
+def _golden_cases(scheme):
+    z = np.load(os.path.join(GOLDEN, "ops_%s.npz" % scheme))
+    for name in z["case_names"]:
+        name = str(name)
+        lz, mu, factor = z[name + "/params"]
+        mask = z[name + "/mask"]
+        mask = False if mask.ndim == 0 else mask
+        yield name, z, dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=factor)
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors from the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_golden_operators(pytv, scheme, dtype):
+    ops = pytv.tv_operators_GPU
+    for name, z, kw in _golden_cases(scheme):
+        x = z[name + "/x"].astype(dtype)
+        y = z[name + "/y"].astype(dtype)
+        exact_input = (z[name + "/x"].dtype == np.dtype(dtype))
+        # when the cast changed the input, compare with the oracle on the cast input instead
+        want_D = z[name + "/D"] if exact_input else orc.D(x.astype(np.float64), scheme, **kw)
+        want_DT = z[name + "/DT"] if exact_input else orc.D_T(y.astype(np.float64), scheme, **kw)
+        got_D = getattr(ops, "D_" + scheme)(x, **kw)
+        assert isinstance(got_D, np.ndarray) and got_D.dtype == dtype and got_D.shape == want_D.shape
+        np.testing.assert_allclose(got_D, want_D, err_msg="D %s %s" % (scheme, name), **_tol(dtype))
+        got_DT = getattr(ops, "D_T_" + scheme)(y, **kw)
+        np.testing.assert_allclose(got_DT, want_DT, err_msg="DT %s %s" % (scheme, name), **_tol(dtype))
+        got_DTD = getattr(ops, "D_T_" + scheme)(got_D, **kw)
+        want_DTD = orc.D_T(want_D.astype(np.float64), scheme, **kw)
+        np.testing.assert_allclose(got_DTD, want_DTD, err_msg="DTD %s %s" % (scheme, name), **_tol(dtype))
+        l21, norms = ops.compute_L21_norm(want_D.astype(dtype), return_array=True)
+        wl21, wnorms = orc.compute_L21_norm(want_D.astype(dtype).astype(np.float64), return_array=True)
+        assert isinstance(l21, np.ndarray) and l21.ndim == 0
+        np.testing.assert_allclose(float(l21), wl21, rtol=_tol(dtype)["rtol"])
+        np.testing.assert_allclose(norms.cpu().numpy(), wnorms, **_tol(dtype))
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_golden_tv_and_subgradient(pytv, scheme, dtype):
+    for name, z, kw in _golden_cases(scheme):
+        x = z[name + "/x"].astype(dtype)
+        exact_input = (z[name + "/x"].dtype == np.dtype(dtype))
+        if exact_input:
+            wtv, wG, wgn = z[name + "/tv"], z[name + "/G"], z[name + "/grad_norms"]
+        else:
+            wtv, wG, wgn = orc.tv(x.astype(np.float64), scheme, return_grad_norms=True, **kw)
+        tv, G, gn = getattr(pytv.tv_GPU, "tv_" + scheme)(x.copy(), return_grad_norms=True, **kw)
+        assert isinstance(tv, np.ndarray) and tv.ndim == 0
+        assert isinstance(G, np.ndarray) and G.dtype == dtype and isinstance(gn, np.ndarray)
+        np.testing.assert_allclose(float(tv), wtv, rtol=_tol(dtype)["rtol"], err_msg="%s %s" % (scheme, name))
+        np.testing.assert_allclose(G, wG, err_msg="G %s %s" % (scheme, name), **_tol(dtype))
+        assert np.array_equal(np.isinf(gn), np.isinf(wgn)), (scheme, name)
+        fin = np.isfinite(wgn)
+        np.testing.assert_allclose(gn[fin], wgn[fin], **_tol(dtype))
+        tv2, G2 = getattr(pytv.tv_GPU, "tv_" + scheme)(x.copy(), **kw)
+        assert np.array_equal(G2, G)
+
+
+def test_readme_known_answer(pytv):
+    # README.md:76-93: 532166.8251801673 (CPU) / 532166.8 (GPU), |G1 - G2| < 1e-5
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+    np.random.seed(0)
+    x = np.random.rand(20, 4, 100, 100)
+    tv64, G64 = pytv.tv_GPU.tv_hybrid(x)
+    assert abs(float(tv64) - 532166.8251801673) < 1e-6
+    tv32, G32 = pytv.tv_GPU.tv_hybrid(x.astype(np.float32))
+    assert abs(float(tv32) - 532166.8251801673) < 1e-5 * 532166.8
+    _, G_ref = orc.tv(x, "hybrid")
+    np.testing.assert_allclose(G64, G_ref, **F64)
+    assert np.max(np.abs(G32 - G_ref)) < 5e-5          # fp32 input rounding included
+    for scheme in SCHEMES:
+        for tag, mu in (("mu0", 0.0), ("mu2m5", 2 ** -5)):
+            k = ka["readme_%s_%s" % (scheme, tag)]
+            tv, G = getattr(pytv.tv_GPU, "tv_" + scheme)(x, reg_time=mu)
+            assert abs(float(tv) - k["tv"]) <= 1e-12 * k["tv"], (scheme, tag)
+            np.testing.assert_allclose((G * G).sum(), k["G_sq_sum"], rtol=1e-11)
+            probe = G[[0, 7, 19, 3], [0, 1, 3, 2], [0, 50, 99, 17], [0, 31, 99, 64]]
+            np.testing.assert_allclose(probe, k["G_probe"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_impulse_5x5(pytv, scheme):
+    k = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["impulse5_" + scheme]
+    A = np.zeros((1, 1, 5, 5))
+    A[0, 0, 2, 2] = 1.0
+    tv, G = getattr(pytv.tv_GPU, "tv_" + scheme)(A)
+    assert abs(float(tv) - k["tv"]) < 1e-14
+    np.testing.assert_allclose(G[0, 0], np.array(k["G"]), rtol=1e-14, atol=1e-15)
+
+
+# ------------------------------------------------------------------------------------------------
+# random shapes (vector path: Nx % 4 == 0; scalar path otherwise; non-square; ragged)
+# ------------------------------------------------------------------------------------------------
+SHAPES = [(1, 1, 16, 16), (5, 1, 12, 20), (4, 3, 8, 24), (3, 2, 9, 11), (6, 8, 16, 16), (2, 3, 7, 12),
+          (1, 4, 10, 8), (7, 1, 5, 4), (3, 5, 1, 16), (3, 5, 16, 1), (20, 4, 100, 100)]
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_random_shapes_all_paths(pytv, scheme, dtype):
+    ops, tvg = pytv.tv_operators_GPU, pytv.tv_GPU
+    rng = np.random.default_rng(21)
+    for shape in SHAPES:
+        if scheme == "central" and shape[0] == 2:
+            continue                     # unpinned in the reference, covered separately
+        for lz, mu, use_mask in ((1.0, 0.0, False), (0.0, 1.0, False), (2.5, 0.7, True)):
+            x = rng.standard_normal(shape).astype(dtype)
+            x[..., : max(1, shape[2] // 3), : max(1, shape[3] // 3)] = 0.5
+            mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
+            kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=3.0 if use_mask else 0)
+            x64 = x.astype(np.float64)
+            wD = orc.D(x64, scheme, **kw)
+            gD = getattr(ops, "D_" + scheme)(x, **kw)
+            np.testing.assert_allclose(gD, wD, err_msg="D %s %s" % (scheme, shape), **_tol(dtype))
+            y = rng.standard_normal(wD.shape).astype(dtype)
+            np.testing.assert_allclose(getattr(ops, "D_T_" + scheme)(y, **kw), orc.D_T(y.astype(np.float64), scheme, **kw),
+                                       err_msg="DT %s %s" % (scheme, shape), **_tol(dtype))
+            wtv, wG = orc.tv(x64, scheme, **kw)
+            tv, G = getattr(tvg, "tv_" + scheme)(x.copy(), **kw)
+            np.testing.assert_allclose(float(tv), wtv, rtol=_tol(dtype)["rtol"])
+            np.testing.assert_allclose(G, wG, err_msg="G %s %s %s" % (scheme, shape, (lz, mu)), **_tol(dtype))
+
+
+def test_central_two_planes_uses_forward_z(pytv):
+    # the reference raises for central with Nz == 2; the build (and the oracle) use the
+    # forward z stencil, the evident intent of pytv/tv_operators_CPU.py:338-340.  Unpinned.
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 3, 8, 8))
+    np.testing.assert_allclose(pytv.tv_operators_GPU.D_central(x, reg_time=1.0), orc.D(x, "central", 1.0, 1.0), **F64)
+    tv, G = pytv.tv_GPU.tv_central(x, reg_time=1.0)
+    wtv, wG = orc.tv(x, "central", 1.0, 1.0)
+    np.testing.assert_allclose(G, wG, **F64)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_adjointness(pytv, scheme):
+    # pytv/tests.py:363-404 / :111-185: <Y, D X> == <X, D^T Y>, fp32, tol 1e-4
+    ops = pytv.tv_operators_GPU
+    rng = np.random.default_rng(8)
+    geoms = [((1, 1, 100, 100), 1.0, 0.0), ((20, 1, 100, 100), 1.0, 0.0), ((20, 1, 100, 100), 0.0, 0.0)]
+    for m in (2, 3, 4, 8):
+        geoms += [((1, m, 100, 100), 1.0, 1.0), ((20, m, 100, 100), 1.0, 1.0), ((20, m, 100, 100), 0.0, 1.0)]
+    for shape, lz, mu in geoms:
+        x = rng.standard_normal(shape).astype(np.float32)
+        Dx = getattr(ops, "D_" + scheme)(x, reg_z_over_reg=lz, reg_time=mu)
+        y = rng.standard_normal(Dx.shape).astype(np.float32)
+        DTy = getattr(ops, "D_T_" + scheme)(y, reg_z_over_reg=lz, reg_time=mu)
+        lhs = np.sum(y.astype(np.float64) * Dx)
+        rhs = np.sum(x.astype(np.float64) * DTy)
+        assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (scheme, shape, lz, mu, lhs, rhs)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_2d_vs_3d_tiling(pytv, scheme):
+    # pytv/tests.py:187-245 restated with explicit reshapes
+    ops, tvg = pytv.tv_operators_GPU, pytv.tv_GPU
+    rng = np.random.default_rng(9)
+    img = rng.standard_normal((1, 1, 100, 100)).astype(np.float32)
+    Nz = 20
+    vol = np.tile(img, (Nz, 1, 1, 1))
+    tv2, G2 = getattr(tvg, "tv_" + scheme)(img.copy())
+    tv3, G3 = getattr(tvg, "tv_" + scheme)(vol.copy())
+    assert abs(float(tv3) / Nz - float(tv2)) <= 1e-5 * float(tv2)
+    np.testing.assert_allclose(G3[1], G2[0], **F32)
+    D2 = getattr(ops, "D_" + scheme)(img, reg_z_over_reg=0)
+    D3 = getattr(ops, "D_" + scheme)(vol, reg_z_over_reg=0)
+    assert np.array_equal(D3[1], D2[0])
+
+
+def test_return_conventions(pytv):
+    import torch
+    ops, tvg = pytv.tv_operators_GPU, pytv.tv_GPU
+    x = np.random.default_rng(1).standard_normal((3, 2, 8, 8)).astype(np.float32)
+    d = ops.D_hybrid(x, reg_time=1.0)
+    assert isinstance(d, np.ndarray) and d.shape == (3, 8, 2, 8, 8) and d.dtype == np.float32
+    d_t = ops.D_hybrid(x, reg_time=1.0, return_pytorch_tensor=True)
+    assert isinstance(d_t, torch.Tensor) and d_t.is_cuda
+    xt = torch.as_tensor(x)
+    d_t2 = ops.D_hybrid(xt, reg_time=1.0)                # torch in forces torch (device) out
+    assert isinstance(d_t2, torch.Tensor) and d_t2.is_cuda and torch.equal(d_t2, d_t)
+    assert isinstance(ops.D_T_hybrid(d_t, reg_time=1.0), torch.Tensor)
+    assert isinstance(ops.D_T_hybrid(d, reg_time=1.0), np.ndarray)
+    v = ops.compute_L21_norm(d)
+    assert isinstance(v, np.ndarray) and v.ndim == 0
+    v2, arr = ops.compute_L21_norm(d, return_array=True)
+    assert isinstance(v2, np.ndarray) and isinstance(arr, torch.Tensor)
+    v3, arr3 = ops.compute_L21_norm(d, return_array=True, return_pytorch_tensor=True)
+    assert isinstance(v3, torch.Tensor) and v3.dim() == 0
+    tv, G = tvg.tv_hybrid(xt, reg_time=1.0)               # torch in, numpy G unless asked
+    assert isinstance(tv, np.ndarray) and tv.ndim == 0 and isinstance(G, np.ndarray)
+    tv, G, gn = tvg.tv_hybrid(x, reg_time=1.0, return_pytorch_tensor=True, return_grad_norms=True)
+    assert isinstance(tv, np.ndarray) and isinstance(G, torch.Tensor) and isinstance(gn, torch.Tensor)
+    # integer input behaves as float64
+    xi = (np.arange(64).reshape(1, 1, 8, 8) % 7).astype(np.int64)
+    np.testing.assert_allclose(ops.D_upwind(xi), orc.D(xi.astype(np.float64), "upwind"), **F64)
+    # mask zeroes the caller's array in place
+    xm = x.copy()
+    mask = np.zeros(x.shape, dtype=bool)
+    mask[:, :, 2:6, 2:6] = True
+    tvg.tv_upwind(xm, mask=mask)
+    assert np.all(xm[~mask] == 0) and np.array_equal(xm[mask], x[mask])
+    with pytest.raises(ValueError):
+        ops.D_hybrid(np.zeros((4, 4)))
+    with pytest.raises(ValueError):
+        ops.D_T_hybrid(np.zeros((3, 2, 2, 8, 8)), reg_time=1.0)   # too few channels
+
+
+# ------------------------------------------------------------------------------------------------
+# solvers: Chambolle-Pock / sub-gradient descent / ADMM against the oracle loops
+# ------------------------------------------------------------------------------------------------
+def _noisy(shape, seed, dtype):
+    truth = orc.phantom(shape, seed=seed, dtype=np.float64)
+    rng = np.random.RandomState(seed)
+    return (truth + 100.0 * rng.rand(*shape)).astype(dtype)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_cp_2d_trajectory_matches_reference_golden(pytv, scheme):
+    import torch
+    z = np.load(os.path.join(GOLDEN, "trajectories_2d.npz"))
+    noisy = z["noisy"]
+    _, nb_it, reg, _ = z["params"]
+    for dtype, rtol in ((np.float64, 1e-10), (np.float32, 1e-5)):
+        cp = pytv.solvers.ChambollePock(torch.as_tensor(noisy.astype(dtype)).cuda(), reg, scheme=scheme, tau=1 / 9)
+        loss = cp.run(int(nb_it))
+        np.testing.assert_allclose(loss, z["cp_loss_" + scheme], rtol=rtol)
+        atol = 1e-8 if dtype == np.float64 else 2e-3          # pixel values are O(100)
+        np.testing.assert_allclose(cp.result().cpu().numpy(), z["cp_final_" + scheme], rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape,lz,mu,use_mask", [((6, 1, 16, 16), 1.0, 0.0, False), ((5, 3, 12, 16), 1.0, 1.0, False),
+                                                   ((4, 4, 9, 10), 2.5, 0.5, True)])
+def test_cp_3d_4d_matches_oracle(pytv, scheme, shape, lz, mu, use_mask):
+    import torch
+    rng = np.random.default_rng(4)
+    mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
+    kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=4.0 if use_mask else 0)
+    for dtype, rtol, atol in ((np.float64, 1e-10, 1e-9), (np.float32, 1e-5, 2e-3)):
+        x0 = _noisy(shape, 5, dtype)
+        wx, wloss = orc.chambolle_pock(x0.astype(np.float64), 40, 25.0, scheme=scheme, **kw)
+        cp = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 25.0, scheme=scheme, **kw)
+        loss = cp.run(40)
+        np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s" % (scheme, shape))
+        np.testing.assert_allclose(cp.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_subgradient_descent_head_matches_oracle(pytv, scheme):
+    import torch
+    z = np.load(os.path.join(GOLDEN, "trajectories_2d.npz"))
+    noisy = z["noisy"]
+    _, _, reg, step = z["params"]
+    sg = pytv.solvers.SubgradientDescent(torch.as_tensor(noisy).cuda(), reg, step, scheme=scheme)
+    loss = sg.run(40)
+    np.testing.assert_allclose(loss, z["gd_loss_" + scheme][:40], rtol=1e-9)
+    # the numpy-in/numpy-out README loop (README.md:118-124) through the drop-in API
+    est = noisy.copy()
+    for it in range(5):
+        tv, G = getattr(pytv.tv_GPU, "tv_" + scheme)(est)
+        est += -step * ((est - noisy) + reg * G)
+        l = 0.5 * np.sum(np.square(est - noisy)) + reg * tv
+        np.testing.assert_allclose(l, z["gd_loss_" + scheme][it], rtol=1e-10)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape,lz,mu", [((1, 1, 16, 16), 1.0, 0.0), ((5, 3, 8, 12), 1.5, 0.5)])
+def test_admm_matches_oracle(pytv, scheme, shape, lz, mu):
+    import torch
+    for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-5, 5e-3)):
+        x0 = _noisy(shape, 6, dtype)
+        wx, wloss = orc.admm(x0.astype(np.float64), 8, 25.0, 0.05, 6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu)
+        ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 25.0, 0.05, n_cg=6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu)
+        loss = ad.run(8)
+        np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s" % (scheme, shape))
+        np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------------
+# z-slab halos on ONE GPU: every slab call with halos == the unsharded call (slab edges are where
+# the bugs live; the multi-process exchange itself is covered on CPU with gloo in test_slab_gloo.py)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("cuts", [(0, 3, 7), (0, 2, 4, 7), (0, 1, 2, 3, 4, 5, 6, 7)])
+def test_slab_calls_equal_unsharded(pytv, scheme, cuts):
+    import torch
+    from pytv import _native as nv
+    lib = nv.lib()
+    rng = np.random.default_rng(12)
+    shape = (7, 3, 8, 12)
+    kw = dict(reg_z_over_reg=1.7, reg_time=0.6)
+    x = torch.as_tensor(rng.standard_normal(shape)).cuda()
+    full = nv.Geometry(shape, scheme, x.dtype, x.device, **kw)
+    nd, nzg = full.nd, shape[0]
+    y = torch.as_tensor(rng.standard_normal(full.grad_shape)).cuda()
+    st = nv.current_stream(x.device)
+    D_full = torch.empty(full.grad_shape, dtype=x.dtype, device=x.device)
+    nv.check(lib.tv_D(full.ref, nv.ptr(x), None, None, nv.ptr(D_full), st))
+    DT_full = torch.empty_like(x)
+    nv.check(lib.tv_DT(full.ref, nv.ptr(y), None, None, nv.ptr(DT_full), st))
+    tv_full, G_full, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, **kw)
+    A_full = torch.empty_like(x)
+    dot_full = full.scalar()
+    nv.check(lib.tv_normal_op(full.ref, nv.ptr(x), None, None, 0.3, nv.ptr(A_full), nv.ptr(dot_full), nv.ptr(full.workspace()), st))
+    per = 2 if scheme == "hybrid" else 1
+    ch_back, ch_fwd = 2 * per, 2 * per + (1 if scheme == "hybrid" else 0)
+    tv_sum, dot_sum = 0.0, 0.0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if scheme == "central" and False:
+            pass
+        g = nv.Geometry((b - a,) + shape[1:], scheme, x.dtype, x.device, nz_global=nzg, z0=a, **kw)
+        assert g.nd == nd
+        xs = x[a:b].contiguous()
+        xp1 = x[a - 1:a].contiguous() if a > 0 else None
+        xn1 = x[b:b + 1].contiguous() if b < nzg else None
+        d = torch.empty(g.grad_shape, dtype=x.dtype, device=x.device)
+        nv.check(lib.tv_D(g.ref, nv.ptr(xs), nv.ptr(xp1), nv.ptr(xn1), nv.ptr(d), st))
+        assert torch.equal(d, D_full[a:b]), (scheme, a, b)
+        ys = y[a:b].contiguous()
+        yp = y[a - 1, ch_back].contiguous() if a > 0 else None
+        yn = y[b, ch_fwd].contiguous() if b < nzg else None
+        o = torch.empty_like(xs)
+        nv.check(lib.tv_DT(g.ref, nv.ptr(ys), nv.ptr(yp), nv.ptr(yn), nv.ptr(o), st))
+        assert torch.equal(o, DT_full[a:b]), (scheme, a, b)
+        # two-plane halos (zero-filled where the global plane does not exist: never read)
+        def two(lo):
+            buf = torch.zeros((2,) + shape[1:], dtype=x.dtype, device=x.device)
+            for k in range(2):
+                if 0 <= lo + k < nzg:
+                    buf[k] = x[lo + k]
+            return buf
+        xp2 = two(a - 2) if a > 0 else None
+        xn2 = two(b) if b < nzg else None
+        G = torch.empty_like(xs)
+        ne = torch.empty((b - a + 2,) + shape[1:], dtype=x.dtype, device=x.device)
+        tvs = g.scalar()
+        nv.check(lib.tv_subgrad(g.ref, nv.ptr(xs), nv.ptr(xp2), nv.ptr(xn2), nv.ptr(G), nv.ptr(ne), nv.ptr(tvs), nv.ptr(g.workspace()), st))
+        assert torch.equal(G, G_full[a:b]), (scheme, a, b)
+        tv_sum += float(tvs)
+        A = torch.empty_like(xs)
+        dt = g.scalar()
+        nv.check(lib.tv_normal_op(g.ref, nv.ptr(xs), nv.ptr(xp2), nv.ptr(xn2), 0.3, nv.ptr(A), nv.ptr(dt), nv.ptr(g.workspace()), st))
+        assert torch.equal(A, A_full[a:b]), (scheme, a, b)
+        dot_sum += float(dt)
+    assert abs(tv_sum - float(tv_full)) <= 1e-12 * abs(float(tv_full))
+    assert abs(dot_sum - float(dot_full)) <= 1e-12 * abs(float(dot_full))
+
+
+def test_missing_halo_is_an_error(pytv):
+    import torch
+    from pytv import _native as nv
+    x = torch.zeros((3, 1, 8, 8), device="cuda")
+    g = nv.Geometry((3, 1, 8, 8), "hybrid", x.dtype, x.device, nz_global=9, z0=3)
+    d = torch.empty(g.grad_shape, device="cuda")
+    rc = nv.lib().tv_D(g.ref, nv.ptr(x), None, None, nv.ptr(d), nv.current_stream(x.device))
+    assert rc == -2
+    with pytest.raises(ValueError):
+        nv.check(rc)
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties at a BASELINE configuration (configs[1]: 3-D 256 x 512 x 512, hybrid)
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties_config1(pytv):
+    import torch
+    from pytv import _native as nv
+    lib = nv.lib()
+    shape = (256, 1, 512, 512)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(shape, device="cuda", generator=gen)
+    geo = nv.Geometry(shape, "hybrid", x.dtype, x.device)
+    st = nv.current_stream(x.device)
+    d = torch.empty(geo.grad_shape, device="cuda")
+    nv.check(lib.tv_D(geo.ref, nv.ptr(x), None, None, nv.ptr(d), st))
+    y = torch.randn(geo.grad_shape, device="cuda", generator=gen)
+    o = torch.empty_like(x)
+    nv.check(lib.tv_DT(geo.ref, nv.ptr(y), None, None, nv.ptr(o), st))
+    # adjointness in fp64 accumulation
+    lhs = torch.sum(y.double() * d.double()).item()
+    rhs = torch.sum(x.double() * o.double()).item()
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+    # the down channels are the up channels shifted by one (pytv/tv_operators_CPU.py:123-127,137)
+    assert torch.equal(d[:, 2, :, 1:, :], d[:, 0, :, :-1, :]) and torch.equal(d[:, 3, :, :, 1:], d[:, 1, :, :, :-1])
+    assert torch.equal(d[1:, 5], d[:-1, 4])
+    assert torch.count_nonzero(d[:, 0, :, -1, :]) == 0 and torch.count_nonzero(d[-1, 4]) == 0
+    # linearity: D(2x) == 2 D(x) exactly in binary floating point
+    d2 = torch.empty_like(d)
+    x2 = 2 * x
+    nv.check(lib.tv_D(geo.ref, nv.ptr(x2), None, None, nv.ptr(d2), st))
+    assert torch.equal(d2, 2 * d)
+    # TV three ways: fused sub-gradient pass, l21 of the materialised gradient, torch on the gradient
+    tv_a, G, _ = pytv.tv_GPU.tv_subgradient_device(x, "hybrid")
+    tv_b = pytv.tv_operators_GPU.compute_L21_norm(d)
+    tv_c = torch.sqrt((d.double() ** 2).sum(dim=1)).sum().item()
+    assert abs(float(tv_a) - tv_c) <= 1e-9 * tv_c and abs(float(tv_b) - tv_c) <= 1e-9 * tv_c
+    # sub-gradient == unit-weight D^T (D/|D|)  (SURVEY 3.3 identity), checked at full size
+    n = torch.sqrt((d * d).sum(dim=1, keepdim=True))
+    gfield = torch.where(n > 0, d / n, torch.zeros_like(d))
+    nv.check(lib.tv_DT(geo.ref, nv.ptr(gfield), None, None, nv.ptr(o), st))
+    assert torch.allclose(G, o, rtol=1e-5, atol=1e-5)
