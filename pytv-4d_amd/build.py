@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """Build libpytv4d_hip.so (gfx950) in-tree with hipcc.  No cmake, no JIT cache: the .so sits next
-to the Python package so that it travels with the repository snapshot to the GPU box."""
+to the Python package so that it travels with the repository snapshot to the GPU box.  The three
+translation units are compiled in parallel and linked with hipcc."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "tv_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "tv_device.h"), os.path.join(os.path.dirname(HERE), "include", "pytv4d.h")]
+CSRC = os.path.join(HERE, "csrc")
+UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip"]
+HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h"]
+DEPS = [os.path.join(CSRC, f) for f in UNITS + HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "pytv4d.h")]
 OUT = os.path.join(HERE, "pytv", "libpytv4d_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-variable",
+         "-Wno-unused-but-set-variable", "-Wno-unused-function"]
 
 
 def hipcc():
-    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
-        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
             return cand
     return "hipcc"
 
@@ -22,11 +29,22 @@ def up_to_date():
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
 
 
+def _compile(unit, verbose):
+    obj = os.path.join(OBJDIR, unit.replace(".hip", ".o"))
+    cmd = [hipcc()] + FLAGS + os.environ.get("TV_EXTRA_FLAGS", "").split() + ["-c", os.path.join(CSRC, unit), "-o", obj]
+    if verbose:
+        print("[pytv build] " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build(force=False, verbose=True):
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-o", OUT, SRC]
+    os.makedirs(OBJDIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+        objs = list(ex.map(lambda u: _compile(u, verbose), UNITS))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
     if verbose:
         print("[pytv build] " + " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,0 +1,195 @@
+// tv_host.h -- host-side helpers shared by the translation units of libpytv4d_hip.so:
+// error reporting, tv_geom -> DG, launch geometry, partial-sum reduction, dispatch tables.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <initializer_list>
+#include <string>
+
+#include "../../include/pytv4d.h"
+#include "tv_device.h"
+
+using namespace tv;
+
+namespace tv { __global__ void k_reduce(const double* in, long long n, double* out); }
+
+inline thread_local std::string g_err;
+inline int fail(int code, const char* msg) {
+    g_err = msg;
+    return code;
+}
+inline int hipfail(hipError_t e, const char* where) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return (int)e;
+}
+#define HIP_TRY(call)                                         \
+    do {                                                      \
+        hipError_t e__ = (call);                              \
+        if (e__ != hipSuccess) return hipfail(e__, #call);    \
+    } while (0)
+
+inline int make_dg(const tv_geom* g, DG& d) {
+    if (g == nullptr) return fail(TV_E_ARG, "tv_geom is NULL");
+    if (g->nz < 1 || g->m < 1 || g->ny < 1 || g->nx < 1) return fail(TV_E_ARG, "every dimension must be >= 1");
+    if (g->nz_global < g->nz || g->z0 < 0 || g->z0 + g->nz > g->nz_global)
+        return fail(TV_E_ARG, "slab [z0, z0+nz) must lie inside [0, nz_global)");
+    if (g->scheme < 0 || g->scheme > 3) return fail(TV_E_ARG, "unknown scheme");
+    if (g->dtype != TV_F32 && g->dtype != TV_F64) return fail(TV_E_ARG, "unknown dtype");
+    if (g->nz_global > 60000 || g->m > 65535 || g->ny > (1 << 24) || g->nx > (1 << 24))
+        return fail(TV_E_ARG, "dimension too large for the launch grid");
+    if (!(g->reg_z_over_reg >= 0.0) || !(g->reg_time >= 0.0) || !(g->factor_reg_static >= 0.0))
+        return fail(TV_E_ARG, "weights must be non-negative numbers");
+    d.nz = (int)g->nz; d.m = (int)g->m; d.ny = (int)g->ny; d.nx = (int)g->nx;
+    d.nzg = (int)g->nz_global; d.z0 = (int)g->z0;
+    d.za = (g->nz_global > 1 && g->reg_z_over_reg > 0.0) ? 1 : 0;
+    d.ta = (g->m > 1 && g->reg_time > 0.0) ? 1 : 0;
+    const int per = (g->scheme == TV_HYBRID) ? 2 : 1;
+    d.nd = per * (2 + d.za + d.ta);
+    d.ch_z = 2 * per;
+    d.ch_t = d.ch_z + (d.za ? per : 0);
+    d.z_two = (g->scheme == TV_CENTRAL && g->nz_global == 2) ? 1 : 0;
+    d.t_two = (g->scheme == TV_CENTRAL && g->m == 2) ? 1 : 0;
+    d.s_t = (long long)g->ny * g->nx;
+    d.s_z = d.s_t * g->m;
+    d.s_dz = d.s_z * d.nd;
+    d.mask = g->mask_static;
+    return 0;
+}
+
+template <typename T> inline WT<T> make_w(const tv_geom* g) {
+    WT<T> w;
+    w.wz = (T)std::sqrt(g->reg_z_over_reg);
+    w.wt = (T)std::sqrt(g->reg_time);
+    w.sf = (T)std::sqrt(g->factor_reg_static);
+    return w;
+}
+
+struct LC { dim3 grid, block; long long nblocks; };
+inline LC launch_cfg(const DG& d, int V, int planes) {
+    const int nxv = d.nx / V;
+    int bx = 1;
+    while (bx < nxv && bx < 64) bx <<= 1;
+    const int by = 256 / bx;
+    const long long tx = (nxv + bx - 1) / bx, ty = (d.ny + by - 1) / by;
+    LC lc;
+    lc.block = dim3(bx, by, 1);
+    lc.grid = dim3((unsigned)(tx * ty), (unsigned)d.m, (unsigned)planes);
+    lc.nblocks = tx * ty * d.m * planes;
+    return lc;
+}
+
+static const int kFlatBlocks = 2048;    // grid-stride kernels: 256 CUs x 8 blocks
+static const int kStage = 256;          // second-level partials
+
+// layout of the scratch buffer: [partials ... nmax][stage kStage]
+inline long long max_partials(const DG& d) {
+    LC lc = launch_cfg(d, 1, d.nz + 2);
+    return lc.nblocks > kFlatBlocks ? lc.nblocks : kFlatBlocks;
+}
+
+inline int reduce_partials(double* ws, long long n, long long nmax, double* result, hipStream_t st) {
+    if (n <= 4096) {
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st, ws, n, result);
+    } else {
+        double* stage = ws + nmax;
+        hipLaunchKernelGGL(k_reduce, dim3(kStage), dim3(256), 0, st, ws, n, stage);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st, stage, (long long)kStage, result);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+inline bool aligned16(std::initializer_list<const void*> ps) {
+    for (const void* p : ps)
+        if (p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15u) != 0) return false;
+    return true;
+}
+
+// call f.template operator()<S, T, V>() for the run-time (scheme, dtype, vec)
+template <typename F> inline int dispatch(int scheme, int dtype, bool vec, F&& f) {
+#define TV_CASE(SC)                                                                  \
+    case SC:                                                                         \
+        if (dtype == TV_F32) {                                                       \
+            if (vec) return f.template operator()<SC, float, 4>();                   \
+            return f.template operator()<SC, float, 1>();                            \
+        }                                                                            \
+        return f.template operator()<SC, double, 1>();
+    switch (scheme) {
+        TV_CASE(0) TV_CASE(1) TV_CASE(2) TV_CASE(3)
+    }
+#undef TV_CASE
+    return fail(TV_E_ARG, "unknown scheme");
+}
+
+// ---- plane-marching fast path (tv_march.h): fp32, 16-byte lanes, M in {1,2,3,4,8,16} ---------------
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
+    if (g->dtype != TV_F32 || !vec || d.nx < 128) return false;
+    if (env_int("TV_NO_MARCH", 0)) return false;
+    return d.m == 1 || d.m == 2 || d.m == 3 || d.m == 4 || d.m == 8 || d.m == 16;
+}
+inline int march_zchunk(const DG& d) {
+    int zc = env_int("TV_ZCHUNK", 16);
+    if (zc < 1) zc = 1;
+    if (zc > d.nz) zc = d.nz;
+    return zc;
+}
+inline LC march_cfg(const DG& d, int zchunk) {
+    const long long tx = (d.nx / 4 + 63) / 64, ty = (d.ny + 3) / 4, nch = (d.nz + zchunk - 1) / zchunk;
+    LC lc;
+    lc.block = dim3(64, 4, 1);
+    lc.grid = dim3((unsigned)(tx * ty), (unsigned)nch, 1);
+    lc.nblocks = tx * ty * nch;
+    return lc;
+}
+template <typename F> inline int dispatch_sm(int scheme, int m, F&& f) {
+#define TV_CASE_M(SC)                                              \
+    case SC:                                                       \
+        switch (m) {                                               \
+            case 1: return f.template operator()<SC, 1>();         \
+            case 2: return f.template operator()<SC, 2>();         \
+            case 3: return f.template operator()<SC, 3>();         \
+            case 4: return f.template operator()<SC, 4>();         \
+            case 8: return f.template operator()<SC, 8>();         \
+            case 16: return f.template operator()<SC, 16>();       \
+        }                                                          \
+        break;
+    switch (scheme) { TV_CASE_M(0) TV_CASE_M(1) TV_CASE_M(2) TV_CASE_M(3) }
+#undef TV_CASE_M
+    return fail(TV_E_ARG, "unsupported (scheme, M) for the marching path");
+}
+inline int check_x_halos(const tv_geom* g, const DG& d, const void* xp, const void* xn) {
+    if (!d.za) return 0;
+    const bool need_prev = (g->scheme != TV_UPWIND), need_next = (g->scheme != TV_DOWNWIND);
+    if (need_prev && g->z0 > 0 && xp == nullptr) return fail(TV_E_HALO, "previous-slab halo plane required");
+    if (need_next && g->z0 + g->nz < g->nz_global && xn == nullptr) return fail(TV_E_HALO, "next-slab halo plane required");
+    return 0;
+}
+inline int check_y_halos(const tv_geom* g, const DG& d, const void* yp, const void* yn) {
+    if (!d.za) return 0;
+    // backward-looking adjoint (upwind-type, central) reads the previous slab; forward-looking the next
+    const bool need_prev = (g->scheme != TV_DOWNWIND), need_next = (g->scheme != TV_UPWIND);
+    if (need_prev && g->z0 > 0 && yp == nullptr) return fail(TV_E_HALO, "previous-slab gradient halo required");
+    if (need_next && g->z0 + g->nz < g->nz_global && yn == nullptr) return fail(TV_E_HALO, "next-slab gradient halo required");
+    return 0;
+}
+
+// ---- plane-marching launchers, defined in tv_march_D.hip / tv_march_DT.hip ---------------------------
+namespace tvm {
+int D_store(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb, float* dout);
+int D_cp_dual(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
+              float* q, float sigma, float inv_lambda, double* partials);
+int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
+              float* z, float* u, float thresh, double* partials);
+int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb, float* out);
+int DT_axpy(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
+            float* out, const float* base, float alpha);
+int DT_cp_primal(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
+                 float* x, const float* x0, float* p, float tau, float sigma_a, float inv_1p_sigma_a, double* partials);
+}  // namespace tvm

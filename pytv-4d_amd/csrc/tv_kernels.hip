@@ -14,247 +14,10 @@
 // Per-voxel definitions follow SURVEY 8a-1 / 8a-2, i.e. pytv/tv_operators_CPU.py:117-154,198-218,
 // 264-284,330-358 (D) and :398-448,487-516,554-583,622-658 (D^T); the sub-gradient follows
 // pytv/tv_CPU.py:91-126,176-190,239-253,302-330.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <initializer_list>
-#include <string>
-#include <type_traits>
-
-#include "../../include/pytv4d.h"
-#include "tv_device.h"
+#include "tv_host.h"
+#include "tv_stencil.h"
 
 namespace tv {
-
-// =============================================================================================
-// neighbourhood of x around one voxel-vector
-// =============================================================================================
-template <typename T, int V> struct XN {
-    Vec<T, V> c;                 // centre
-    Vec<T, V> nr, pr;            // next / previous row
-    Vec<T, V> nc, pc;            // next / previous column (shifted vectors)
-    Vec<T, V> nz, pz;            // next / previous plane
-    Vec<T, V> nt, pt;            // next / previous frame
-    bool h_nr, h_pr, h_nz, h_pz, h_nt, h_pt;
-    int col0;
-};
-
-template <typename T, int V, bool NEXT, bool PREV>
-__device__ __forceinline__ void load_xn(const DG& g, const T* plane_c, const T* plane_p, const T* plane_n,
-                                        const Coord& c, XN<T, V>& o) {
-    const long long off = (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
-    const T* p = plane_c + off;
-    o.c = vload<T, V>(p);
-    o.col0 = c.col0;
-    const Vec<T, V> zero = vsplat<T, V>(T(0));
-    o.nr = o.pr = o.nc = o.pc = o.nz = o.pz = o.nt = o.pt = zero;
-    o.h_nr = o.h_pr = o.h_nz = o.h_pz = o.h_nt = o.h_pt = false;
-    if (NEXT) {
-        o.h_nr = (c.y + 1 < g.ny);
-        if (o.h_nr) o.nr = vload<T, V>(p + g.nx);
-        const T tail = (c.col0 + V < g.nx) ? p[V] : T(0);
-        o.nc = shift_left<T, V>(o.c, tail);
-        if (g.za) {
-            o.h_nz = (plane_n != nullptr);
-            if (o.h_nz) o.nz = vload<T, V>(plane_n + off);
-        }
-        if (g.ta) {
-            o.h_nt = (c.t + 1 < g.m);
-            if (o.h_nt) o.nt = vload<T, V>(p + g.s_t);
-        }
-    }
-    if (PREV) {
-        o.h_pr = (c.y > 0);
-        if (o.h_pr) o.pr = vload<T, V>(p - g.nx);
-        const T head = (c.col0 > 0) ? p[-1] : T(0);
-        o.pc = shift_right<T, V>(o.c, head);
-        if (g.za) {
-            o.h_pz = (plane_p != nullptr);
-            if (o.h_pz) o.pz = vload<T, V>(plane_p + off);
-        }
-        if (g.ta) {
-            o.h_pt = (c.t > 0);
-            if (o.h_pt) o.pt = vload<T, V>(p - g.s_t);
-        }
-    }
-}
-
-// =============================================================================================
-// gradient channels of one voxel-vector, in SLOT order
-//   non-hybrid: 0 rows, 1 cols, 2 z, 3 t
-//   hybrid    : 0 row-up, 1 col-up, 2 row-down, 3 col-down, 4 z-up, 5 z-down, 6 t-up, 7 t-down
-// =============================================================================================
-template <int S, typename T, int V>
-__device__ __forceinline__ void d_slots(const DG& g, const WT<T>& w, const XN<T, V>& n, const Vec<T, V>& mf,
-                                        Vec<T, V> (&o)[8]) {
-    const Vec<T, V> zero = vsplat<T, V>(T(0));
-    Vec<T, V> f_r = zero, f_c = zero, f_z = zero, f_t = zero;   // forward
-    Vec<T, V> b_r = zero, b_c = zero, b_z = zero, b_t = zero;   // backward
-    Vec<T, V> c_r = zero, c_c = zero, c_z = zero, c_t = zero;   // central
-    constexpr bool FW = (S == UPWIND || S == HYBRID || S == CENTRAL);   // central needs fwd for 2-point axes
-    constexpr bool BW = (S == DOWNWIND || S == HYBRID);
-    if (FW) {
-        if (n.h_nr) f_r = n.nr - n.c;
-#pragma unroll
-        for (int i = 0; i < V; ++i) f_c.v[i] = (n.col0 + i < g.nx - 1) ? n.nc.v[i] - n.c.v[i] : T(0);
-        if (n.h_nz) f_z = w.wz * (n.nz - n.c);
-        if (n.h_nt) f_t = (w.wt * (n.nt - n.c)) * mf;
-    }
-    if (BW) {
-        if (n.h_pr) b_r = n.c - n.pr;
-#pragma unroll
-        for (int i = 0; i < V; ++i) b_c.v[i] = (n.col0 + i > 0) ? n.c.v[i] - n.pc.v[i] : T(0);
-        if (n.h_pz) b_z = w.wz * (n.c - n.pz);
-        if (n.h_pt) b_t = (w.wt * (n.c - n.pt)) * mf;
-    }
-    if (S == CENTRAL) {
-        if (n.h_nr && n.h_pr) c_r = n.nr - n.pr;
-#pragma unroll
-        for (int i = 0; i < V; ++i)
-            c_c.v[i] = (n.col0 + i > 0 && n.col0 + i < g.nx - 1) ? n.nc.v[i] - n.pc.v[i] : T(0);
-        if (g.z_two) c_z = f_z;
-        else if (n.h_nz && n.h_pz) c_z = w.wz * (n.nz - n.pz);
-        if (g.t_two) c_t = f_t;
-        else if (n.h_nt && n.h_pt) c_t = (w.wt * (n.nt - n.pt)) * mf;
-    }
-    if (S == UPWIND) { o[0] = f_r; o[1] = f_c; o[2] = f_z; o[3] = f_t; }
-    if (S == DOWNWIND) { o[0] = b_r; o[1] = b_c; o[2] = b_z; o[3] = b_t; }
-    if (S == CENTRAL) {
-        const T h = T(0.5);
-        o[0] = h * c_r; o[1] = h * c_c; o[2] = h * c_z; o[3] = h * c_t;
-    }
-    if (S == HYBRID) {
-        const T s = Consts<T>::inv_sqrt2();
-        o[0] = s * f_r; o[1] = s * f_c; o[2] = s * b_r; o[3] = s * b_c;
-        o[4] = s * f_z; o[5] = s * b_z; o[6] = s * f_t; o[7] = s * b_t;
-    }
-    if (S != HYBRID) { o[4] = o[5] = o[6] = o[7] = zero; }
-}
-
-template <int I> using IC = std::integral_constant<int, I>;
-
-// f(slot, channel) for every ACTIVE channel; slot is a compile-time constant
-template <int S, typename F> __device__ __forceinline__ void for_each_channel(const DG& g, F&& f) {
-    f(IC<0>{}, 0);
-    f(IC<1>{}, 1);
-    if (S == HYBRID) {
-        f(IC<2>{}, 2);
-        f(IC<3>{}, 3);
-        if (g.za) { f(IC<4>{}, g.ch_z); f(IC<5>{}, g.ch_z + 1); }
-        if (g.ta) { f(IC<6>{}, g.ch_t); f(IC<7>{}, g.ch_t + 1); }
-    } else {
-        if (g.za) f(IC<2>{}, g.ch_z);
-        if (g.ta) f(IC<3>{}, g.ch_t);
-    }
-}
-
-template <typename T, int V> __device__ __forceinline__ Vec<T, V> sumsq_slots(const Vec<T, V> (&o)[8]) {
-    Vec<T, V> s = vsplat<T, V>(T(0));
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s = s + o[k] * o[k];   // inactive slots are exactly zero
-    return s;
-}
-
-// =============================================================================================
-// epilogues of the forward kernel
-// =============================================================================================
-template <int S, typename T, int V> struct StoreD {
-    static constexpr bool REDUCES = false;
-    T* d;
-    double* partials;
-    __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8]) const {
-        T* base = d + (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
-        for_each_channel<S>(g, [&](auto slot, int ch) { vstore<T, V>(base + (long long)ch * g.s_z, o[decltype(slot)::value]); });
-        return 0.0;
-    }
-};
-
-// |Dx| per voxel (0 -> +inf, pytv/tv_GPU.py:88) into an array with one extra plane in front
-template <int S, typename T, int V> struct NormEpi {
-    static constexpr bool REDUCES = true;
-    T* norms_ext;
-    double* partials;
-    __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8]) const {
-        const Vec<T, V> s = sumsq_slots<T, V>(o);
-        Vec<T, V> n;
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const T r = tsqrt(s.v[i]);
-            acc += (double)r;
-            n.v[i] = (r == T(0)) ? (T)INFINITY : r;
-        }
-        vstore<T, V>(norms_ext + (long long)(c.zl + 1) * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, n);
-        return (c.zl >= 0 && c.zl < g.nz) ? acc : 0.0;
-    }
-};
-
-// Chambolle-Pock dual update, README.md:149-151 (with keepdims over the channel axis)
-template <int S, typename T, int V> struct CpDual {
-    static constexpr bool REDUCES = true;
-    T* q;
-    T sigma, inv_lambda;
-    double* partials;
-    __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8]) const {
-        T* base = q + (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
-        Vec<T, V> v[8];
-        Vec<T, V> vs = vsplat<T, V>(T(0));
-        for_each_channel<S>(g, [&](auto slot, int ch) {
-            constexpr int k = decltype(slot)::value;
-            v[k] = vload<T, V>(base + (long long)ch * g.s_z) + sigma * o[k];
-            vs = vs + v[k] * v[k];
-        });
-        const Vec<T, V> ds = sumsq_slots<T, V>(o);
-        Vec<T, V> scale;
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            acc += (double)tsqrt(ds.v[i]);
-            scale.v[i] = T(1) / tmax(T(1), tsqrt(vs.v[i]) * inv_lambda);
-        }
-        for_each_channel<S>(g, [&](auto slot, int ch) {
-            constexpr int k = decltype(slot)::value;
-            vstore<T, V>(base + (long long)ch * g.s_z, v[k] * scale);
-        });
-        return acc;
-    }
-};
-
-// ADMM: v = Dx + u;  z = v * max(0, 1 - thresh/|v|);  u = v - z
-template <int S, typename T, int V> struct AdmmZU {
-    static constexpr bool REDUCES = true;
-    T* z;
-    T* u;
-    T thresh;
-    double* partials;
-    __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8]) const {
-        const long long off = (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
-        Vec<T, V> v[8];
-        Vec<T, V> vs = vsplat<T, V>(T(0));
-        for_each_channel<S>(g, [&](auto slot, int ch) {
-            constexpr int k = decltype(slot)::value;
-            v[k] = o[k] + vload<T, V>(u + off + (long long)ch * g.s_z);
-            vs = vs + v[k] * v[k];
-        });
-        const Vec<T, V> ds = sumsq_slots<T, V>(o);
-        Vec<T, V> scale;
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            acc += (double)tsqrt(ds.v[i]);
-            const T nv = tsqrt(vs.v[i]);
-            scale.v[i] = (nv > T(0)) ? tmax(T(0), T(1) - thresh / nv) : T(0);
-        }
-        for_each_channel<S>(g, [&](auto slot, int ch) {
-            constexpr int k = decltype(slot)::value;
-            const Vec<T, V> zz = v[k] * scale;
-            vstore<T, V>(z + off + (long long)ch * g.s_z, zz);
-            vstore<T, V>(u + off + (long long)ch * g.s_z, v[k] - zz);
-        });
-        return acc;
-    }
-};
 
 // =============================================================================================
 // forward kernel
@@ -284,88 +47,6 @@ __global__ __launch_bounds__(256) void k_D(DG g, WT<T> w, const T* x, const T* x
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0 && threadIdx.y == 0) epi.partials[linear_block_id()] = acc;
     }
-}
-
-// =============================================================================================
-// transposed operator: sources and epilogues
-// =============================================================================================
-template <typename T, int V> struct SrcPlain {
-    const T* y;
-    const T* yp;     // halo plane z0-1 of the backward-looking z channel
-    const T* yn;     // halo plane z0+nz of the forward-looking z channel
-    __device__ __forceinline__ Vec<T, V> ld(long long off) const { return vload<T, V>(y + off); }
-    __device__ __forceinline__ T lds(long long off) const { return y[off]; }
-    __device__ __forceinline__ Vec<T, V> ldp(long long off) const { return vload<T, V>(yp + off); }
-    __device__ __forceinline__ Vec<T, V> ldn(long long off) const { return vload<T, V>(yn + off); }
-};
-template <typename T, int V> struct SrcDiff {    // a - b, halos already differenced
-    const T* a;
-    const T* b;
-    const T* yp;
-    const T* yn;
-    __device__ __forceinline__ Vec<T, V> ld(long long off) const { return vload<T, V>(a + off) - vload<T, V>(b + off); }
-    __device__ __forceinline__ T lds(long long off) const { return a[off] - b[off]; }
-    __device__ __forceinline__ Vec<T, V> ldp(long long off) const { return vload<T, V>(yp + off); }
-    __device__ __forceinline__ Vec<T, V> ldn(long long off) const { return vload<T, V>(yn + off); }
-};
-
-template <typename T, int V> struct StoreDT {
-    static constexpr bool REDUCES = false;
-    T* out;
-    double* partials;
-    __device__ __forceinline__ double operator()(long long off, const Vec<T, V>& r) const {
-        vstore<T, V>(out + off, r);
-        return 0.0;
-    }
-};
-template <typename T, int V> struct AxpyDT {     // out = base + alpha * r
-    static constexpr bool REDUCES = false;
-    T* out;
-    const T* base;
-    T alpha;
-    double* partials;
-    __device__ __forceinline__ double operator()(long long off, const Vec<T, V>& r) const {
-        Vec<T, V> b = (base != nullptr) ? vload<T, V>(base + off) : vsplat<T, V>(T(0));
-        vstore<T, V>(out + off, b + alpha * r);
-        return 0.0;
-    }
-};
-// Chambolle-Pock primal step with the fidelity-dual update folded in, README.md:148,154,157
-template <typename T, int V> struct CpPrimal {
-    static constexpr bool REDUCES = true;
-    T* x;
-    const T* x0;
-    T* p;
-    T tau, sigma_a, inv_1p_sigma_a;
-    double* partials;
-    __device__ __forceinline__ double operator()(long long off, const Vec<T, V>& r) const {
-        const Vec<T, V> xv = vload<T, V>(x + off), x0v = vload<T, V>(x0 + off), pv = vload<T, V>(p + off);
-        Vec<T, V> pn, xn;
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            pn.v[i] = (pv.v[i] + sigma_a * (xv.v[i] - x0v.v[i])) * inv_1p_sigma_a;
-            xn.v[i] = (xv.v[i] - tau * pn.v[i]) - tau * r.v[i];
-            const double e = (double)xn.v[i] - (double)x0v.v[i];
-            acc += 0.5 * e * e;
-        }
-        vstore<T, V>(p + off, pn);
-        vstore<T, V>(x + off, xn);
-        return acc;
-    }
-};
-
-// One axis of the gather.  MODE 0: y^(p-e) - y^(p)   (adjoint of a forward difference)
-//                          MODE 1: y^(p) - y^(p+e)   (adjoint of a backward difference)
-//                          MODE 2: y^(p-e) - y^(p+e) (adjoint of a central difference)
-// y^ = y with the samples the forward operator never writes forced to zero.
-// lo/hi are the loaded neighbour vectors; pos/n the coordinate along the axis and its extent.
-template <int MODE, typename T, int V>
-__device__ __forceinline__ Vec<T, V> adj_axis(int pos, int n, const Vec<T, V>& lo, const Vec<T, V>& ce, const Vec<T, V>& hi) {
-    const Vec<T, V> zero = vsplat<T, V>(T(0));
-    if (MODE == 0) return ((pos >= 1) ? lo : zero) - ((pos <= n - 2) ? ce : zero);
-    if (MODE == 1) return ((pos >= 1) ? ce : zero) - ((pos <= n - 2) ? hi : zero);
-    return ((pos >= 2) ? lo : zero) - ((pos <= n - 3) ? hi : zero);
 }
 
 template <int S, typename T, int V, typename Src, typename Epi>
@@ -657,135 +338,6 @@ __global__ __launch_bounds__(256) void k_reduce(const double* in, long long n, d
 
 }  // namespace tv
 
-// =============================================================================================
-// host side: argument checking, launch geometry, C-ABI
-// =============================================================================================
-using namespace tv;
-
-static thread_local std::string g_err;
-static int fail(int code, const char* msg) {
-    g_err = msg;
-    return code;
-}
-static int hipfail(hipError_t e, const char* where) {
-    g_err = std::string(where) + ": " + hipGetErrorString(e);
-    return (int)e;
-}
-#define HIP_TRY(call)                                         \
-    do {                                                      \
-        hipError_t e__ = (call);                              \
-        if (e__ != hipSuccess) return hipfail(e__, #call);    \
-    } while (0)
-
-static int make_dg(const tv_geom* g, DG& d) {
-    if (g == nullptr) return fail(TV_E_ARG, "tv_geom is NULL");
-    if (g->nz < 1 || g->m < 1 || g->ny < 1 || g->nx < 1) return fail(TV_E_ARG, "every dimension must be >= 1");
-    if (g->nz_global < g->nz || g->z0 < 0 || g->z0 + g->nz > g->nz_global)
-        return fail(TV_E_ARG, "slab [z0, z0+nz) must lie inside [0, nz_global)");
-    if (g->scheme < 0 || g->scheme > 3) return fail(TV_E_ARG, "unknown scheme");
-    if (g->dtype != TV_F32 && g->dtype != TV_F64) return fail(TV_E_ARG, "unknown dtype");
-    if (g->nz_global > 60000 || g->m > 65535 || g->ny > (1 << 24) || g->nx > (1 << 24))
-        return fail(TV_E_ARG, "dimension too large for the launch grid");
-    if (!(g->reg_z_over_reg >= 0.0) || !(g->reg_time >= 0.0) || !(g->factor_reg_static >= 0.0))
-        return fail(TV_E_ARG, "weights must be non-negative numbers");
-    d.nz = (int)g->nz; d.m = (int)g->m; d.ny = (int)g->ny; d.nx = (int)g->nx;
-    d.nzg = (int)g->nz_global; d.z0 = (int)g->z0;
-    d.za = (g->nz_global > 1 && g->reg_z_over_reg > 0.0) ? 1 : 0;
-    d.ta = (g->m > 1 && g->reg_time > 0.0) ? 1 : 0;
-    const int per = (g->scheme == TV_HYBRID) ? 2 : 1;
-    d.nd = per * (2 + d.za + d.ta);
-    d.ch_z = 2 * per;
-    d.ch_t = d.ch_z + (d.za ? per : 0);
-    d.z_two = (g->scheme == TV_CENTRAL && g->nz_global == 2) ? 1 : 0;
-    d.t_two = (g->scheme == TV_CENTRAL && g->m == 2) ? 1 : 0;
-    d.s_t = (long long)g->ny * g->nx;
-    d.s_z = d.s_t * g->m;
-    d.s_dz = d.s_z * d.nd;
-    d.mask = g->mask_static;
-    return 0;
-}
-
-template <typename T> static WT<T> make_w(const tv_geom* g) {
-    WT<T> w;
-    w.wz = (T)std::sqrt(g->reg_z_over_reg);
-    w.wt = (T)std::sqrt(g->reg_time);
-    w.sf = (T)std::sqrt(g->factor_reg_static);
-    return w;
-}
-
-struct LC { dim3 grid, block; long long nblocks; };
-static LC launch_cfg(const DG& d, int V, int planes) {
-    const int nxv = d.nx / V;
-    int bx = 1;
-    while (bx < nxv && bx < 64) bx <<= 1;
-    const int by = 256 / bx;
-    const long long tx = (nxv + bx - 1) / bx, ty = (d.ny + by - 1) / by;
-    LC lc;
-    lc.block = dim3(bx, by, 1);
-    lc.grid = dim3((unsigned)(tx * ty), (unsigned)d.m, (unsigned)planes);
-    lc.nblocks = tx * ty * d.m * planes;
-    return lc;
-}
-
-static const int kFlatBlocks = 2048;    // grid-stride kernels: 256 CUs x 8 blocks
-static const int kStage = 256;          // second-level partials
-
-// layout of the scratch buffer: [partials ... nmax][stage kStage]
-static long long max_partials(const DG& d) {
-    LC lc = launch_cfg(d, 1, d.nz + 2);
-    return lc.nblocks > kFlatBlocks ? lc.nblocks : kFlatBlocks;
-}
-
-static int reduce_partials(double* ws, long long n, long long nmax, double* result, hipStream_t st) {
-    if (n <= 4096) {
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st, ws, n, result);
-    } else {
-        double* stage = ws + nmax;
-        hipLaunchKernelGGL(k_reduce, dim3(kStage), dim3(256), 0, st, ws, n, stage);
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st, stage, (long long)kStage, result);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-static bool aligned16(std::initializer_list<const void*> ps) {
-    for (const void* p : ps)
-        if (p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15u) != 0) return false;
-    return true;
-}
-
-// call f.template operator()<S, T, V>() for the run-time (scheme, dtype, vec)
-template <typename F> static int dispatch(int scheme, int dtype, bool vec, F&& f) {
-#define TV_CASE(SC)                                                                  \
-    case SC:                                                                         \
-        if (dtype == TV_F32) {                                                       \
-            if (vec) return f.template operator()<SC, float, 4>();                   \
-            return f.template operator()<SC, float, 1>();                            \
-        }                                                                            \
-        return f.template operator()<SC, double, 1>();
-    switch (scheme) {
-        TV_CASE(0) TV_CASE(1) TV_CASE(2) TV_CASE(3)
-    }
-#undef TV_CASE
-    return fail(TV_E_ARG, "unknown scheme");
-}
-
-static int check_x_halos(const tv_geom* g, const DG& d, const void* xp, const void* xn) {
-    if (!d.za) return 0;
-    const bool need_prev = (g->scheme != TV_UPWIND), need_next = (g->scheme != TV_DOWNWIND);
-    if (need_prev && g->z0 > 0 && xp == nullptr) return fail(TV_E_HALO, "previous-slab halo plane required");
-    if (need_next && g->z0 + g->nz < g->nz_global && xn == nullptr) return fail(TV_E_HALO, "next-slab halo plane required");
-    return 0;
-}
-static int check_y_halos(const tv_geom* g, const DG& d, const void* yp, const void* yn) {
-    if (!d.za) return 0;
-    // backward-looking adjoint (upwind-type, central) reads the previous slab; forward-looking the next
-    const bool need_prev = (g->scheme != TV_DOWNWIND), need_next = (g->scheme != TV_UPWIND);
-    if (need_prev && g->z0 > 0 && yp == nullptr) return fail(TV_E_HALO, "previous-slab gradient halo required");
-    if (need_next && g->z0 + g->nz < g->nz_global && yn == nullptr) return fail(TV_E_HALO, "next-slab gradient halo required");
-    return 0;
-}
-
 extern "C" {
 
 const char* tv_last_error(void) { return g_err.c_str(); }
@@ -811,6 +363,10 @@ int tv_D(const tv_geom* g, const void* x, const void* x_prev, const void* x_next
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
     const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, dout});
     hipStream_t st = (hipStream_t)stream;
+    if (march_ok(g, d, vec)) {
+        long long nb;
+        return tvm::D_store(g, d, x, x_prev, x_next, st, &nb, (float*)dout);
+    }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lc = launch_cfg(d, V, d.nz);
         StoreD<S, T, V> epi{(T*)dout, nullptr};
@@ -834,6 +390,11 @@ int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_pr
     const bool vec = (d.nx % 4 == 0) && aligned16({a, b, ab_prev, ab_next, base, out});
     hipStream_t st = (hipStream_t)stream;
     const bool plain_store = (base == nullptr && alpha == 1.0);
+    if (b == nullptr && march_ok(g, d, vec)) {
+        long long nb;
+        if (plain_store) return tvm::DT_store(g, d, a, ab_prev, ab_next, st, &nb, (float*)out);
+        return tvm::DT_axpy(g, d, a, ab_prev, ab_next, st, &nb, (float*)out, (const float*)base, (float)alpha);
+    }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lc = launch_cfg(d, V, d.nz);
         WT<T> w = make_w<T>(g);
@@ -938,6 +499,12 @@ int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* 
     const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, q});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
+    if (march_ok(g, d, vec)) {
+        long long nb;
+        if (int rc = tvm::D_cp_dual(g, d, x, x_prev, x_next, st, &nb, (float*)q, (float)sigma_D, (float)(1.0 / lambda),
+                                            (double*)ws)) return rc;
+        return reduce_partials((double*)ws, nb, nmax, tvout, st);
+    }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lc = launch_cfg(d, V, d.nz);
         CpDual<S, T, V> epi{(T*)q, (T)sigma_D, (T)(1.0 / lambda), (double*)ws};
@@ -958,6 +525,12 @@ int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void
     const bool vec = (d.nx % 4 == 0) && aligned16({q, q_prev, q_next, x, x0, p});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
+    if (march_ok(g, d, vec)) {
+        long long nb;
+        if (int rc = tvm::DT_cp_primal(g, d, q, q_prev, q_next, st, &nb, (float*)x, (const float*)x0, (float*)p, (float)tau,
+                                               (float)sigma_A, (float)(1.0 / (1.0 + sigma_A)), (double*)ws)) return rc;
+        return reduce_partials((double*)ws, nb, nmax, fid, st);
+    }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lc = launch_cfg(d, V, d.nz);
         SrcPlain<T, V> src{(const T*)q, (const T*)q_prev, (const T*)q_next};
@@ -977,6 +550,12 @@ int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* 
     const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, z, u});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
+    if (march_ok(g, d, vec)) {
+        long long nb;
+        if (int rc = tvm::D_admm_zu(g, d, x, x_prev, x_next, st, &nb, (float*)z, (float*)u, (float)thresh, (double*)ws))
+            return rc;
+        return reduce_partials((double*)ws, nb, nmax, tvout, st);
+    }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lc = launch_cfg(d, V, d.nz);
         AdmmZU<S, T, V> epi{(T*)z, (T*)u, (T)thresh, (double*)ws};

@@ -1,0 +1,33 @@
+// tv_march_D.hip -- instantiations + launchers of the plane-marching FORWARD kernels (tv_march.h).
+#include "tv_host.h"
+#include "tv_stencil.h"
+#include "tv_march.h"
+
+template <template <int, typename, int> class EpiT, typename... Args>
+static int launch_D_march(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st,
+                          long long* nblocks, Args... args) {
+    const int zc = march_zchunk(d);
+    const LC lc = march_cfg(d, zc);
+    *nblocks = lc.nblocks;
+    return dispatch_sm(g->scheme, d.m, [&]<int S, int M>() -> int {
+        EpiT<S, float, 4> epi{args...};
+        hipLaunchKernelGGL((k_D_march<S, M, EpiT<S, float, 4>>), lc.grid, lc.block, 0, st, d, make_w<float>(g), (const float*)x,
+                           (const float*)xp, (const float*)xn, zc, epi);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    });
+}
+
+namespace tvm {
+int D_store(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb, float* dout) {
+    return launch_D_march<StoreD>(g, d, x, xp, xn, st, nb, dout, (double*)nullptr);
+}
+int D_cp_dual(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
+              float* q, float sigma, float inv_lambda, double* partials) {
+    return launch_D_march<CpDual>(g, d, x, xp, xn, st, nb, q, sigma, inv_lambda, partials);
+}
+int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
+              float* z, float* u, float thresh, double* partials) {
+    return launch_D_march<AdmmZU>(g, d, x, xp, xn, st, nb, z, u, thresh, partials);
+}
+}  // namespace tvm

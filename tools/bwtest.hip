@@ -1,0 +1,122 @@
+// bwtest.hip -- practical HBM ceilings on MI355X for the access patterns of the CP kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/bwtest.hip -o tools/bwtest ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+typedef float float4_ __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_copy(const float4_* __restrict__ a, float4_* __restrict__ b, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_read(const float4_* __restrict__ a, float* out, long long n) {
+    float4_ s = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += a[i];
+    if (s.x + s.y + s.z + s.w == 1.2345f) out[0] = 1;
+}
+__global__ __launch_bounds__(256) void k_write(float4_* __restrict__ b, long long n) {
+    float4_ s = {1, 2, 3, 4};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) b[i] = s;
+}
+// marching pattern: block (64,4) owns a 4-row x 256-col tile, marches z in a chunk, M frames, NR read + NW written streams
+template <int M, int NC, bool WR, bool NT, bool BAR>
+__global__ __launch_bounds__(256) void k_march(const float* __restrict__ x, float* __restrict__ q, int nz, int ny, int nx, int zchunk) {
+    __shared__ float4_ tile[BAR ? M * 256 : 1];
+    const int lane = threadIdx.x, ty = threadIdx.y;
+    const int tiles_x = nx / 256;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const long long inpl = (long long)(by * 4 + ty) * nx + (bx * 64 + lane) * 4;
+    const long long s_t = (long long)ny * nx, s_z = s_t * M, s_dz = s_z * NC;
+    const int zs = blockIdx.y * zchunk, ze = min(zs + zchunk, nz);
+    float4_ acc = {0, 0, 0, 0};
+    for (int z = zs; z < ze; ++z) {
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const float4_ xv = *(const float4_*)(x + (long long)z * s_z + t * s_t + inpl);
+            if (BAR) tile[t * 256 + ty * 64 + lane] = xv;
+            float4_ v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4_* p = (const float4_*)(q + (long long)z * s_dz + c * s_z + t * s_t + inpl);
+                v[c] = NT ? __builtin_nontemporal_load(p) : *p;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float4_* p = (float4_*)(q + (long long)z * s_dz + c * s_z + t * s_t + inpl);
+                const float4_ r = v[c] * 1.0001f + xv;
+                if (WR) { if (NT) __builtin_nontemporal_store(r, p); else *p = r; }
+                else acc += r;
+            }
+        }
+        if (BAR) { __syncthreads(); acc += tile[((ty + 1) & 3) * 64 + lane]; __syncthreads(); }
+    }
+    if (acc.x == 1.2345f) q[0] = acc.y;
+}
+// frame-sweep pattern (one site per thread, grid (tiles, M, nz)) like the generic kernels
+template <int NC, bool WR>
+__global__ __launch_bounds__(256) void k_sweep(const float* __restrict__ x, float* __restrict__ q, int m, int ny, int nx) {
+    const int tiles_x = nx / 256;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const long long inpl = (long long)(by * 4 + threadIdx.y) * nx + (bx * 64 + threadIdx.x) * 4;
+    const long long s_t = (long long)ny * nx, s_z = s_t * m, s_dz = s_z * NC;
+    const int t = blockIdx.y, z = blockIdx.z;
+    const float4_ xv = *(const float4_*)(x + (long long)z * s_z + t * s_t + inpl);
+    float4_ v[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = *(const float4_*)(q + (long long)z * s_dz + c * s_z + t * s_t + inpl);
+    float4_ acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float4_ r = v[c] * 1.0001f + xv;
+        if (WR) *(float4_*)(q + (long long)z * s_dz + c * s_z + t * s_t + inpl) = r; else acc += r;
+    }
+    if (acc.x == 1.2345f) q[0] = acc.y;
+}
+
+template <typename F> float timeit(F f, int reps = 5) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a)); for (int i = 0; i < reps; ++i) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const int nz = argc > 1 ? atoi(argv[1]) : 256, M = 8, ny = 1024, nx = 1024, NC = 8;
+    const long long V = (long long)nz * M * ny * nx;
+    float *x, *q;
+    CK(hipMalloc(&x, V * 4)); CK(hipMalloc(&q, V * 4 * NC));
+    CK(hipMemset(x, 0, V * 4)); CK(hipMemset(q, 0, V * 4 * NC));
+    printf("V=%lld voxels, x %.1f GiB, q %.1f GiB\n", V, V * 4 / 1073741824.0, V * 4.0 * NC / 1073741824.0);
+    const long long n4 = V * NC / 4 / 2;   // copy half of q onto the other half
+    float ms;
+    ms = timeit([&] { hipLaunchKernelGGL(k_copy, dim3(2048 * 4), dim3(256), 0, 0, (const float4_*)q, (float4_*)q + n4, n4); });
+    printf("copy  float4 grid-stride 8192 blocks : %.2f ms  %.0f GB/s (r+w)\n", ms, 2.0 * n4 * 16 / ms / 1e6);
+    ms = timeit([&] { hipLaunchKernelGGL(k_read, dim3(2048 * 4), dim3(256), 0, 0, (const float4_*)q, x, 2 * n4); });
+    printf("read  float4                          : %.2f ms  %.0f GB/s\n", ms, 2.0 * n4 * 16 / ms / 1e6);
+    ms = timeit([&] { hipLaunchKernelGGL(k_write, dim3(2048 * 4), dim3(256), 0, 0, (float4_*)q, 2 * n4); });
+    printf("write float4                          : %.2f ms  %.0f GB/s\n", ms, 2.0 * n4 * 16 / ms / 1e6);
+    const double b_rw = (1.0 + 2 * NC) * 4 * V, b_r = (1.0 + NC) * 4 * V;
+    for (int zc : {8, 16, 32}) {
+        dim3 grid((nx / 256) * (ny / 4), (nz + zc - 1) / zc), blk(64, 4);
+        ms = timeit([&] { hipLaunchKernelGGL((k_march<8, 8, true, false, false>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
+        printf("march 1+8 read 8 write, zchunk %2d     : %.2f ms  %.0f GB/s\n", zc, ms, b_rw / ms / 1e6);
+    }
+    {
+        const int zc = 16; dim3 grid((nx / 256) * (ny / 4), (nz + zc - 1) / zc), blk(64, 4);
+        ms = timeit([&] { hipLaunchKernelGGL((k_march<8, 8, true, true, false>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
+        printf("march r/w nontemporal                 : %.2f ms  %.0f GB/s\n", ms, b_rw / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL((k_march<8, 8, true, false, true>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
+        printf("march r/w + LDS tile + 2 barriers     : %.2f ms  %.0f GB/s\n", ms, b_rw / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL((k_march<8, 8, false, false, false>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
+        printf("march read only (1+8 streams)         : %.2f ms  %.0f GB/s\n", ms, b_r / ms / 1e6);
+    }
+    {
+        dim3 grid((nx / 256) * (ny / 4), M, nz), blk(64, 4);
+        ms = timeit([&] { hipLaunchKernelGGL((k_sweep<8, true>), grid, blk, 0, 0, x, q, M, ny, nx); });
+        printf("sweep (site/thread) 1+8 read 8 write  : %.2f ms  %.0f GB/s\n", ms, b_rw / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL((k_sweep<8, false>), grid, blk, 0, 0, x, q, M, ny, nx); });
+        printf("sweep read only                       : %.2f ms  %.0f GB/s\n", ms, b_r / ms / 1e6);
+    }
+    return 0;
+}
