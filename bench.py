@@ -110,12 +110,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    # TEST-ONLY knobs (tests / single-GPU box): several ranks on one GPU over gloo with host-staged halos
+    backend = os.environ.get("TV_BENCH_BACKEND", "nccl")
+    if os.environ.get("TV_BENCH_SHARE_GPU", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     shape = wl["shape"]
@@ -128,7 +136,8 @@ def main():
     hist = torch.zeros((K + W, 6), dtype=torch.float64, device=device)
 
     def barrier():
-        if world > 1:
+        torch.cuda.synchronize()
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,12 +168,13 @@ def main():
     elapsed = time.perf_counter() - t0
     cp._dual, cp._primal = orig_dual, orig_primal
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    hist_r = hist if backend == "nccl" else hist.cpu()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        dist.all_reduce(hist_r, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
-    h = hist.cpu().numpy()
+    h = hist_r.cpu().numpy()
     loss = h[:, 3:6].sum(axis=1) + 25.0 * h[:, 0:3].sum(axis=1)
 
     V = float(np.prod(shape))
@@ -185,19 +195,26 @@ def main():
                                "fused_(6+3Nd)": bytes_iter_fused * it_s / 1e9 / world, "per": "GPU"},
         "loss_first_last": [float(loss[W]), float(loss[-1])],
     }
+    traffic = {}
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s|%s" % (args.workload, args.scheme), {})
+    except Exception:
+        pass
     if ev is not None:
         torch.cuda.synchronize()
         t_dual = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
         t_primal = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
         b_dual = 4.0 * (1 + 2 * nd) * V_local
         b_primal = 4.0 * (nd + 5) * V_local
-        out["roofline"] = {"bound": "hbm", "kernel": "k_D<hybrid,float,4,CpDual> (tv_cp_dual)", "achieved": b_dual / t_dual / 1e9,
-                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_dual / t_dual / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+        out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_dual: k_D_march<S,M,CpDual> (fp32 Nx>=128) or k_D<S,T,V,CpDual>", "achieved": b_dual / t_dual / 1e9,
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_dual / t_dual / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("dual"),
+                           "traffic_source": traffic.get("source"),
                            "bytes_per_launch": b_dual, "ms_per_launch": 1e3 * t_dual,
                            "note": "algorithmic bytes (1+2Nd)*4 per voxel; HIP events on the launch stream, includes the two tiny partial-sum kernels"}
-        out["roofline_primal"] = {"bound": "hbm", "kernel": "k_DT<hybrid,float,4,CpPrimal> (tv_cp_primal)",
+        out["roofline_primal"] = {"bound": "hbm", "kernel": "tv_cp_primal: k_DT_march<S,M,CpPrimal> (fp32 Nx>=128) or k_DT<S,T,V,SrcPlain,CpPrimal>",
                                   "achieved": b_primal / t_primal / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": b_primal / t_primal / 1e9 / HBM_PEAK_GBPS, "bytes_per_launch": b_primal,
+                                  "frac": b_primal / t_primal / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("primal"),
+                                  "bytes_per_launch": b_primal,
                                   "ms_per_launch": 1e3 * t_primal,
                                   "note": "algorithmic bytes (Nd+5)*4 per voxel: reads q,x,x0,p; writes x,p (fidelity dual fused in)"}
     else:
@@ -211,7 +228,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(shape, wl["reg_z"], wl["reg_time"], nd)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -57,6 +57,8 @@ class Slab:
         (``wait()`` orders the current stream behind the transfer on RCCL; it blocks on gloo)."""
         if not self.sharded:
             return []
+        if self._stage_through_host(send_prev, send_next, recv_prev, recv_next):
+            return self._exchange_staged(send_prev, send_next, recv_prev, recv_next)
         ops = []
         if self.prev is not None:
             if recv_prev is not None:
@@ -72,6 +74,39 @@ class Slab:
             return []
         return dist.batch_isend_irecv(ops)
 
+    def _stage_through_host(self, *tensors):
+        """gloo moves host memory only: device tensors are staged through the host.  This is the
+        TEST configuration (several ranks sharing one GPU); production is RCCL, device to device."""
+        if dist.get_backend(self.group) != "gloo":
+            return False
+        return any(t is not None and t.is_cuda for t in tensors)
+
+    def _exchange_staged(self, send_prev, send_next, recv_prev, recv_next):
+        def host(t):
+            return None if t is None else t.detach().to("cpu").contiguous()
+
+        def like(t):
+            return None if t is None else torch.empty(t.shape, dtype=t.dtype, device="cpu")
+        sp, sn, rp, rn = host(send_prev), host(send_next), like(recv_prev), like(recv_next)
+        ops = []
+        if self.prev is not None:
+            if rp is not None:
+                ops.append(dist.P2POp(dist.irecv, rp, self._global_rank(self.prev), self.group))
+            if sp is not None:
+                ops.append(dist.P2POp(dist.isend, sp, self._global_rank(self.prev), self.group))
+        if self.next is not None:
+            if sn is not None:
+                ops.append(dist.P2POp(dist.isend, sn, self._global_rank(self.next), self.group))
+            if rn is not None:
+                ops.append(dist.P2POp(dist.irecv, rn, self._global_rank(self.next), self.group))
+        for h in (dist.batch_isend_irecv(ops) if ops else []):
+            h.wait()
+        if self.prev is not None and rp is not None:
+            recv_prev.copy_(rp)
+        if self.next is not None and rn is not None:
+            recv_next.copy_(rn)
+        return []
+
     @staticmethod
     def wait(handles):
         for h in handles:
@@ -80,7 +115,12 @@ class Slab:
     def allreduce_sum_(self, t):
         """In-place sum over ranks of a (small, fp64) tensor."""
         if self.sharded:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.detach().to("cpu")
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def local(self, full):

@@ -1,0 +1,87 @@
+"""N > 1 on REAL kernels with ONE GPU: 2-4 processes share cuda:0, talk over gloo (halo planes
+staged through the host -- pytv/slab.py does that automatically for the gloo backend), and run
+the z-slab solvers end to end: halo plan, interior/edge launches with overlap, sub-slab geometries,
+scalar all-reduce.  The result must equal the unsharded oracle run.  RCCL itself cannot put two
+ranks on one device, so the device-to-device transport is exercised only by bench.py --gpus N."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT, SCHEMES
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pytv
+        from pytv.slab import Slab
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(91)
+        x0_full = (60.0 * rng.random(shape)).astype(np.float32)
+        slab = Slab(shape[0])
+        x0 = torch.as_tensor(slab.local(x0_full).copy()).cuda()
+        out = {}
+        cp = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, slab=slab, overlap=overlap, **kw)
+        out["cp_loss"] = cp.run(8)
+        out["cp_x"] = cp.result().cpu().numpy()
+        out["cp_overlap"] = cp.overlap
+        if min(n for _, n in slab.parts) >= 2:
+            sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, slab=slab, **kw)
+            out["sg_loss"] = sg.run(5)
+            out["sg_x"] = sg.result().cpu().numpy()
+            ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, **kw)
+            out["ad_loss"] = ad.run(3)
+            out["ad_x"] = ad.result().cpu().numpy()
+        out["z"] = (slab.z0, slab.nz)
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("world,shape,overlap", [(2, (8, 3, 6, 132), True), (3, (9, 2, 8, 16), True), (4, (8, 4, 5, 128), False)])
+def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap):
+    from oracle import tv_oracle as orc
+    kw = dict(reg_z_over_reg=1.3, reg_time=0.7)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), shape, scheme, kw, overlap, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    rng = np.random.default_rng(91)
+    x0 = (60.0 * rng.random(shape)).astype(np.float32).astype(np.float64)
+    wx, wloss = orc.chambolle_pock(x0, 8, 7.0, scheme=scheme, **kw)
+    for r in range(world):
+        z0, nz = ret[r]["z"]
+        np.testing.assert_allclose(ret[r]["cp_loss"], wloss, rtol=1e-5, err_msg="rank %d" % r)
+        np.testing.assert_allclose(ret[r]["cp_x"], wx[z0:z0 + nz], rtol=1e-5, atol=2e-3, err_msg="rank %d" % r)
+    if overlap:
+        assert any(ret[r]["cp_overlap"] for r in range(world))
+    if "sg_loss" in ret[0]:
+        sx, sloss = orc.subgradient_descent(x0, 5, 7.0, 2e-3, scheme=scheme, **kw)
+        ax, aloss = orc.admm(x0, 3, 7.0, 0.1, 3, scheme=scheme, **kw)
+        for r in range(world):
+            z0, nz = ret[r]["z"]
+            np.testing.assert_allclose(ret[r]["sg_loss"], sloss, rtol=1e-5)
+            np.testing.assert_allclose(ret[r]["sg_x"], sx[z0:z0 + nz], rtol=1e-5, atol=2e-3)
+            np.testing.assert_allclose(ret[r]["ad_loss"], aloss, rtol=5e-5)
+            np.testing.assert_allclose(ret[r]["ad_x"], ax[z0:z0 + nz], rtol=1e-4, atol=5e-3)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools_prof.sh <tag> [bench args...]
+# usage (on the GPU box): bash tools/prof.sh <tag> [bench args...]
 # kernel trace + stats, then two separate PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass)
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT
