@@ -132,6 +132,9 @@ inline int env_int(const char* name, int dflt) {
 inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
     if (g->dtype != TV_F32 || !vec || d.nx < 128) return false;
     if (env_int("TV_NO_MARCH", 0)) return false;
+    // small planes (z/t neighbours one plane away stay L2-resident) are served better by the
+    // one-site-per-thread kernels: measured on 512x512xM=1 (BASELINE config 1)
+    if ((long long)d.s_z * 4 < (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024) return false;
     return d.m == 1 || d.m == 2 || d.m == 3 || d.m == 4 || d.m == 8 || d.m == 16;
 }
 inline int march_zchunk(const DG& d) {

@@ -243,6 +243,110 @@ __global__ __launch_bounds__(256) void k_gather(XA<T> X, WT<T> w, const T* norms
     }
 }
 
+
+// =============================================================================================
+// vectorised forms of the two gather kernels for the schemes whose stencil has radius 1 in x
+// (upwind, downwind, hybrid).  With f = forward and b = backward difference at the site:
+//   D up-channel at p-e equals (w b)(p), D down-channel at p+e equals (w f)(p), so
+//   G(p)      = s * sum_a [ up: d_b/n(p-e) - d_f/n(p) ]  +  [ down: d_b/n(p) - d_f/n(p+e) ]
+//   D^T D x   = sum_a w_a^2 (b_a - f_a)           (identical for the three schemes)
+// where d_f = ((w f) mf) s, d_b = ((w b) mf) s reproduce the arithmetic of D exactly.
+// =============================================================================================
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> div_where(const Vec<T, V>& d, const Vec<T, V>& n, bool valid) {
+    Vec<T, V> r = vsplat<T, V>(T(0));
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) r.v[i] = d.v[i] / n.v[i];       // n == +inf where |Dx| == 0 -> 0
+    }
+    return r;
+}
+
+template <int S, typename T, int V>
+__global__ __launch_bounds__(256) void k_subgrad_vec(DG g, WT<T> w, const T* x, const T* xp, const T* xn, const T* norms_ext, T* G) {
+    static_assert(S != CENTRAL, "radius-2 scheme: use k_gather");
+    const Coord c = thread_coord<V>(g, 0);
+    if (!c.ok) return;
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    const T* pc = zplane<T>(g, x, xp, xn, 2, c.zl);
+    const T* pp = g.za ? zplane<T>(g, x, xp, xn, 2, c.zl - 1) : nullptr;
+    const T* pn = g.za ? zplane<T>(g, x, xp, xn, 2, c.zl + 1) : nullptr;
+    XN<T, V> xs, ns;
+    load_xn<T, V, true, true>(g, pc, pp, pn, c, xs);
+    const T* nc = norms_ext + (long long)(c.zl + 1) * g.s_z;
+    load_xn<T, V, true, true>(g, nc, pp ? nc - g.s_z : nullptr, pn ? nc + g.s_z : nullptr, c, ns);
+    const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : T(1);
+    const Vec<T, V> mf = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
+    const Vec<T, V> zero = vsplat<T, V>(T(0));
+    Vec<T, V> r = zero;
+    auto axis = [&](const Vec<T, V>& nxt, const Vec<T, V>& prv, bool hn, bool hp, const Vec<T, V>& n_nxt, const Vec<T, V>& n_prv,
+                    T wa, bool weighted, bool timeax) {
+        Vec<T, V> f = hn ? nxt - xs.c : zero, b = hp ? xs.c - prv : zero;
+        if (weighted) { f = wa * f; b = wa * b; }
+        if (timeax) { f = f * mf; b = b * mf; }
+        if (S == HYBRID) { f = s * f; b = s * b; }
+        if (UP) r = r + (div_where<T, V>(b, n_prv, hp) - div_where<T, V>(f, ns.c, hn));
+        if (DN) r = r + (div_where<T, V>(b, ns.c, hp) - div_where<T, V>(f, n_nxt, hn));
+    };
+    axis(xs.nr, xs.pr, xs.h_nr, xs.h_pr, ns.nr, ns.pr, T(1), false, false);
+    {   // columns: validity per element
+        Vec<T, V> f, b, t1 = zero, t2 = zero;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int col = c.col0 + i;
+            const bool hn = col < g.nx - 1, hp = col > 0;
+            T fi = hn ? xs.nc.v[i] - xs.c.v[i] : T(0), bi = hp ? xs.c.v[i] - xs.pc.v[i] : T(0);
+            if (S == HYBRID) { fi *= s; bi *= s; }
+            T acc = T(0);
+            if (UP) acc += (hp ? bi / ns.pc.v[i] : T(0)) - (hn ? fi / ns.c.v[i] : T(0));
+            if (DN) acc += (hp ? bi / ns.c.v[i] : T(0)) - (hn ? fi / ns.nc.v[i] : T(0));
+            r.v[i] += acc;
+        }
+    }
+    if (g.za) axis(xs.nz, xs.pz, xs.h_nz, xs.h_pz, ns.nz, ns.pz, w.wz, true, false);
+    if (g.ta) axis(xs.nt, xs.pt, xs.h_nt, xs.h_pt, ns.nt, ns.pt, w.wt, true, true);
+    if (S == HYBRID) r = s * r;
+    vstore<T, V>(G + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, r);
+}
+
+template <int S, typename T, int V>
+__global__ __launch_bounds__(256) void k_normal_vec(DG g, WT<T> w, const T* x, const T* xp, const T* xn, T rho, T* out, double* partials) {
+    static_assert(S != CENTRAL, "radius-2 scheme: use k_gather");
+    __shared__ double sm[16];
+    const Coord c = thread_coord<V>(g, 0);
+    double acc = 0.0;
+    if (c.ok) {
+        const T* pc = zplane<T>(g, x, xp, xn, 2, c.zl);
+        const T* pp = g.za ? zplane<T>(g, x, xp, xn, 2, c.zl - 1) : nullptr;
+        const T* pn = g.za ? zplane<T>(g, x, xp, xn, 2, c.zl + 1) : nullptr;
+        XN<T, V> xs;
+        load_xn<T, V, true, true>(g, pc, pp, pn, c, xs);
+        const Vec<T, V> zero = vsplat<T, V>(T(0));
+        Vec<T, V> r = zero;
+        r = r + ((xs.h_pr ? xs.c - xs.pr : zero) - (xs.h_nr ? xs.nr - xs.c : zero));
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int col = c.col0 + i;
+            r.v[i] += ((col > 0) ? xs.c.v[i] - xs.pc.v[i] : T(0)) - ((col < g.nx - 1) ? xs.nc.v[i] - xs.c.v[i] : T(0));
+        }
+        if (g.za) r = r + (w.wz * w.wz) * ((xs.h_pz ? xs.c - xs.pz : zero) - (xs.h_nz ? xs.nz - xs.c : zero));
+        if (g.ta) {
+            const Vec<T, V> mf = mask_factor<T, V>(g, w.sf, c.y, c.col0);
+            r = r + ((w.wt * w.wt) * ((xs.h_pt ? xs.c - xs.pt : zero) - (xs.h_nt ? xs.nt - xs.c : zero))) * (mf * mf);
+        }
+        const long long off = (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+        Vec<T, V> o;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            o.v[i] = xs.c.v[i] + rho * r.v[i];
+            acc += (double)xs.c.v[i] * (double)o.v[i];
+        }
+        vstore<T, V>(out + off, o);
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[linear_block_id()] = acc;
+}
+
 // =============================================================================================
 // l2,1 norm of a materialised gradient (pytv/tv_operators_GPU.py:75-81 as ONE pass)
 // =============================================================================================
@@ -459,10 +563,23 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
                            (const T*)x_next, 2, -ghosts_lo, epi);
         HIP_TRY(hipGetLastError());
         if (int rc = reduce_partials((double*)ws, lc.nblocks, nmax, tvout, st)) return rc;
-        // pass 2: gather
-        LC lg = launch_cfg(d, 1, d.nz);
-        XA<T> X{d, (const T*)x, (const T*)x_prev, (const T*)x_next, 2};
-        hipLaunchKernelGGL((k_gather<S, T, 0>), lg.grid, lg.block, 0, st, X, w, (const T*)norms_ext, T(0), (T*)G, (double*)nullptr);
+        // pass 2: gather (vectorised for the radius-1 schemes, scalar radius-2 kernel for central)
+        if constexpr (S != CENTRAL) {
+            const bool v2 = vec && aligned16({G});
+            if (v2 && V == 4) {
+                LC lg = launch_cfg(d, V, d.nz);
+                hipLaunchKernelGGL((k_subgrad_vec<S, T, V>), lg.grid, lg.block, 0, st, d, w, (const T*)x, (const T*)x_prev,
+                                   (const T*)x_next, (const T*)norms_ext, (T*)G);
+            } else {
+                LC lg = launch_cfg(d, 1, d.nz);
+                hipLaunchKernelGGL((k_subgrad_vec<S, T, 1>), lg.grid, lg.block, 0, st, d, w, (const T*)x, (const T*)x_prev,
+                                   (const T*)x_next, (const T*)norms_ext, (T*)G);
+            }
+        } else {
+            LC lg = launch_cfg(d, 1, d.nz);
+            XA<T> X{d, (const T*)x, (const T*)x_prev, (const T*)x_next, 2};
+            hipLaunchKernelGGL((k_gather<S, T, 0>), lg.grid, lg.block, 0, st, X, w, (const T*)norms_ext, T(0), (T*)G, (double*)nullptr);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     });
@@ -478,13 +595,22 @@ int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void
         return fail(TV_E_HALO, "tv_normal_op on a slab needs two halo planes on each interior side");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    return dispatch(g->scheme, g->dtype, false, [&]<int S, typename T, int V>() -> int {
-        LC lg = launch_cfg(d, 1, d.nz);
-        XA<T> X{d, (const T*)x, (const T*)x_prev, (const T*)x_next, 2};
-        hipLaunchKernelGGL((k_gather<S, T, 1>), lg.grid, lg.block, 0, st, X, make_w<T>(g), (const T*)nullptr, (T)rho, (T*)out,
-                           (double*)ws);
-        HIP_TRY(hipGetLastError());
-        return reduce_partials((double*)ws, lg.nblocks, nmax, dot, st);
+    const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, out});
+    return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
+        if constexpr (S != CENTRAL) {
+            LC lg = launch_cfg(d, V, d.nz);
+            hipLaunchKernelGGL((k_normal_vec<S, T, V>), lg.grid, lg.block, 0, st, d, make_w<T>(g), (const T*)x, (const T*)x_prev,
+                               (const T*)x_next, (T)rho, (T*)out, (double*)ws);
+            HIP_TRY(hipGetLastError());
+            return reduce_partials((double*)ws, lg.nblocks, nmax, dot, st);
+        } else {
+            LC lg = launch_cfg(d, 1, d.nz);
+            XA<T> X{d, (const T*)x, (const T*)x_prev, (const T*)x_next, 2};
+            hipLaunchKernelGGL((k_gather<S, T, 1>), lg.grid, lg.block, 0, st, X, make_w<T>(g), (const T*)nullptr, (T)rho, (T*)out,
+                               (double*)ws);
+            HIP_TRY(hipGetLastError());
+            return reduce_partials((double*)ws, lg.nblocks, nmax, dot, st);
+        }
     });
 }
 

@@ -17,6 +17,9 @@ from conftest import PKG, ROOT, SCHEMES
 
 pytestmark = pytest.mark.gpu
 
+# exercise the plane-marching kernels on the small test shapes too (production threshold: 4 MiB planes)
+os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+
 
 def _free_port():
     s = socket.socket()

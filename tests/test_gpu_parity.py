@@ -15,6 +15,9 @@ from oracle import tv_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
+# exercise the plane-marching kernels on the small test shapes too (production threshold: 4 MiB planes)
+os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+
 F64 = dict(rtol=1e-11, atol=1e-11)
 F32 = dict(rtol=1e-5, atol=1e-5)
 
