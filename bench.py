@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--scheme", default="hybrid", choices=["upwind", "downwind", "central", "hybrid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--two-kernel", action="store_true", help="force the dual + primal kernel pair instead of the one-sweep kernel")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +131,7 @@ def main():
     slab = Slab(shape[0], rank=rank, world=world)
     x0 = synth_slab(shape, slab.z0, slab.nz, device)
     cp = pytv.solvers.ChambollePock(x0, 25.0, scheme=args.scheme, reg_z_over_reg=wl["reg_z"], reg_time=wl["reg_time"],
-                                    slab=slab, overlap=not args.no_overlap)
+                                    slab=slab, overlap=not args.no_overlap, fused=False if args.two_kernel else None)
     nd = cp.geo.nd
     K, W = args.steps, args.warmup
     hist = torch.zeros((K + W, 6), dtype=torch.float64, device=device)
@@ -143,22 +144,8 @@ def main():
 
     for it in range(W):
         cp.step(hist[it])
-    # per-kernel HIP events on the launch stream (torch's current stream) -- unsharded launches only
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)] if not cp.overlap else None
-    orig_dual, orig_primal = cp._dual, cp._primal
-    if ev is not None:
-        state = {"it": 0}
-
-        def dual_timed(*a):
-            ev[state["it"]][0].record()
-            orig_dual(*a)
-            ev[state["it"]][1].record()
-
-        def primal_timed(*a):
-            orig_primal(*a)
-            ev[state["it"]][2].record()
-            state["it"] += 1
-        cp._dual, cp._primal = dual_timed, primal_timed
+    # per-kernel HIP events on the launch stream (torch's current stream == the stream the C-ABI enqueues on)
+    cp.timing = []
 
     barrier()
     t0 = time.perf_counter()
@@ -166,7 +153,8 @@ def main():
         cp.step(hist[W + it])
     barrier()
     elapsed = time.perf_counter() - t0
-    cp._dual, cp._primal = orig_dual, orig_primal
+    ev = cp.timing[:K]
+    cp.timing = None
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     hist_r = hist if backend == "nccl" else hist.cpu()
@@ -191,8 +179,9 @@ def main():
                    "lambda": 25.0, "sigma_D": cp.sigma_D, "sigma_A": cp.sigma_A, "tau": cp.tau,
                    "parallelism": "z-slab x%d%s" % (world, " (halo overlapped)" if cp.overlap else "")},
         "voxel_iterations_per_sec": it_s * V,
-        "hbm_gbps_iteration": {"algorithmic_unfused_(8+3Nd)": bytes_iter_algo * it_s / 1e9 / world,
-                               "fused_(6+3Nd)": bytes_iter_fused * it_s / 1e9 / world, "per": "GPU"},
+        "hbm_gbps_iteration": {"readme_unfused_(8+3Nd)_words": bytes_iter_algo * it_s / 1e9 / world,
+                               "two_kernel_(6+3Nd)_words": bytes_iter_fused * it_s / 1e9 / world,
+                               "one_sweep_(5+2Nd)_words": 4.0 * (5 + 2 * nd) * V * it_s / 1e9 / world, "per": "GPU"},
         "loss_first_last": [float(loss[W]), float(loss[-1])],
     }
     traffic = {}
@@ -200,28 +189,36 @@ def main():
         traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s|%s" % (args.workload, args.scheme), {})
     except Exception:
         pass
-    if ev is not None:
-        torch.cuda.synchronize()
-        t_dual = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
-        t_primal = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    torch.cuda.synchronize()
+    t_k1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+    t_k2 = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    sharded = " (per GPU; kernel 2 interval includes the halo wait)" if world > 1 else ""
+    if cp.fused:
+        b_k1 = 4.0 * (5 + 2 * nd) * V_local      # read x, x0, p, q ; write q, x, p
+        out["config"]["kernels"] = "one-sweep: tv_cp_fused + tv_cp_fixup"
+        out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_fused: k_cp_fused<S,M> (dual update + lagged primal update, one pass over q)",
+                           "achieved": b_k1 / t_k1 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_k1 / t_k1 / 1e9 / HBM_PEAK_GBPS,
+                           "traffic": traffic.get("fused"), "traffic_source": traffic.get("source"), "bytes_per_launch": b_k1,
+                           "ms_per_launch": 1e3 * t_k1,
+                           "note": "algorithmic bytes (5+2Nd)*4 per voxel: q read+written once, x/x0/p read, x/p written; HIP events on the "
+                                   "launch stream (includes the tiny partial-sum kernels)" + sharded}
+        out["roofline_fixup"] = {"kernel": "tv_cp_fixup: k_cp_fixup<S> (tile-edge rows/cols, chunk-edge planes)", "ms_per_launch": 1e3 * t_k2,
+                                 "traffic": traffic.get("fixup"),
+                                 "note": "adds the adjoint terms that cross wave tiles / z-chunks / slabs; touches ~57% of the sites, ~2.5 words/voxel"}
+    else:
         b_dual = 4.0 * (1 + 2 * nd) * V_local
         b_primal = 4.0 * (nd + 5) * V_local
-        out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_dual: k_D_march<S,M,CpDual> (fp32 Nx>=128) or k_D<S,T,V,CpDual>", "achieved": b_dual / t_dual / 1e9,
-                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_dual / t_dual / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("dual"),
-                           "traffic_source": traffic.get("source"),
-                           "bytes_per_launch": b_dual, "ms_per_launch": 1e3 * t_dual,
-                           "note": "algorithmic bytes (1+2Nd)*4 per voxel; HIP events on the launch stream, includes the two tiny partial-sum kernels"}
-        out["roofline_primal"] = {"bound": "hbm", "kernel": "tv_cp_primal: k_DT_march<S,M,CpPrimal> (fp32 Nx>=128) or k_DT<S,T,V,SrcPlain,CpPrimal>",
-                                  "achieved": b_primal / t_primal / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": b_primal / t_primal / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("primal"),
-                                  "bytes_per_launch": b_primal,
-                                  "ms_per_launch": 1e3 * t_primal,
-                                  "note": "algorithmic bytes (Nd+5)*4 per voxel: reads q,x,x0,p; writes x,p (fidelity dual fused in)"}
-    else:
-        b_it = bytes_iter_fused / world
-        out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_dual + tv_cp_primal (interior + 2 edge launches each, halo overlapped)",
-                           "achieved": b_it * it_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_it * it_s / 1e9 / HBM_PEAK_GBPS,
-                           "traffic": None, "note": "per-GPU, whole iteration incl. halo exchange"}
+        out["config"]["kernels"] = "two-kernel: tv_cp_dual + tv_cp_primal"
+        out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_dual: k_D_march<S,M,CpDual> (fp32, planes >= 4 MiB) or k_D<S,T,V,CpDual>",
+                           "achieved": b_dual / t_k1 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_dual / t_k1 / 1e9 / HBM_PEAK_GBPS,
+                           "traffic": traffic.get("dual"), "traffic_source": traffic.get("source"), "bytes_per_launch": b_dual,
+                           "ms_per_launch": 1e3 * t_k1,
+                           "note": "algorithmic bytes (1+2Nd)*4 per voxel; HIP events on the launch stream (includes the tiny partial-sum kernels)" + sharded}
+        out["roofline_primal"] = {"bound": "hbm", "kernel": "tv_cp_primal: k_DT_march<S,M,CpPrimal> or k_DT<S,T,V,SrcPlain,CpPrimal>",
+                                  "achieved": b_primal / t_k2 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": b_primal / t_k2 / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("primal"),
+                                  "bytes_per_launch": b_primal, "ms_per_launch": 1e3 * t_k2,
+                                  "note": "algorithmic bytes (Nd+5)*4 per voxel: reads q,x,x0,p; writes x,p (fidelity dual fused in)" + sharded}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del cp, x0
         torch.cuda.empty_cache()

@@ -99,6 +99,22 @@ int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* 
 int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x,
                  const void* x0, void* p, double tau, double sigma_A, double* fid, void* ws, void* stream);
 
+/* One-sweep form of the same iteration for the radius-1 schemes (upwind, downwind, hybrid; fp32,
+ * nx % 4 == 0, m in {1,2,3,4,8}): q is read and written ONCE per iteration.  x is ping-ponged.
+ *   tv_cp_fused_supported : 1 if this geometry can take the one-sweep path, else 0
+ *   tv_cp_fused           : q <- proj(q + sigma_D D x_in); p <- (p + sigma_A (x_in - x0)) / (1 + sigma_A);
+ *                           x_out <- x_in - tau p - tau D^T q   EXCEPT the adjoint terms that cross a
+ *                           wave tile (4 rows x 64 cols), a z-chunk or the slab; *tv = |D x_in|_{2,1},
+ *                           *fid = 1/2 |x_out - x0|^2 over the sites that are already complete
+ *   tv_cp_fixup           : adds the missing terms to x_out (q_prev / q_next as in tv_DT) and returns
+ *                           the fidelity of those sites in *fid; total fidelity = sum of the two.   */
+int tv_cp_fused_supported(const tv_geom* g);
+int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* x0,
+                void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, double* tv, double* fid,
+                void* ws, void* stream);
+int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
+                double tau, double* fid, void* ws, void* stream);
+
 /* ---- fused ADMM updates (not in the reference; README.md:26,135 mention only) --------------- */
 /* v = D x + u; z = v * max(0, 1 - thresh/|v|_2); u = v - z; *tv (device fp64) = |D x|_{2,1}. */
 int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* z, void* u,

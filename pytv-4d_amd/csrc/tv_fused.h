@@ -1,0 +1,445 @@
+// tv_fused.h -- ONE-SWEEP Chambolle-Pock iteration (README.md:145-157 of the reference) for the
+// radius-1 schemes (upwind, downwind, hybrid), fp32, 16-byte lanes.
+//
+// The two-kernel form (tv_cp_dual + tv_cp_primal) reads the dual variable q twice and writes it once
+// per iteration: 30 words/voxel at Nd = 8.  Here the primal update of plane z-1 is done in the same
+// sweep that produces q'(z), lagging one plane behind, so q is read once and written once:
+//
+//   step z, frame t (thread = one (row, 4-col) site, marching z inside a z-chunk, frames unrolled):
+//     q'(z,t) = proj(q + sigma D x)                       (x(z-1), x(z) in registers, x(z+1) loaded)
+//     R[t]  (adjoint accumulator of plane z-1)  -= wz q'_zdown(z,t)        -> now complete:
+//     x_out(z-1,t) = x(z-1,t) - tau p' - tau s R[t],  p' = (p + sigma_A (x - x0)) / (1 + sigma_A)
+//     R[t]  := own-site terms of q'(z,t) + row / col neighbour terms (wave shuffles)
+//              + wz q'_zup(z-1,t) (carried) + wt q'_tup(z,t-1) (carried);   R[t-1] -= wt q'_tdown(z,t)
+//
+// A wave covers a 4-row x 64-col tile (16 lanes x 4 rows): row and column neighbours of both x and q'
+// are lane shuffles, so there is no LDS tile and no barrier.  Terms that live in ANOTHER wave's tile or
+// another z-chunk (tile-edge rows / columns, chunk-edge planes) are left out by the sweep and added by
+// the thin fix-up kernel k_cp_fixup afterwards (it touches only those rows / planes: ~2.5 words/voxel).
+// x is ping-ponged (x_in -> x_out) because neighbouring tiles read old halo values at their own pace.
+#pragma once
+#include "tv_device.h"
+#include "tv_stencil.h"
+
+namespace tv {
+
+using F4 = Vec<float, 4>;
+
+struct FusedCoord {
+    int lane, row, lx, col0, y, zs, ze;
+    bool ok;
+    long long inpl;
+};
+
+// block (64, 4): wave = threadIdx.y covers columns [64 w, 64 w + 64) of a 4-row x 256-col block tile
+__device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk) {
+    FusedCoord c;
+    c.lane = (int)threadIdx.x;
+    c.row = c.lane >> 4;
+    c.lx = c.lane & 15;
+    const int nxv = g.nx / 4;
+    const int tiles_x = (nxv + 63) / 64;
+    const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
+    c.col0 = (bx * 64 + (int)threadIdx.y * 16 + c.lx) * 4;
+    c.y = by * 4 + c.row;
+    c.ok = (c.col0 < g.nx) && (c.y < g.ny);
+    c.zs = (int)blockIdx.y * zchunk;
+    c.ze = (c.zs + zchunk < g.nz) ? c.zs + zchunk : g.nz;
+    c.inpl = (long long)c.y * g.nx + c.col0;
+    return c;
+}
+
+// does the sweep leave a term of this site-vector to the fix-up kernel?  (shared by both kernels)
+template <int S, bool XW>
+__device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, int col0, int zchunk) {
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    constexpr int CM = XW ? 255 : 63;          // column period of the tiles whose edges are left to the fix-up
+    bool f = false;
+    // rows: every wave tile (4 rows); columns: only the 256-column BLOCK tile edges -- the four waves
+    // of a block hand their edge columns to each other through LDS inside the sweep
+    if (UP) f = f || ((y & 3) == 0 && y >= 1) || ((col0 & CM) == 0 && col0 >= 1);
+    if (DN) f = f || ((y & 3) == 3 && y <= g.ny - 2) || ((col0 & CM) == CM - 3 && col0 + 4 <= g.nx - 1);
+    if (g.za) {
+        const int gz = g.z0 + zl;
+        const int zs = (zl / zchunk) * zchunk;
+        const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
+        if (UP) f = f || (zl == zs && gz >= 1);
+        if (DN) f = f || (zl == ze - 1 && gz <= g.nzg - 2);
+    }
+    return f;
+}
+
+__device__ __forceinline__ F4 shfl_up16(const F4& v) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_up(v.v[i], 16, 64);
+    return r;
+}
+__device__ __forceinline__ F4 shfl_down16(const F4& v) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_down(v.v[i], 16, 64);
+    return r;
+}
+
+struct FusedArgs {
+    const float* x_in;
+    const float* xp;      // plane z0-1 of x_in (or nullptr)
+    const float* xn;      // plane z0+nz of x_in (or nullptr)
+    float* q;
+    const float* x0;
+    float* p;
+    float* x_out;
+    float sigma, inv_lambda, tau, sigma_a, inv_1p_sigma_a;
+    double* part_tv;
+    double* part_fid;
+};
+
+// XW: the four waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
+template <int S, int M, bool XW>
+__global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk) {
+    static_assert(S != CENTRAL, "central has a radius-2 adjoint: two-kernel path");
+    __shared__ double sm[16];
+    const FusedCoord c = fused_coord(g, zchunk);
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    constexpr bool NEXT = UP, PREV = DN;       // forward differences need x(+e), backward x(-e)
+    const F4 zero = vsplat<float, 4>(0.f);
+    const F4 mf = g.ta ? mask_factor<float, 4>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<float, 4>(1.f);
+    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : 1.f;
+    double acc_tv = 0.0, acc_fid = 0.0;
+    // channel numbers
+    const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
+    const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
+    const int c_tu = g.ch_t, c_td = (S == HYBRID) ? g.ch_t + 1 : g.ch_t;
+
+    // x planes z (C) and z-1 (P) live in registers; the adjoint accumulators R (plane z-1 waiting
+    // for its z+1 term) and the carried z-up terms U live in LDS, private per thread ([frame][thread]:
+    // conflict-free 16-byte lanes, no barrier needed) -- 4 M vectors of state do not fit the VGPR file
+    __shared__ F4 lds_R[M][256];
+    __shared__ F4 lds_U[M][256];
+    // column terms that cross the 64-column wave tiles INSIDE the block: each wave publishes, per plane and
+    // frame, the col-up value of its last column and the col-down value of its first column (per row);
+    // the neighbouring wave adds them one plane later (after the per-plane barrier), double-buffered
+    __shared__ float edge_cu[XW ? 2 : 1][XW ? M : 1][4][4];
+    __shared__ float edge_cd[XW ? 2 : 1][XW ? M : 1][4][4];
+    const int wave = (int)threadIdx.y;
+    const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+    F4 C[M], P[M];
+    {
+        const float* pc = zplane<float>(g, a.x_in, a.xp, a.xn, 1, c.zs);
+        const float* pp = (PREV && g.za) ? zplane<float>(g, a.x_in, a.xp, a.xn, 1, c.zs - 1) : nullptr;
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            C[t] = c.ok ? vload<float, 4>(pc + (long long)t * g.s_t + c.inpl) : zero;
+            P[t] = (c.ok && pp != nullptr) ? vload<float, 4>(pp + (long long)t * g.s_t + c.inpl) : zero;
+            lds_R[t][tid] = zero;
+            lds_U[t][tid] = zero;
+        }
+    }
+
+    // finalise plane zf (its x values are in `xv`), adjoint accumulator `racc` (un-scaled)
+    auto finalize = [&](int zf, int t, const F4& xv, F4 racc) {
+        if (!c.ok) return;
+        const int eb = (zf - c.zs) & 1;
+        if (XW) {
+            if (UP && c.lx == 0 && wave > 0) racc.v[0] += edge_cu[eb][t][wave - 1][c.row];
+            if (DN && c.lx == 15 && wave < 3) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
+        }
+        const long long off = (long long)zf * g.s_z + (long long)t * g.s_t + c.inpl;
+        const F4 x0v = vload<float, 4>(a.x0 + off), pv = vload<float, 4>(a.p + off);
+        F4 pn, xo;
+        double e2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pn.v[i] = (pv.v[i] + a.sigma_a * (xv.v[i] - x0v.v[i])) * a.inv_1p_sigma_a;
+            xo.v[i] = (xv.v[i] - a.tau * pn.v[i]) - a.tau * (s * racc.v[i]);
+            const double e = (double)xo.v[i] - (double)x0v.v[i];
+            e2 += 0.5 * e * e;
+        }
+        vstore<float, 4>(a.p + off, pn);
+        vstore<float, 4>(a.x_out + off, xo);
+        if (!fused_needs_fixup<S, XW>(g, zf, c.y, c.col0, zchunk)) acc_fid += e2;
+    };
+
+    for (int z = c.zs; z < c.ze; ++z) {
+        const int gz = g.z0 + z;
+        const float* pc = zplane<float>(g, a.x_in, a.xp, a.xn, 1, z);
+        const float* pn = zplane<float>(g, a.x_in, a.xp, a.xn, 1, z + 1);
+        const bool has_pz = PREV && g.za && (gz > 0);
+        const bool has_nz = NEXT && g.za && (pn != nullptr);
+        const bool load_next = (pn != nullptr) && c.ok && (has_nz || (z + 1 < c.ze));
+        F4 cold = zero;        // x(z, t-1)
+        F4 ut_prev = zero;     // wt * q'_tup(z, t-1) * mf, already valid-masked
+        F4 r_prev = zero;      // accumulator of frame t-1 of THIS plane, still missing its time-down term
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const long long off = (long long)t * g.s_t + c.inpl;
+            const F4 N = load_next ? vload<float, 4>(pn + off) : zero;
+            // ------------------------------------------------ neighbourhood of x(z, t)
+            XN<float, 4> n;
+            n.c = C[t];
+            n.col0 = c.col0;
+            n.nr = n.pr = n.nc = n.pc = n.nz = n.pz = n.nt = n.pt = zero;
+            n.h_nr = n.h_pr = n.h_nz = n.h_pz = n.h_nt = n.h_pt = false;
+            {   // halo rows of the wave tile: one predicated load (row 0 lanes read y-1, row 3 lanes y+1)
+                const bool want_up = PREV && (c.row == 0) && c.ok && (c.y > 0);
+                const bool want_dn = NEXT && (c.row == 3) && c.ok && (c.y + 1 < g.ny);
+                F4 halo = zero;
+                if (want_up || want_dn) halo = vload<float, 4>(pc + off + (want_up ? -(long long)g.nx : (long long)g.nx));
+                if (NEXT) {
+                    n.h_nr = c.ok && (c.y + 1 < g.ny);
+                    const F4 sdn = shfl_down16(C[t]);
+                    n.nr = (c.row == 3) ? halo : sdn;
+                }
+                if (PREV) {
+                    n.h_pr = c.ok && (c.y > 0);
+                    const F4 sup = shfl_up16(C[t]);
+                    n.pr = (c.row == 0) ? halo : sup;
+                }
+            }
+            {   // columns: adjacent lane inside the 16-lane row segment, one scalar at the segment edges
+                const bool le = PREV && (c.lx == 0) && c.ok && (c.col0 > 0);
+                const bool re = NEXT && (c.lx == 15) && c.ok && (c.col0 + 4 < g.nx);
+                float edge = 0.f;
+                if (le || re) edge = le ? pc[off - 1] : pc[off + 4];
+                if (NEXT) {
+                    const float sh = __shfl_down(C[t].v[0], 1, 64);
+                    n.nc = shift_left<float, 4>(C[t], (c.lx == 15) ? edge : sh);
+                }
+                if (PREV) {
+                    const float sh = __shfl_up(C[t].v[3], 1, 64);
+                    n.pc = shift_right<float, 4>(C[t], (c.lx == 0) ? edge : sh);
+                }
+            }
+            if (NEXT) {
+                n.h_nz = has_nz; n.nz = N;
+                if (t + 1 < M) { n.h_nt = (g.ta != 0); n.nt = C[(t + 1 < M) ? t + 1 : t]; }
+            }
+            if (PREV) {
+                n.h_pz = has_pz; n.pz = P[t];
+                if (t > 0) { n.h_pt = (g.ta != 0); n.pt = cold; }
+            }
+            F4 o[8];
+            d_slots<S, float, 4>(g, w, n, mf, o);
+            // ------------------------------------------------ dual update (README.md:149-151)
+            F4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = zero;
+            float* qbase = a.q + (long long)z * g.s_dz + off;
+            F4 vs = zero;
+            if (c.ok) {
+                for_each_channel<S>(g, [&](auto slot, int ch) {
+                    constexpr int k = decltype(slot)::value;
+                    v[k] = vload<float, 4>(qbase + (long long)ch * g.s_z) + a.sigma * o[k];
+                    vs = vs + v[k] * v[k];
+                });
+                const F4 ds = sumsq_slots<float, 4>(o);
+                F4 scale;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc_tv += (double)tsqrt(ds.v[i]);
+                    scale.v[i] = 1.f / tmax(1.f, tsqrt(vs.v[i]) * a.inv_lambda);
+                }
+                for_each_channel<S>(g, [&](auto slot, int ch) {
+                    constexpr int k = decltype(slot)::value;
+                    v[k] = v[k] * scale;
+                    vstore<float, 4>(qbase + (long long)ch * g.s_z, v[k]);
+                });
+            }
+            // slots: non-hybrid 0 rows, 1 cols, 2 z, 3 t ; hybrid 0 ru, 1 cu, 2 rd, 3 cd, 4 zu, 5 zd, 6 tu, 7 td
+            constexpr int k_ru = 0, k_cu = 1, k_rd = (S == HYBRID) ? 2 : 0, k_cd = (S == HYBRID) ? 3 : 1;
+            constexpr int k_zu = (S == HYBRID) ? 4 : 2, k_zd = (S == HYBRID) ? 5 : 2;
+            constexpr int k_tu = (S == HYBRID) ? 6 : 3, k_td = (S == HYBRID) ? 7 : 3;
+            // y^ validity: an up channel is defined where the site has a next neighbour, a down
+            // channel where it has a previous one; everything else counts as zero
+            F4 qru = zero, qrd = zero, qcu = zero, qcd = zero, qzu = zero, qzd = zero, qtu = zero, qtd = zero;
+            if (UP) {
+                if (c.ok && c.y + 1 < g.ny) qru = v[k_ru];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qcu.v[i] = (c.ok && c.col0 + i < g.nx - 1) ? v[k_cu].v[i] : 0.f;
+                if (g.za && c.ok && gz + 1 < g.nzg) qzu = w.wz * v[k_zu];
+                if (g.ta && c.ok && t + 1 < M) qtu = (w.wt * v[k_tu]) * mf;
+            }
+            if (DN) {
+                if (c.ok && c.y > 0) qrd = v[k_rd];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qcd.v[i] = (c.ok && c.col0 + i > 0) ? v[k_cd].v[i] : 0.f;
+                if (g.za && c.ok && gz > 0) qzd = w.wz * v[k_zd];
+                if (g.ta && c.ok && t > 0) qtd = (w.wt * v[k_td]) * mf;
+            }
+            // ------------------------------------------------ lagged primal update of plane z-1
+            if (z > c.zs) {
+                F4 rf = lds_R[t][tid];
+                if (DN) rf = rf - qzd;
+                finalize(z - 1, t, P[t], rf);
+            }
+            // ------------------------------------------------ adjoint accumulator of plane z
+            F4 r = zero;
+            if (UP) {
+                r = r - qru - qcu - qzu - qtu;
+                const F4 above = shfl_up16(qru);                      // q'_rowup of the row above
+                if (c.row > 0) r = r + above;
+                const float lft = __shfl_up(qcu.v[3], 1, 64);         // q'_colup one column to the left
+                r = r + shift_right<float, 4>(qcu, (c.lx == 0) ? 0.f : lft);
+                if (g.za) {
+                    r = r + lds_U[t][tid];                            // wz q'_zup(z-1, t)
+                    lds_U[t][tid] = qzu;
+                }
+                r = r + ut_prev;                                      // wt q'_tup(z, t-1)
+                ut_prev = qtu;
+            }
+            if (DN) {
+                r = r + qrd + qcd + qzd + qtd;
+                const F4 below = shfl_down16(qrd);                    // q'_rowdown of the row below
+                if (c.row < 3) r = r - below;
+                const float rgt = __shfl_down(qcd.v[0], 1, 64);       // q'_coldown one column to the right
+                r = r - shift_left<float, 4>(qcd, (c.lx == 15) ? 0.f : rgt);
+                r_prev = r_prev - qtd;                                // time-down term of frame t-1
+            }
+            if (XW) {
+                const int eb = (z - c.zs) & 1;
+                if (UP && c.lx == 15) edge_cu[eb][t][wave][c.row] = qcu.v[3];
+                if (DN && c.lx == 0) edge_cd[eb][t][wave][c.row] = qcd.v[0];
+            }
+            if (t > 0) lds_R[(t > 0) ? t - 1 : 0][tid] = r_prev;     // frame t-1 is complete up to its z+1 term
+            r_prev = r;
+            if (t == M - 1) lds_R[t][tid] = r;
+            cold = C[t];
+            P[t] = C[t];
+            C[t] = N;
+        }
+        if (XW) __syncthreads();      // edge columns of plane z are published before anyone finalises plane z
+    }
+    // last plane of the chunk: its z+1 term (if any) is the fix-up kernel's
+#pragma unroll
+    for (int t = 0; t < M; ++t) finalize(c.ze - 1, t, P[t], lds_R[t][tid]);
+
+    acc_tv = block_sum(acc_tv, sm);
+    if (threadIdx.x == 0 && threadIdx.y == 0) a.part_tv[linear_block_id()] = acc_tv;
+    acc_fid = block_sum(acc_fid, sm);
+    if (threadIdx.x == 0 && threadIdx.y == 0) a.part_fid[linear_block_id()] = acc_fid;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fix-up: add the adjoint terms the sweep could not see (other wave tiles, other z-chunks, other
+// ranks) to x_out and account the fidelity of those sites.  One site-vector per thread; vectors
+// with nothing missing return at once.
+// ---------------------------------------------------------------------------------------------
+struct FixupArgs {
+    const float* q;
+    const float* qp;      // plane z0-1 of the z-up channel (previous rank) or nullptr
+    const float* qn;      // plane z0+nz of the z-down channel (next rank) or nullptr
+    float* x_out;
+    const float* x0;
+    float tau;
+};
+
+// all missing terms of one site-vector; returns its fidelity 1/2 |x_out - x0|^2 (0 if nothing was missing)
+template <int S, bool XW>
+__device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, const FixupArgs& a, int zchunk, int zl, int t, int y,
+                                             int col0) {
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    if (!fused_needs_fixup<S, XW>(g, zl, y, col0, zchunk)) return 0.0;
+    constexpr int CM = XW ? 255 : 63;
+    const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
+    const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
+    const long long inpl = (long long)t * g.s_t + (long long)y * g.nx + col0;
+    const float* qb = a.q + (long long)zl * g.s_dz + inpl;
+    const F4 zero = vsplat<float, 4>(0.f);
+    F4 m = zero;
+    if (UP && (y & 3) == 0 && y >= 1) m = m + vload<float, 4>(qb + (long long)c_ru * g.s_z - g.nx);
+    if (DN && (y & 3) == 3 && y <= g.ny - 2) m = m - vload<float, 4>(qb + (long long)c_rd * g.s_z + g.nx);
+    if (UP && (col0 & CM) == 0 && col0 >= 1) m.v[0] += qb[(long long)c_cu * g.s_z - 1];
+    if (DN && (col0 & CM) == CM - 3 && col0 + 4 <= g.nx - 1) m.v[3] -= qb[(long long)c_cd * g.s_z + 4];
+    if (g.za) {
+        const int gz = g.z0 + zl;
+        const int zs = (zl / zchunk) * zchunk;
+        const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
+        if (UP && zl == zs && gz >= 1) {
+            const F4 u = (zl >= 1) ? vload<float, 4>(qb + (long long)c_zu * g.s_z - g.s_dz) : vload<float, 4>(a.qp + inpl);
+            m = m + w.wz * u;
+        }
+        if (DN && zl == ze - 1 && gz <= g.nzg - 2) {
+            const F4 d = (zl + 1 < g.nz) ? vload<float, 4>(qb + (long long)c_zd * g.s_z + g.s_dz) : vload<float, 4>(a.qn + inpl);
+            m = m - w.wz * d;
+        }
+    }
+    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : 1.f;
+    const long long off = (long long)zl * g.s_z + inpl;
+    const F4 xv = vload<float, 4>(a.x_out + off), x0v = vload<float, 4>(a.x0 + off);
+    F4 xo;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xo.v[i] = xv.v[i] - a.tau * (s * m.v[i]);
+        const double e = (double)xo.v[i] - (double)x0v.v[i];
+        acc += 0.5 * e * e;
+    }
+    vstore<float, 4>(a.x_out + off, xo);
+    return acc;
+}
+
+// is row y one of the rows whose every vector misses a row term ("fix-up rows")?
+template <int S> __device__ __forceinline__ bool is_fix_row(const DG& g, int y) {
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    return (UP && (y & 3) == 0 && y >= 1) || (DN && (y & 3) == 3 && y <= g.ny - 2);
+}
+// is local plane zl a z-chunk edge plane with a missing z term?
+template <int S> __device__ __forceinline__ bool is_fix_plane(const DG& g, int zl, int zchunk) {
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    if (!g.za) return false;
+    const int gz = g.z0 + zl;
+    const int zs = (zl / zchunk) * zchunk;
+    const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
+    return (UP && zl == zs && gz >= 1) || (DN && zl == ze - 1 && gz <= g.nzg - 2);
+}
+
+// The fix-up work is split into three densely mapped classes so that no wave idles:
+//   CLS 0  fix-up rows (every plane): each wave = 256 columns of ONE fix-up row; all terms of those sites
+//   CLS 1  chunk-edge planes, the remaining rows: generic (tiles, m, plane-list) mapping
+//   CLS 2  the sparse column-edge vectors of the remaining rows on the remaining planes: one per thread
+// grid: CLS 0 (tiles_x * row groups, m, nz); CLS 1 (tiles_x * tiles_y, m, 2 * nchunks); CLS 2 (ceil(cands/256), m, nz)
+template <int S, int CLS, bool XW>
+__global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a, int zchunk, double* partials) {
+    __shared__ double sm[16];
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    const int nxv = g.nx / 4;
+    const int tiles_x = (nxv + 63) / 64;
+    double acc = 0.0;
+    if (CLS == 0) {
+        const int bx = (int)blockIdx.x % tiles_x, grp = (int)blockIdx.x / tiles_x;
+        const int ty = (int)threadIdx.y;
+        int y;
+        if (S == HYBRID) y = grp * 8 + ((ty & 1) ? 3 : 0) + ((ty & 2) ? 4 : 0);      // rows 8k + {0, 3, 4, 7}
+        else y = grp * 16 + 4 * ty + (S == DOWNWIND ? 3 : 0);                         // rows 16k + 4j (+3)
+        const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
+        if (col0 < g.nx && y < g.ny && is_fix_row<S>(g, y))
+            acc = fixup_site<S, XW>(g, w, a, zchunk, (int)blockIdx.z, (int)blockIdx.y, y, col0);
+    } else if (CLS == 1) {
+        const int k = (int)blockIdx.z, chunk = k >> 1;
+        const int zs = chunk * zchunk;
+        const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
+        const int zl = (k & 1) ? ze - 1 : zs;
+        const bool dup = (k & 1) && (ze - 1 == zs);                      // one-plane chunk: handled as its "zs"
+        const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
+        const int y = by * 4 + (int)threadIdx.y;
+        const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
+        if (!dup && zs < g.nz && col0 < g.nx && y < g.ny && is_fix_plane<S>(g, zl, zchunk) && !is_fix_row<S>(g, y))
+            acc = fixup_site<S, XW>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
+    } else {
+        // candidates per row: vectors starting at 256 j (left edge of a block tile) and 256 j + 252 (right edge)
+        constexpr int TW = XW ? 256 : 64;
+        const int ntile = (g.nx + TW - 1) / TW, ncand = 2 * ntile;
+        const long long idx = (long long)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;
+        const int zl = (int)blockIdx.z;
+        if (idx < (long long)g.ny * ncand && !is_fix_plane<S>(g, zl, zchunk)) {
+            const int y = (int)(idx / ncand), cnd = (int)(idx % ncand);
+            const int col0 = (cnd >> 1) * TW + ((cnd & 1) ? TW - 4 : 0);
+            if (col0 < g.nx && !is_fix_row<S>(g, y)) acc = fixup_site<S, XW>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
+        }
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[linear_block_id()] = acc;
+}
+
+}  // namespace tv

@@ -1,0 +1,107 @@
+// tv_fused.hip -- instantiations + C-ABI of the one-sweep Chambolle-Pock iteration (tv_fused.h).
+#include "tv_host.h"
+#include "tv_stencil.h"
+#include "tv_fused.h"
+
+static bool fused_m_ok(int m) { return m == 1 || m == 2 || m == 3 || m == 4 || m == 8; }
+
+template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
+#define TV_CASE_F(SC)                                              \
+    case SC:                                                       \
+        switch (m) {                                               \
+            case 1: return f.template operator()<SC, 1>();         \
+            case 2: return f.template operator()<SC, 2>();         \
+            case 3: return f.template operator()<SC, 3>();         \
+            case 4: return f.template operator()<SC, 4>();         \
+            case 8: return f.template operator()<SC, 8>();         \
+        }                                                          \
+        break;
+    switch (scheme) { TV_CASE_F(0) TV_CASE_F(1) TV_CASE_F(3) }
+#undef TV_CASE_F
+    return fail(TV_E_ARG, "unsupported (scheme, M) for the one-sweep path");
+}
+
+extern "C" {
+
+int tv_cp_fused_supported(const tv_geom* g) {
+    DG d;
+    if (make_dg(g, d)) return 0;
+    if (g->dtype != TV_F32 || g->scheme == TV_CENTRAL || d.nx % 4 != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;
+    if (env_int("TV_NO_FUSED", 0)) return 0;
+    return 1;
+}
+
+int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* x0,
+                void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, double* tvout, double* fid,
+                void* ws, void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (!x_in || !q || !x0 || !p || !x_out || !tvout || !fid || !ws) return fail(TV_E_ARG, "NULL array");
+    if (x_in == x_out) return fail(TV_E_ARG, "x_in and x_out must be different buffers (ping-pong)");
+    if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
+    if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
+    if (!aligned16({x_in, x_prev, x_next, q, x0, p, x_out})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const long long nmax = max_partials(d);
+    const int zc = march_zchunk(d);
+    const LC lc = march_cfg(d, zc);
+    double* w0 = (double*)ws;
+    double* w1 = w0 + nmax + kStage + 16;
+    FusedArgs a{(const float*)x_in, (const float*)x_prev, (const float*)x_next, (float*)q, (const float*)x0, (float*)p,
+                (float*)x_out, (float)sigma_D, (float)(1.0 / lambda), (float)tau, (float)sigma_A,
+                (float)(1.0 / (1.0 + sigma_A)), w0, w1};
+    const bool xw = env_int("TV_FUSED_XW", 0) != 0;
+    int rc = dispatch_fused(g->scheme, d.m, [&]<int S, int M>() -> int {
+        if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc);
+        else hipLaunchKernelGGL((k_cp_fused<S, M, false>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    });
+    if (rc) return rc;
+    if (int r2 = reduce_partials(w0, lc.nblocks, nmax, tvout, st)) return r2;
+    return reduce_partials(w1, lc.nblocks, nmax, fid, st);
+}
+
+int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
+                double tau, double* fid, void* ws, void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (!q || !x_out || !x0 || !fid || !ws) return fail(TV_E_ARG, "NULL array");
+    if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
+    if (!aligned16({q, q_prev, q_next, x_out, x0})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    if (int rc = check_y_halos(g, d, q_prev, q_next)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const long long nmax = max_partials(d);
+    const int zc = march_zchunk(d);
+    FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau};
+    const long long tiles_x = (d.nx / 4 + 63) / 64, tiles_y = (d.ny + 3) / 4, nch = (d.nz + zc - 1) / zc;
+    const long long ngrp = (g->scheme == TV_HYBRID) ? (d.ny + 7) / 8 : (d.ny + 15) / 16;
+    const bool xw = env_int("TV_FUSED_XW", 0) != 0;
+    const long long ncand = xw ? 2ll * ((d.nx + 255) / 256) : 2ll * ((d.nx + 63) / 64);
+    const dim3 blk(64, 4, 1);
+    const dim3 g0((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)d.nz);
+    const dim3 g1((unsigned)(tiles_x * tiles_y), (unsigned)d.m, (unsigned)(2 * nch));
+    const dim3 g2((unsigned)(((long long)d.ny * ncand + 255) / 256), (unsigned)d.m, (unsigned)d.nz);
+    const long long n0 = (long long)g0.x * g0.y * g0.z, n1 = d.za ? (long long)g1.x * g1.y * g1.z : 0,
+                    n2 = (long long)g2.x * g2.y * g2.z;
+    if (n0 + n1 + n2 > nmax) return fail(TV_E_ARG, "internal: fix-up partials exceed the workspace");
+    double* w0 = (double*)ws;
+    auto launch = [&]<int S, bool XW>() -> int {
+        hipLaunchKernelGGL((k_cp_fixup<S, 0, XW>), g0, blk, 0, st, d, make_w<float>(g), a, zc, w0);
+        if (d.za) hipLaunchKernelGGL((k_cp_fixup<S, 1, XW>), g1, blk, 0, st, d, make_w<float>(g), a, zc, w0 + n0);
+        hipLaunchKernelGGL((k_cp_fixup<S, 2, XW>), g2, blk, 0, st, d, make_w<float>(g), a, zc, w0 + n0 + n1);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    int rc;
+    switch (g->scheme) {
+        case TV_UPWIND: rc = xw ? launch.template operator()<UPWIND, true>() : launch.template operator()<UPWIND, false>(); break;
+        case TV_DOWNWIND: rc = xw ? launch.template operator()<DOWNWIND, true>() : launch.template operator()<DOWNWIND, false>(); break;
+        default: rc = xw ? launch.template operator()<HYBRID, true>() : launch.template operator()<HYBRID, false>(); break;
+    }
+    if (rc) return rc;
+    return reduce_partials(w0, n0 + n1 + n2, nmax, fid, st);
+}
+
+}  // extern "C"

@@ -138,7 +138,16 @@ inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
     return d.m == 1 || d.m == 2 || d.m == 3 || d.m == 4 || d.m == 8 || d.m == 16;
 }
 inline int march_zchunk(const DG& d) {
-    int zc = env_int("TV_ZCHUNK", 16);
+    // planes per z-chunk: long chunks amortise the chunk prologue (and, for the one-sweep CP kernel, the
+    // chunk-edge fix-up planes); short ones keep >= ~4096 blocks in flight.  TV_ZCHUNK overrides.
+    int zc = env_int("TV_ZCHUNK", 0);
+    if (zc <= 0) {
+        const long long tiles = (long long)((d.nx / 4 + 63) / 64) * ((d.ny + 3) / 4);
+        const long long want_chunks = (4096 + tiles - 1) / tiles;
+        zc = (int)(d.nz / (want_chunks > 0 ? want_chunks : 1));
+        if (zc > 32) zc = 32;
+        if (zc < 4) zc = 4;
+    }
     if (zc < 1) zc = 1;
     if (zc > d.nz) zc = d.nz;
     return zc;

@@ -456,7 +456,7 @@ int tv_num_channels(const tv_geom* g) {
 size_t tv_workspace_bytes(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
-    return (size_t)(max_partials(d) + kStage + 16) * sizeof(double);
+    return (size_t)(2 * (max_partials(d) + kStage + 16)) * sizeof(double);    // two independent partial arrays
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -79,7 +79,9 @@ class ChambollePock(_SlabProblem):
     and returns the loss history (one host synchronisation at the end)."""
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
-                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True):
+                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None):
+        """fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
+        iteration) whenever the geometry supports it, False = always the dual + primal kernel pair."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
@@ -96,9 +98,15 @@ class ChambollePock(_SlabProblem):
         self.xh_next = self.new_plane() if pl.x_need_next else None
         self.qh_prev = self.new_plane() if pl.g_need_prev else None
         self.qh_next = self.new_plane() if pl.g_need_next else None
-        self.overlap = bool(overlap) and sh and self.slab.nz >= 3
+        self.fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) if fused is None else bool(fused)
+        if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
+            raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry "
+                             "(needs fp32, Nx % 4 == 0, M in {1,2,3,4,8}, a non-central scheme)")
+        self.x_alt = torch.empty_like(self.x) if self.fused else None      # ping-pong partner of x
+        self.overlap = bool(overlap) and sh and self.slab.nz >= 3 and not self.fused
         self.hist = None
         self.it = 0
+        self.timing = None      # set to a list to collect (start, after kernel 1, after kernel 2) HIP events per step
         self._scratch = torch.zeros(6, dtype=torch.float64, device=self.device)
 
     # ---- one phase on local planes [a, b) -----------------------------------------------------
@@ -113,14 +121,47 @@ class ChambollePock(_SlabProblem):
                                         _nv.ptr(self.x0[a:b]), _nv.ptr(self.p[a:b]), self.tau, self.sigma_A,
                                         out.data_ptr(), _nv.ptr(self.ws), self.stream))
 
+    def _step_fused(self, out):
+        """One-sweep iteration: x halos -> sweep (x -> x_alt) -> q' halos -> fix-up -> swap."""
+        s, g = self.slab, self.geo
+        ev = self._events()
+        s.wait(self.plan.exchange_image(self.x, self.xh_prev, self.xh_next))
+        if ev:
+            ev[0].record()
+        _nv.check(self.lib.tv_cp_fused(g.ref, _nv.ptr(self.x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.q),
+                                       _nv.ptr(self.x0), _nv.ptr(self.p), _nv.ptr(self.x_alt), self.sigma_D, self.reg, self.tau,
+                                       self.sigma_A, out[0:1].data_ptr(), out[3:4].data_ptr(), _nv.ptr(self.ws), self.stream))
+        if ev:
+            ev[1].record()
+        s.wait(self.plan.exchange_grad(self.q, self.qh_prev[0] if self.qh_prev is not None else None,
+                                       self.qh_next[0] if self.qh_next is not None else None))
+        _nv.check(self.lib.tv_cp_fixup(g.ref, _nv.ptr(self.q), _nv.ptr(self.qh_prev), _nv.ptr(self.qh_next), _nv.ptr(self.x_alt),
+                                       _nv.ptr(self.x0), self.tau, out[4:5].data_ptr(), _nv.ptr(self.ws), self.stream))
+        if ev:
+            ev[2].record()
+        self.x, self.x_alt = self.x_alt, self.x
+        self.it += 1
+
+    def _events(self):
+        if self.timing is None:
+            return None
+        ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+        self.timing.append(ev)
+        return ev
+
     def step(self, out=None):
         """Enqueue one iteration.  out: fp64 device tensor of 6 slots receiving the TV parts [0:3]
         and fidelity parts [3:6] of this rank (summed later); defaults to an internal scratch."""
         out = self._scratch if out is None else out
+        if self.fused:
+            return self._step_fused(out)
         nz, s = self.slab.nz, self.slab
         x, q = self.x, self.q
+        ev = self._events()
         # ---------------- dual: q <- proj(q + sigma D x) -----------------------------------------
         h = self.plan.exchange_image(x, self.xh_prev, self.xh_next)
+        if ev:
+            ev[0].record()
         if self.overlap:
             self._dual(1, nz - 1, x[0:1], x[nz - 1:nz], out[0:1])
             s.wait(h)
@@ -129,6 +170,8 @@ class ChambollePock(_SlabProblem):
         else:
             s.wait(h)
             self._dual(0, nz, self.xh_prev, self.xh_next, out[0:1])
+        if ev:
+            ev[1].record()
         # ---------------- primal: x <- x - tau p - tau D^T q ---------------------------------------
         h = self.plan.exchange_grad(q, self.qh_prev[0] if self.qh_prev is not None else None,
                                     self.qh_next[0] if self.qh_next is not None else None)
@@ -140,6 +183,8 @@ class ChambollePock(_SlabProblem):
         else:
             s.wait(h)
             self._primal(0, nz, self.qh_prev, self.qh_next, out[3:4])
+        if ev:
+            ev[2].record()
         self.it += 1
 
     def run(self, n_iter, record_loss=True):

@@ -202,6 +202,41 @@ def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, mo
         np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=1e-4, atol=2e-3)
 
 
+FUSED_SHAPES = [(1, 1, 64, 64), (5, 1, 9, 64), (6, 2, 7, 68), (7, 3, 10, 256), (9, 4, 5, 132), (5, 8, 6, 320), (20, 8, 4, 64)]
+
+
+@pytest.mark.parametrize("scheme", ["upwind", "downwind", "hybrid"])
+@pytest.mark.parametrize("zchunk,xw", [("2", "0"), ("16", "0"), ("0", "1"), ("3", "1")])
+def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, monkeypatch):
+    """tv_cp_fused + tv_cp_fixup (q read/written once) against tv_cp_dual + tv_cp_primal and the oracle:
+    ragged rows (Ny % 4 != 0), partial wave tiles (Nx % 64 != 0), chunk edges inside the volume."""
+    import torch
+    from pytv import _native as nv
+    monkeypatch.setenv("TV_ZCHUNK", zchunk)          # "0" = the library's own choice
+    monkeypatch.setenv("TV_FUSED_XW", xw)            # in-block column-edge exchange variant
+    rng = np.random.default_rng(41)
+    for shape in FUSED_SHAPES:
+        for lz, mu, use_mask in ((1.0, 1.0, False), (0.0, 0.6, True), (2.5, 0.0, False)):
+            mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
+            kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=3.0 if use_mask else 0)
+            x0 = (50.0 * rng.random(shape)).astype(np.float32)
+            a = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 5.0, scheme=scheme, **kw)
+            b = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 5.0, scheme=scheme, fused=False, **kw)
+            assert a.fused and not b.fused
+            la, lb = a.run(9), b.run(9)
+            wx, wloss = orc.chambolle_pock(x0.astype(np.float64), 9, 5.0, scheme=scheme, **kw)
+            msg = "%s %s %s" % (scheme, shape, (lz, mu, use_mask))
+            np.testing.assert_allclose(la, wloss, rtol=1e-5, err_msg=msg)
+            np.testing.assert_allclose(la, lb, rtol=2e-6, err_msg=msg)
+            np.testing.assert_allclose(a.result().cpu().numpy(), wx, rtol=1e-5, atol=1e-3, err_msg=msg)
+            np.testing.assert_allclose(a.q.cpu().numpy(), b.q.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
+            np.testing.assert_allclose(a.p.cpu().numpy(), b.p.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
+    g = nv.Geometry((4, 5, 8, 64), "hybrid", torch.float32, "cuda")
+    assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # M = 5 is not instantiated
+    g = nv.Geometry((4, 4, 8, 64), "central", torch.float32, "cuda")
+    assert nv.lib().tv_cp_fused_supported(g.ref) == 0
+
+
 def test_central_two_planes_uses_forward_z(pytv):
     # SURVEY Q3: the reference raises for central with Nz == 2; the build (and the oracle) use the
     # forward z stencil, the evident intent of pytv/tv_operators_CPU.py:338-340.  Unpinned.
