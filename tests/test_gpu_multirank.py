@@ -44,10 +44,16 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
         slab = Slab(shape[0])
         x0 = torch.as_tensor(slab.local(x0_full).copy()).cuda()
         out = {}
-        cp = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, slab=slab, overlap=overlap, **kw)
+        # two-kernel path (interior-first overlap when asked) ...
+        cp = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, slab=slab, overlap=overlap, fused=False, **kw)
         out["cp_loss"] = cp.run(8)
         out["cp_x"] = cp.result().cpu().numpy()
         out["cp_overlap"] = cp.overlap
+        # ... and the library's default (the one-sweep kernel where the geometry supports it)
+        cp2 = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, slab=slab, **kw)
+        out["cp2_loss"] = cp2.run(8)
+        out["cp2_x"] = cp2.result().cpu().numpy()
+        out["cp2_fused"] = cp2.fused
         if min(n for _, n in slab.parts) >= 2:
             sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, slab=slab, **kw)
             out["sg_loss"] = sg.run(5)
@@ -77,6 +83,10 @@ def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap):
         z0, nz = ret[r]["z"]
         np.testing.assert_allclose(ret[r]["cp_loss"], wloss, rtol=1e-5, err_msg="rank %d" % r)
         np.testing.assert_allclose(ret[r]["cp_x"], wx[z0:z0 + nz], rtol=1e-5, atol=2e-3, err_msg="rank %d" % r)
+        np.testing.assert_allclose(ret[r]["cp2_loss"], wloss, rtol=1e-5, err_msg="rank %d (default path)" % r)
+        np.testing.assert_allclose(ret[r]["cp2_x"], wx[z0:z0 + nz], rtol=1e-5, atol=2e-3, err_msg="rank %d (default path)" % r)
+    if scheme != "central" and shape[-1] % 4 == 0 and shape[-1] >= 64:
+        assert all(ret[r]["cp2_fused"] for r in range(world))
     if overlap:
         assert any(ret[r]["cp_overlap"] for r in range(world))
     if "sg_loss" in ret[0]:
