@@ -134,7 +134,7 @@ def main():
                                     slab=slab, overlap=not args.no_overlap, fused=False if args.two_kernel else None)
     nd = cp.geo.nd
     K, W = args.steps, args.warmup
-    hist = torch.zeros((K + W, 6), dtype=torch.float64, device=device)
+    hist = torch.zeros((K + W, cp.SLOTS), dtype=torch.float64, device=device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -163,7 +163,7 @@ def main():
         dist.all_reduce(hist_r, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
     h = hist_r.cpu().numpy()
-    loss = h[:, 3:6].sum(axis=1) + 25.0 * h[:, 0:3].sum(axis=1)
+    loss = cp.loss_from_slots(h, 25.0)
 
     V = float(np.prod(shape))
     V_local = float(slab.nz * shape[1] * shape[2] * shape[3])
@@ -177,7 +177,7 @@ def main():
         "config": {"workload": "%s %s fp32 %s CP" % (args.workload, "x".join(str(s) for s in shape), args.scheme),
                    "shape": list(shape), "scheme": args.scheme, "nd": nd, "reg_z_over_reg": wl["reg_z"], "reg_time": wl["reg_time"],
                    "lambda": 25.0, "sigma_D": cp.sigma_D, "sigma_A": cp.sigma_A, "tau": cp.tau,
-                   "parallelism": "z-slab x%d%s" % (world, " (halo overlapped)" if cp.overlap else "")},
+                   "parallelism": "z-slab x%d%s" % (world, " (halo overlapped)" if (cp.overlap or getattr(cp, "overlap_fused", False)) else "")},
         "voxel_iterations_per_sec": it_s * V,
         "hbm_gbps_iteration": {"readme_unfused_(8+3Nd)_words": bytes_iter_algo * it_s / 1e9 / world,
                                "two_kernel_(6+3Nd)_words": bytes_iter_fused * it_s / 1e9 / world,

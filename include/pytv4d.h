@@ -107,13 +107,18 @@ int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void
  *                           wave tile (4 rows x 64 cols), a z-chunk or the slab; *tv = |D x_in|_{2,1},
  *                           *fid = 1/2 |x_out - x0|^2 over the sites that are already complete
  *   tv_cp_fixup           : adds the missing terms to x_out (q_prev / q_next as in tv_DT) and returns
- *                           the fidelity of those sites in *fid; total fidelity = sum of the two.   */
+ *                           the fidelity of those sites in *fid; total fidelity = sum of the two.
+ * Both can be restricted to a range so that halo exchanges hide behind the interior work: the sweep to
+ * z-chunks [chunk_begin, chunk_begin + chunk_count) (tv_cp_zchunk() planes each, chunk_count < 0 = all),
+ * the fix-up to local planes [z_begin, z_begin + z_count) (z_count < 0 = all).  Only the first chunk reads
+ * x_prev, only the last x_next; only plane 0 reads q_prev, only plane nz-1 q_next.                         */
 int tv_cp_fused_supported(const tv_geom* g);
+int tv_cp_zchunk(const tv_geom* g);
 int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* x0,
-                void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, double* tv, double* fid,
-                void* ws, void* stream);
+                void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int64_t chunk_begin,
+                int64_t chunk_count, double* tv, double* fid, void* ws, void* stream);
 int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
-                double tau, double* fid, void* ws, void* stream);
+                double tau, int64_t z_begin, int64_t z_count, double* fid, void* ws, void* stream);
 
 /* ---- fused ADMM updates (not in the reference; README.md:26,135 mention only) --------------- */
 /* v = D x + u; z = v * max(0, 1 - thresh/|v|_2); u = v - z; *tv (device fp64) = |D x|_{2,1}. */

@@ -32,7 +32,7 @@ struct FusedCoord {
 };
 
 // block (64, 4): wave = threadIdx.y covers columns [64 w, 64 w + 64) of a 4-row x 256-col block tile
-__device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk) {
+__device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk, int chunk0) {
     FusedCoord c;
     c.lane = (int)threadIdx.x;
     c.row = c.lane >> 4;
@@ -43,7 +43,7 @@ __device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk) {
     c.col0 = (bx * 64 + (int)threadIdx.y * 16 + c.lx) * 4;
     c.y = by * 4 + c.row;
     c.ok = (c.col0 < g.nx) && (c.y < g.ny);
-    c.zs = (int)blockIdx.y * zchunk;
+    c.zs = ((int)blockIdx.y + chunk0) * zchunk;
     c.ze = (c.zs + zchunk < g.nz) ? c.zs + zchunk : g.nz;
     c.inpl = (long long)c.y * g.nx + c.col0;
     return c;
@@ -97,10 +97,10 @@ struct FusedArgs {
 
 // XW: the four waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
 template <int S, int M, bool XW>
-__global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk) {
+__global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk, int chunk0) {
     static_assert(S != CENTRAL, "central has a radius-2 adjoint: two-kernel path");
     __shared__ double sm[16];
-    const FusedCoord c = fused_coord(g, zchunk);
+    const FusedCoord c = fused_coord(g, zchunk, chunk0);
     constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
     constexpr bool NEXT = UP, PREV = DN;       // forward differences need x(+e), backward x(-e)
     const F4 zero = vsplat<float, 4>(0.f);
@@ -332,6 +332,7 @@ struct FixupArgs {
     float* x_out;
     const float* x0;
     float tau;
+    int chunk0;           // class 1: first chunk whose edge planes are visited
 };
 
 // all missing terms of one site-vector; returns its fidelity 1/2 |x_out - x0|^2 (0 if nothing was missing)
@@ -400,7 +401,9 @@ template <int S> __device__ __forceinline__ bool is_fix_plane(const DG& g, int z
 //   CLS 2  the sparse column-edge vectors of the remaining rows on the remaining planes: one per thread
 // grid: CLS 0 (tiles_x * row groups, m, nz); CLS 1 (tiles_x * tiles_y, m, 2 * nchunks); CLS 2 (ceil(cands/256), m, nz)
 template <int S, int CLS, bool XW>
-__global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a, int zchunk, double* partials) {
+__global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a, int zchunk, int zb, int zn, double* partials) {
+    // the call covers local planes [zb, zb + zn): classes 0 and 2 have grid z = zn; class 1 has two grid-z
+    // slots (first / last plane) per z-chunk intersecting the range, starting at chunk a.chunk0
     __shared__ double sm[16];
     constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
     const int nxv = g.nx / 4;
@@ -414,9 +417,9 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
         else y = grp * 16 + 4 * ty + (S == DOWNWIND ? 3 : 0);                         // rows 16k + 4j (+3)
         const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
         if (col0 < g.nx && y < g.ny && is_fix_row<S>(g, y))
-            acc = fixup_site<S, XW>(g, w, a, zchunk, (int)blockIdx.z, (int)blockIdx.y, y, col0);
+            acc = fixup_site<S, XW>(g, w, a, zchunk, zb + (int)blockIdx.z, (int)blockIdx.y, y, col0);
     } else if (CLS == 1) {
-        const int k = (int)blockIdx.z, chunk = k >> 1;
+        const int k = (int)blockIdx.z, chunk = a.chunk0 + (k >> 1);
         const int zs = chunk * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
         const int zl = (k & 1) ? ze - 1 : zs;
@@ -424,14 +427,15 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
         const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
         const int y = by * 4 + (int)threadIdx.y;
         const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
-        if (!dup && zs < g.nz && col0 < g.nx && y < g.ny && is_fix_plane<S>(g, zl, zchunk) && !is_fix_row<S>(g, y))
+        if (!dup && zs < g.nz && zl >= zb && zl < zb + zn && col0 < g.nx && y < g.ny && is_fix_plane<S>(g, zl, zchunk) &&
+            !is_fix_row<S>(g, y))
             acc = fixup_site<S, XW>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
     } else {
         // candidates per row: vectors starting at 256 j (left edge of a block tile) and 256 j + 252 (right edge)
         constexpr int TW = XW ? 256 : 64;
         const int ntile = (g.nx + TW - 1) / TW, ncand = 2 * ntile;
         const long long idx = (long long)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;
-        const int zl = (int)blockIdx.z;
+        const int zl = zb + (int)blockIdx.z;
         if (idx < (long long)g.ny * ncand && !is_fix_plane<S>(g, zl, zchunk)) {
             const int y = (int)(idx / ncand), cnd = (int)(idx % ncand);
             const int col0 = (cnd >> 1) * TW + ((cnd & 1) ? TW - 4 : 0);

@@ -31,9 +31,15 @@ int tv_cp_fused_supported(const tv_geom* g) {
     return 1;
 }
 
+int tv_cp_zchunk(const tv_geom* g) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    return march_zchunk(d);
+}
+
 int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* x0,
-                void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, double* tvout, double* fid,
-                void* ws, void* stream) {
+                void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int64_t chunk_begin,
+                int64_t chunk_count, double* tvout, double* fid, void* ws, void* stream) {
     DG d;
     if (int rc = make_dg(g, d)) return rc;
     if (!x_in || !q || !x0 || !p || !x_out || !tvout || !fid || !ws) return fail(TV_E_ARG, "NULL array");
@@ -41,11 +47,27 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
     if (!aligned16({x_in, x_prev, x_next, q, x0, p, x_out})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
-    if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     const int zc = march_zchunk(d);
-    const LC lc = march_cfg(d, zc);
+    {   // halos are only needed by the chunks that touch the slab boundary
+        const long long nch_all = (d.nz + zc - 1) / zc;
+        const long long cb = (chunk_count < 0) ? 0 : chunk_begin, ce = (chunk_count < 0) ? nch_all : chunk_begin + chunk_count;
+        const bool first = (cb == 0 && ce > 0), last = (ce == nch_all && ce > cb);
+        if (int rc = check_x_halos(g, d, first ? x_prev : (const void*)x_in, last ? x_next : (const void*)x_in)) return rc;
+    }
+    LC lc = march_cfg(d, zc);
+    const long long nch = lc.grid.y;
+    if (chunk_count < 0) { chunk_begin = 0; chunk_count = nch; }
+    if (chunk_begin < 0 || chunk_begin + chunk_count > nch) return fail(TV_E_ARG, "chunk range outside the slab");
+    if (chunk_count == 0) {
+        HIP_TRY(hipMemsetAsync(tvout, 0, sizeof(double), st));
+        HIP_TRY(hipMemsetAsync(fid, 0, sizeof(double), st));
+        return 0;
+    }
+    lc.grid.y = (unsigned)chunk_count;
+    lc.nblocks = (long long)lc.grid.x * chunk_count;
+    const int chunk0 = (int)chunk_begin;
     double* w0 = (double*)ws;
     double* w1 = w0 + nmax + kStage + 16;
     FusedArgs a{(const float*)x_in, (const float*)x_prev, (const float*)x_next, (float*)q, (const float*)x0, (float*)p,
@@ -53,8 +75,8 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
                 (float)(1.0 / (1.0 + sigma_A)), w0, w1};
     const bool xw = env_int("TV_FUSED_XW", 0) != 0;
     int rc = dispatch_fused(g->scheme, d.m, [&]<int S, int M>() -> int {
-        if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc);
-        else hipLaunchKernelGGL((k_cp_fused<S, M, false>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc);
+        if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
+        else hipLaunchKernelGGL((k_cp_fused<S, M, false>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
         HIP_TRY(hipGetLastError());
         return 0;
     });
@@ -64,33 +86,41 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
 }
 
 int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
-                double tau, double* fid, void* ws, void* stream) {
+                double tau, int64_t z_begin, int64_t z_count, double* fid, void* ws, void* stream) {
     DG d;
     if (int rc = make_dg(g, d)) return rc;
     if (!q || !x_out || !x0 || !fid || !ws) return fail(TV_E_ARG, "NULL array");
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
     if (!aligned16({q, q_prev, q_next, x_out, x0})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
-    if (int rc = check_y_halos(g, d, q_prev, q_next)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     const int zc = march_zchunk(d);
-    FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau};
+    if (z_count < 0) { z_begin = 0; z_count = d.nz; }
+    if (z_begin < 0 || z_begin + z_count > d.nz) return fail(TV_E_ARG, "plane range outside the slab");
+    if (z_count == 0) {
+        HIP_TRY(hipMemsetAsync(fid, 0, sizeof(double), st));
+        return 0;
+    }
+    if (int rc = check_y_halos(g, d, (z_begin == 0) ? q_prev : q, (z_begin + z_count == d.nz) ? q_next : q)) return rc;
+    const int zb = (int)z_begin, zn = (int)z_count;
+    const int chunk_lo = zb / zc, chunk_hi = (zb + zn - 1) / zc;           // chunks intersecting the plane range
+    FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau, chunk_lo};
     const long long tiles_x = (d.nx / 4 + 63) / 64, tiles_y = (d.ny + 3) / 4, nch = (d.nz + zc - 1) / zc;
     const long long ngrp = (g->scheme == TV_HYBRID) ? (d.ny + 7) / 8 : (d.ny + 15) / 16;
     const bool xw = env_int("TV_FUSED_XW", 0) != 0;
     const long long ncand = xw ? 2ll * ((d.nx + 255) / 256) : 2ll * ((d.nx + 63) / 64);
     const dim3 blk(64, 4, 1);
-    const dim3 g0((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)d.nz);
-    const dim3 g1((unsigned)(tiles_x * tiles_y), (unsigned)d.m, (unsigned)(2 * nch));
-    const dim3 g2((unsigned)(((long long)d.ny * ncand + 255) / 256), (unsigned)d.m, (unsigned)d.nz);
+    const dim3 g0((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)zn);
+    const dim3 g1((unsigned)(tiles_x * tiles_y), (unsigned)d.m, (unsigned)(2 * (chunk_hi - chunk_lo + 1)));
+    const dim3 g2((unsigned)(((long long)d.ny * ncand + 255) / 256), (unsigned)d.m, (unsigned)zn);
     const long long n0 = (long long)g0.x * g0.y * g0.z, n1 = d.za ? (long long)g1.x * g1.y * g1.z : 0,
                     n2 = (long long)g2.x * g2.y * g2.z;
     if (n0 + n1 + n2 > nmax) return fail(TV_E_ARG, "internal: fix-up partials exceed the workspace");
     double* w0 = (double*)ws;
     auto launch = [&]<int S, bool XW>() -> int {
-        hipLaunchKernelGGL((k_cp_fixup<S, 0, XW>), g0, blk, 0, st, d, make_w<float>(g), a, zc, w0);
-        if (d.za) hipLaunchKernelGGL((k_cp_fixup<S, 1, XW>), g1, blk, 0, st, d, make_w<float>(g), a, zc, w0 + n0);
-        hipLaunchKernelGGL((k_cp_fixup<S, 2, XW>), g2, blk, 0, st, d, make_w<float>(g), a, zc, w0 + n0 + n1);
+        hipLaunchKernelGGL((k_cp_fixup<S, 0, XW>), g0, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0);
+        if (d.za) hipLaunchKernelGGL((k_cp_fixup<S, 1, XW>), g1, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0);
+        hipLaunchKernelGGL((k_cp_fixup<S, 2, XW>), g2, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0 + n1);
         HIP_TRY(hipGetLastError());
         return 0;
     };

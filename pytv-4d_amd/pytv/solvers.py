@@ -75,8 +75,18 @@ class _SlabProblem:
 class ChambollePock(_SlabProblem):
     """min_x 1/2 |x - x0|^2 + regularization * TV(x), README.md:141-157 with the state on the GPU.
 
+    Per-step scalars: ``SLOTS`` fp64 device words, TV parts in [0:6], fidelity parts in [6:12] (one slot per
+    launch; they are summed, over launches and over ranks, only when the loss is asked for).
+
     x0 : this rank's slab (device tensor).  ``step()`` enqueues one iteration; ``run(n)`` enqueues n
     and returns the loss history (one host synchronisation at the end)."""
+
+    SLOTS = 12
+
+    @classmethod
+    def loss_from_slots(cls, h, regularization):
+        """README.md:157 loss from an (n, SLOTS) array of (already rank-summed) per-step scalars."""
+        return h[:, 6:12].sum(axis=1) + regularization * h[:, 0:6].sum(axis=1)
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
                  factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None):
@@ -107,7 +117,12 @@ class ChambollePock(_SlabProblem):
         self.hist = None
         self.it = 0
         self.timing = None      # set to a list to collect (start, after kernel 1, after kernel 2) HIP events per step
-        self._scratch = torch.zeros(6, dtype=torch.float64, device=self.device)
+        self._scratch = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
+        if self.fused:
+            self.zchunk = int(self.lib.tv_cp_zchunk(self.geo.ref))
+            self.nchunks = (self.slab.nz + self.zchunk - 1) // self.zchunk
+            # interior-first scheduling of the one-sweep path needs an interior: >= 3 chunks and >= 3 planes
+            self.overlap_fused = bool(overlap) and sh and self.nchunks >= 3 and self.slab.nz >= 3
 
     # ---- one phase on local planes [a, b) -----------------------------------------------------
     def _dual(self, a, b, xp, xn, out):
@@ -121,22 +136,47 @@ class ChambollePock(_SlabProblem):
                                         _nv.ptr(self.x0[a:b]), _nv.ptr(self.p[a:b]), self.tau, self.sigma_A,
                                         out.data_ptr(), _nv.ptr(self.ws), self.stream))
 
+    def _sweep(self, c0, cn, xp, xn, tv_slot, fid_slot):
+        g = self.geo
+        _nv.check(self.lib.tv_cp_fused(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.q), _nv.ptr(self.x0),
+                                       _nv.ptr(self.p), _nv.ptr(self.x_alt), self.sigma_D, self.reg, self.tau, self.sigma_A,
+                                       c0, cn, tv_slot.data_ptr(), fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def _fixup(self, z0, zn, qp, qn, fid_slot):
+        g = self.geo
+        _nv.check(self.lib.tv_cp_fixup(g.ref, _nv.ptr(self.q), _nv.ptr(qp), _nv.ptr(qn), _nv.ptr(self.x_alt), _nv.ptr(self.x0),
+                                       self.tau, z0, zn, fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
+
     def _step_fused(self, out):
-        """One-sweep iteration: x halos -> sweep (x -> x_alt) -> q' halos -> fix-up -> swap."""
-        s, g = self.slab, self.geo
+        """One-sweep iteration: x halos -> sweep (x -> x_alt) -> q' halos -> fix-up -> swap.  With a sharded
+        slab the interior chunks / planes run while the halo planes are in flight."""
+        s, nz = self.slab, self.slab.nz
         ev = self._events()
-        s.wait(self.plan.exchange_image(self.x, self.xh_prev, self.xh_next))
+        qhp = self.qh_prev[0] if self.qh_prev is not None else None
+        qhn = self.qh_next[0] if self.qh_next is not None else None
+        h = self.plan.exchange_image(self.x, self.xh_prev, self.xh_next)
         if ev:
             ev[0].record()
-        _nv.check(self.lib.tv_cp_fused(g.ref, _nv.ptr(self.x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.q),
-                                       _nv.ptr(self.x0), _nv.ptr(self.p), _nv.ptr(self.x_alt), self.sigma_D, self.reg, self.tau,
-                                       self.sigma_A, out[0:1].data_ptr(), out[3:4].data_ptr(), _nv.ptr(self.ws), self.stream))
+        if self.overlap_fused:
+            nch = self.nchunks
+            self._sweep(1, nch - 2, None, None, out[0:1], out[6:7])
+            s.wait(h)
+            self._sweep(0, 1, self.xh_prev, None, out[1:2], out[7:8])
+            self._sweep(nch - 1, 1, None, self.xh_next, out[2:3], out[8:9])
+        else:
+            s.wait(h)
+            self._sweep(0, -1, self.xh_prev, self.xh_next, out[0:1], out[6:7])
         if ev:
             ev[1].record()
-        s.wait(self.plan.exchange_grad(self.q, self.qh_prev[0] if self.qh_prev is not None else None,
-                                       self.qh_next[0] if self.qh_next is not None else None))
-        _nv.check(self.lib.tv_cp_fixup(g.ref, _nv.ptr(self.q), _nv.ptr(self.qh_prev), _nv.ptr(self.qh_next), _nv.ptr(self.x_alt),
-                                       _nv.ptr(self.x0), self.tau, out[4:5].data_ptr(), _nv.ptr(self.ws), self.stream))
+        h = self.plan.exchange_grad(self.q, qhp, qhn)
+        if self.overlap_fused:
+            self._fixup(1, nz - 2, None, None, out[9:10])
+            s.wait(h)
+            self._fixup(0, 1, self.qh_prev, None, out[10:11])
+            self._fixup(nz - 1, 1, None, self.qh_next, out[11:12])
+        else:
+            s.wait(h)
+            self._fixup(0, -1, self.qh_prev, self.qh_next, out[9:10])
         if ev:
             ev[2].record()
         self.x, self.x_alt = self.x_alt, self.x
@@ -150,8 +190,8 @@ class ChambollePock(_SlabProblem):
         return ev
 
     def step(self, out=None):
-        """Enqueue one iteration.  out: fp64 device tensor of 6 slots receiving the TV parts [0:3]
-        and fidelity parts [3:6] of this rank (summed later); defaults to an internal scratch."""
+        """Enqueue one iteration.  out: fp64 device tensor of SLOTS words receiving this rank's TV parts
+        [0:6] and fidelity parts [6:12] (summed later); defaults to an internal scratch."""
         out = self._scratch if out is None else out
         if self.fused:
             return self._step_fused(out)
@@ -176,13 +216,13 @@ class ChambollePock(_SlabProblem):
         h = self.plan.exchange_grad(q, self.qh_prev[0] if self.qh_prev is not None else None,
                                     self.qh_next[0] if self.qh_next is not None else None)
         if self.overlap:
-            self._primal(1, nz - 1, q[0, self.ch_back], q[nz - 1, self.ch_fwd], out[3:4])
+            self._primal(1, nz - 1, q[0, self.ch_back], q[nz - 1, self.ch_fwd], out[6:7])
             s.wait(h)
-            self._primal(0, 1, self.qh_prev, q[1, self.ch_fwd], out[4:5])
-            self._primal(nz - 1, nz, q[nz - 2, self.ch_back], self.qh_next, out[5:6])
+            self._primal(0, 1, self.qh_prev, q[1, self.ch_fwd], out[7:8])
+            self._primal(nz - 1, nz, q[nz - 2, self.ch_back], self.qh_next, out[8:9])
         else:
             s.wait(h)
-            self._primal(0, nz, self.qh_prev, self.qh_next, out[3:4])
+            self._primal(0, nz, self.qh_prev, self.qh_next, out[6:7])
         if ev:
             ev[2].record()
         self.it += 1
@@ -190,14 +230,13 @@ class ChambollePock(_SlabProblem):
     def run(self, n_iter, record_loss=True):
         """n_iter iterations; returns the README's loss history (README.md:157) as a numpy array
         (global over all ranks), or None."""
-        hist = torch.zeros((n_iter, 6), dtype=torch.float64, device=self.device)
+        hist = torch.zeros((n_iter, self.SLOTS), dtype=torch.float64, device=self.device)
         for it in range(n_iter):
             self.step(hist[it])
         if not record_loss:
             return None
         self.slab.allreduce_sum_(hist)
-        h = hist.cpu().numpy()
-        return h[:, 3:6].sum(axis=1) + self.reg * h[:, 0:3].sum(axis=1)
+        return self.loss_from_slots(hist.cpu().numpy(), self.reg)
 
     def result(self):
         return self.x

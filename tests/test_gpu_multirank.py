@@ -54,6 +54,7 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
         out["cp2_loss"] = cp2.run(8)
         out["cp2_x"] = cp2.result().cpu().numpy()
         out["cp2_fused"] = cp2.fused
+        out["cp2_overlap"] = bool(getattr(cp2, "overlap_fused", False))
         if min(n for _, n in slab.parts) >= 2:
             sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, slab=slab, **kw)
             out["sg_loss"] = sg.run(5)
@@ -68,9 +69,11 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
-@pytest.mark.parametrize("world,shape,overlap", [(2, (8, 3, 6, 132), True), (3, (9, 2, 8, 16), True), (4, (8, 4, 5, 128), False)])
-def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap):
+@pytest.mark.parametrize("world,shape,overlap,zchunk", [(2, (8, 3, 6, 132), True, "1"), (3, (9, 2, 8, 16), True, "0"),
+                                                        (4, (8, 4, 5, 128), False, "0"), (2, (12, 2, 9, 68), True, "2")])
+def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, zchunk, monkeypatch):
     from oracle import tv_oracle as orc
+    monkeypatch.setenv("TV_ZCHUNK", zchunk)     # inherited by the spawned ranks; "1"/"2": >= 3 chunks per rank -> overlap
     kw = dict(reg_z_over_reg=1.3, reg_time=0.7)
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -87,6 +90,8 @@ def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap):
         np.testing.assert_allclose(ret[r]["cp2_x"], wx[z0:z0 + nz], rtol=1e-5, atol=2e-3, err_msg="rank %d (default path)" % r)
     if scheme != "central" and shape[-1] % 4 == 0 and shape[-1] >= 64:
         assert all(ret[r]["cp2_fused"] for r in range(world))
+        if overlap and zchunk in ("1", "2"):
+            assert all(ret[r]["cp2_overlap"] for r in range(world))     # interior-first one-sweep path exercised
     if overlap:
         assert any(ret[r]["cp_overlap"] for r in range(world))
     if "sg_loss" in ret[0]:
