@@ -28,7 +28,7 @@ struct MarchCoord {
     long long inpl;
 };
 
-__device__ __forceinline__ MarchCoord march_coord(const DG& g, int zchunk) {
+__device__ __forceinline__ MarchCoord march_coord(const DG& g, int zchunk, int z_first = 0, int z_end = -1) {
     MarchCoord c;
     c.lane = (int)threadIdx.x;
     c.ty = (int)threadIdx.y;
@@ -38,8 +38,9 @@ __device__ __forceinline__ MarchCoord march_coord(const DG& g, int zchunk) {
     c.col0 = (bx * 64 + c.lane) * 4;
     c.y = by * 4 + c.ty;
     c.ok = (c.col0 < g.nx) && (c.y < g.ny);
-    c.zs = (int)blockIdx.y * zchunk;
-    c.ze = (c.zs + zchunk < g.nz) ? c.zs + zchunk : g.nz;
+    if (z_end < 0) z_end = g.nz;
+    c.zs = z_first + (int)blockIdx.y * zchunk;          // z_first < 0 / z_end > nz: ghost planes of a slab
+    c.ze = (c.zs + zchunk < z_end) ? c.zs + zchunk : z_end;
     c.inpl = (long long)c.y * g.nx + c.col0;
     return c;
 }
@@ -70,12 +71,15 @@ __device__ __forceinline__ void col_neighbours(const V4& v, const float* p, bool
 // forward operator, marching.  Epi is one of the forward epilogues of tv_kernels.hip
 // (StoreD, CpDual, AdmmZU): called once per (z, t) with the gradient channels of the site.
 // =============================================================================================
+// hp: planes per halo buffer (1, or 2 for the radius-2 entry points); [z_first, z_end): local planes to
+// visit (ghost planes outside [0, nz) come from the halo buffers)
 template <int S, int M, typename Epi>
 __global__ __launch_bounds__(256) void k_D_march(DG g, WT<float> w, const float* __restrict__ x, const float* __restrict__ xp,
-                                                 const float* __restrict__ xn, int zchunk, Epi epi) {
+                                                 const float* __restrict__ xn, int zchunk, Epi epi, int hp = 1, int z_first = 0,
+                                                 int z_end = -1) {
     __shared__ V4 tile[2][M][4][64];   // double-buffered: one barrier per z step
     __shared__ double sm[16];
-    const MarchCoord c = march_coord(g, zchunk);
+    const MarchCoord c = march_coord(g, zchunk, z_first, z_end);
     constexpr bool NEXT = (S != DOWNWIND), PREV = (S != UPWIND);
     const V4 zero = vsplat<float, 4>(0.f);
     const V4 mf = g.ta ? mask_factor<float, 4>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<float, 4>(1.f);
@@ -83,8 +87,8 @@ __global__ __launch_bounds__(256) void k_D_march(DG g, WT<float> w, const float*
 
     V4 C[M], P[M];
     {   // prologue: planes zs (centre) and zs-1
-        const float* pc = zplane<float>(g, x, xp, xn, 1, c.zs);
-        const float* pp = (PREV && g.za) ? zplane<float>(g, x, xp, xn, 1, c.zs - 1) : nullptr;
+        const float* pc = zplane<float>(g, x, xp, xn, hp, c.zs);
+        const float* pp = (PREV && g.za) ? zplane<float>(g, x, xp, xn, hp, c.zs - 1) : nullptr;
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             C[t] = c.ok ? vload<float, 4>(pc + (long long)t * g.s_t + c.inpl) : zero;
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(256) void k_D_march(DG g, WT<float> w, const float*
 #pragma unroll
         for (int t = 0; t < M; ++t) tile[buf][t][c.ty][c.lane] = C[t];
         __syncthreads();
-        const float* pc = zplane<float>(g, x, xp, xn, 1, z);
-        const float* pn = zplane<float>(g, x, xp, xn, 1, z + 1);
+        const float* pc = zplane<float>(g, x, xp, xn, hp, z);
+        const float* pn = zplane<float>(g, x, xp, xn, hp, z + 1);
         const bool has_pz = PREV && g.za && (g.z0 + z > 0);
         const bool has_nz = NEXT && g.za && (pn != nullptr);
         // the next plane is needed as a z neighbour and/or as the next centre
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(256) void k_D_march(DG g, WT<float> w, const float*
                 d_slots<S, float, 4>(g, w, n, mf, o);
                 Coord cc;
                 cc.zl = z; cc.t = t; cc.y = c.y; cc.col0 = c.col0; cc.ok = true;
-                acc += epi(g, cc, o);
+                if constexpr (requires { epi(g, cc, o, n.c); }) acc += epi(g, cc, o, n.c);
+                else acc += epi(g, cc, o);
             }
             cold = C[t];
             P[t] = C[t];

@@ -237,6 +237,33 @@ def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, 
     assert nv.lib().tv_cp_fused_supported(g.ref) == 0
 
 
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_normal_operator_matches_oracle(pytv, scheme):
+    """tv_normal_op: x + rho D^T D x from x alone (marching hybrid-stencil kernel for the radius-1 schemes at
+    Nx >= 128 fp32, vectorised one-site kernels otherwise, radius-2 kernel for central incl. two-point axes)."""
+    import torch
+    from pytv import _native as nv
+    lib = nv.lib()
+    rng = np.random.default_rng(51)
+    shapes = [(1, 1, 9, 12), (5, 1, 8, 16), (2, 2, 7, 12), (4, 3, 6, 20), (6, 4, 5, 128), (3, 8, 6, 132), (2, 2, 9, 256), (7, 16, 4, 128)]
+    for shape in shapes:
+        for dtype in (np.float32, np.float64):
+            for lz, mu, use_mask in ((1.0, 1.0, False), (2.5, 0.6, True), (0.0, 0.0, False)):
+                mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
+                kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=3.0 if use_mask else 0)
+                xh = rng.standard_normal(shape).astype(dtype)
+                x = torch.as_tensor(xh).cuda()
+                g = nv.Geometry(shape, scheme, x.dtype, x.device, **kw)
+                out, dot = torch.empty_like(x), g.scalar()
+                nv.check(lib.tv_normal_op(g.ref, nv.ptr(x), None, None, 0.37, nv.ptr(out), nv.ptr(dot), nv.ptr(g.workspace()),
+                                          nv.current_stream(x.device)))
+                x64 = xh.astype(np.float64)
+                want = x64 + 0.37 * orc.D_T(orc.D(x64, scheme, **kw), scheme, **kw)
+                msg = "%s %s %s %s" % (scheme, shape, dtype.__name__, (lz, mu, use_mask))
+                np.testing.assert_allclose(out.cpu().numpy(), want, err_msg=msg, **(F64 if dtype == np.float64 else dict(rtol=2e-5, atol=2e-5)))
+                np.testing.assert_allclose(float(dot), np.sum(x64 * want), rtol=1e-5 if dtype == np.float32 else 1e-11, err_msg=msg)
+
+
 def test_central_two_planes_uses_forward_z(pytv):
     # SURVEY Q3: the reference raises for central with Nz == 2; the build (and the oracle) use the
     # forward z stencil, the evident intent of pytv/tv_operators_CPU.py:338-340.  Unpinned.

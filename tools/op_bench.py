@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Achieved bandwidth of every C-ABI operator (device resident, fp32) against its algorithmic bytes.
+usage: python tools/op_bench.py [NzxMxNyxNx] [scheme ...]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
+import torch, pytv
+from pytv import _native as nv
+shape = tuple(int(v) for v in sys.argv[1].split("x")) if len(sys.argv) > 1 else (64, 8, 1024, 1024)
+schemes = sys.argv[2:] or ["hybrid", "upwind", "downwind", "central"]
+lib = nv.lib()
+dev = torch.device("cuda", 0)
+gen = torch.Generator(device=dev).manual_seed(0)
+x = torch.rand(shape, device=dev, generator=gen) * 100
+V = x.numel()
+
+
+def timeit(f, reps=5):
+    f(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+print("shape %s  V = %.0f Mvox; GB/s = algorithmic bytes / time; frac of 8000 GB/s" % (shape, V / 1e6))
+print("%-9s %-14s %8s %9s %7s  %s" % ("scheme", "op", "ms", "GB/s", "frac", "algorithmic words/voxel"))
+for scheme in schemes:
+    kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
+    g = nv.Geometry(shape, scheme, x.dtype, dev, **kw)
+    nd, st, ws = g.nd, nv.current_stream(dev), g.workspace()
+    d = torch.empty(g.grad_shape, device=dev)
+    o = torch.empty_like(x); o2 = torch.empty_like(x)
+    ne = torch.empty((shape[0] + 2,) + shape[1:], device=dev)
+    sc = g.scalar()
+    u = torch.zeros(g.grad_shape, device=dev)
+    ops = [
+        ("tv_D", 1 + nd, lambda: nv.check(lib.tv_D(g.ref, nv.ptr(x), None, None, nv.ptr(d), st))),
+        ("tv_DT", nd + 1, lambda: nv.check(lib.tv_DT(g.ref, nv.ptr(d), None, None, nv.ptr(o), st))),
+        ("tv_l21", nd, lambda: nv.check(lib.tv_l21(g.ref, nv.ptr(d), nd, None, nv.ptr(sc), nv.ptr(ws), st))),
+        ("tv_subgrad", 2, lambda: nv.check(lib.tv_subgrad(g.ref, nv.ptr(x), None, None, nv.ptr(o), nv.ptr(ne), nv.ptr(sc), nv.ptr(ws), st))),
+        ("tv_normal_op", 2, lambda: nv.check(lib.tv_normal_op(g.ref, nv.ptr(x), None, None, 0.1, nv.ptr(o), nv.ptr(sc), nv.ptr(ws), st))),
+        ("tv_admm_zu", 1 + 3 * nd, lambda: nv.check(lib.tv_admm_zu(g.ref, nv.ptr(x), None, None, nv.ptr(d), nv.ptr(u), 1.0, nv.ptr(sc), nv.ptr(ws), st))),
+        ("tv_DT_axpy", 2 * nd + 2, lambda: nv.check(lib.tv_DT_axpy(g.ref, nv.ptr(d), nv.ptr(u), None, None, nv.ptr(x), 0.1, nv.ptr(o), st))),
+        ("tv_cp_dual", 1 + 2 * nd, lambda: nv.check(lib.tv_cp_dual(g.ref, nv.ptr(x), None, None, nv.ptr(d), 0.5, 25.0, nv.ptr(sc), nv.ptr(ws), st))),
+        ("tv_cp_primal", nd + 5, lambda: nv.check(lib.tv_cp_primal(g.ref, nv.ptr(d), None, None, nv.ptr(o), nv.ptr(x), nv.ptr(o2), 0.05, 1.0, nv.ptr(sc), nv.ptr(ws), st))),
+    ]
+    for name, words, f in ops:
+        t = timeit(f)
+        gbs = words * 4.0 * V / t / 1e9
+        print("%-9s %-14s %8.3f %9.0f %7.3f  %d" % (scheme, name, t * 1e3, gbs, gbs / 8000.0, words))
+    del d, u, o, o2, ne
+    torch.cuda.empty_cache()
