@@ -430,6 +430,97 @@ __global__ __launch_bounds__(256) void k_normal_central_vec(DG g, WT<T> w, const
     if (threadIdx.x == 0 && threadIdx.y == 0) partials[linear_block_id()] = acc;
 }
 
+// central scheme sub-gradient, vectorised:  G(p) = 1/2 sum_a [ g_a(p-e) - g_a(p+e) ],  g_a(q) = d_a(q) / |D x|(q),
+// d_a(q) = 1/2 w_a (x(q+e) - x(q-e)) at interior q (mask factor on the time channel); two-point z / t axes use
+// the forward stencil: G += g_a(p-e) - g_a(p), d_a(q) = 1/2 w_a (x(q+e) - x(q)).   (pytv/tv_CPU.py:302-330)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, const T* x, const T* xp, const T* xn, const T* norms_ext,
+                                                            T* G) {
+    const Coord c = thread_coord<V>(g, 0);
+    if (!c.ok) return;
+    const Vec<T, V> zero = vsplat<T, V>(T(0));
+    const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+    const T* pc = zplane<T>(g, x, xp, xn, 2, c.zl) + inpl;
+    const T* nc = norms_ext + (long long)(c.zl + 1) * g.s_z + inpl;
+    const Vec<T, V> xc = vload<T, V>(pc);
+    const Vec<T, V> mf = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
+    const T h = T(0.5);
+    Vec<T, V> r = zero;
+    // term of one axis from the vectors two steps away (x) and one step away (norms); wa < 0: unweighted
+    auto cen = [&](int pos, int n, const Vec<T, V>& xm2, const Vec<T, V>& xp2, const Vec<T, V>& nm1, const Vec<T, V>& np1, T wa,
+                   bool weighted, bool timeax) {
+        if (pos - 1 > 0 && pos - 1 < n - 1) {
+            Vec<T, V> d = xc - xm2;
+            if (weighted) d = wa * d;
+            if (timeax) d = d * mf;
+            d = h * d;
+#pragma unroll
+            for (int i = 0; i < V; ++i) r.v[i] += d.v[i] / nm1.v[i];
+        }
+        if (pos + 1 > 0 && pos + 1 < n - 1) {
+            Vec<T, V> d = xp2 - xc;
+            if (weighted) d = wa * d;
+            if (timeax) d = d * mf;
+            d = h * d;
+#pragma unroll
+            for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] / np1.v[i];
+        }
+    };
+    auto fwd = [&](int pos, int n, const Vec<T, V>& xm1, const Vec<T, V>& xp1, const Vec<T, V>& nm1, const Vec<T, V>& n0, T wa,
+                   bool timeax) {
+        if (pos >= 1) {             // g(p-e), d(p-e) = 1/2 w (x(p) - x(p-e))
+            Vec<T, V> d = wa * (xc - xm1);
+            if (timeax) d = d * mf;
+            d = h * d;
+#pragma unroll
+            for (int i = 0; i < V; ++i) r.v[i] += d.v[i] / nm1.v[i];
+        }
+        if (pos <= n - 2) {         // - g(p), d(p) = 1/2 w (x(p+e) - x(p))
+            Vec<T, V> d = wa * (xp1 - xc);
+            if (timeax) d = d * mf;
+            d = h * d;
+#pragma unroll
+            for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] / n0.v[i];
+        }
+    };
+    const long long nx = g.nx;
+    cen(c.y, g.ny, (c.y >= 2) ? vload<T, V>(pc - 2 * nx) : zero, (c.y + 2 < g.ny) ? vload<T, V>(pc + 2 * nx) : zero,
+        (c.y >= 1) ? vload<T, V>(nc - nx) : zero, (c.y + 1 < g.ny) ? vload<T, V>(nc + nx) : zero, T(1), false, false);
+    {   // columns, per element
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int col = c.col0 + i;
+            if (col - 1 > 0 && col - 1 < g.nx - 1) r.v[i] += (h * (xc.v[i] - pc[i - 2])) / nc[i - 1];
+            if (col + 1 > 0 && col + 1 < g.nx - 1) r.v[i] -= (h * (pc[i + 2] - xc.v[i])) / nc[i + 1];
+        }
+    }
+    if (g.za) {
+        const int gz = g.z0 + c.zl;
+        const T* nm1 = (gz >= 1) ? nc - g.s_z : nullptr;
+        const T* np1 = (gz + 1 < g.nzg) ? nc + g.s_z : nullptr;
+        if (g.z_two) {
+            const T* pm = zplane<T>(g, x, xp, xn, 2, c.zl - 1);
+            const T* pq = zplane<T>(g, x, xp, xn, 2, c.zl + 1);
+            fwd(gz, g.nzg, pm ? vload<T, V>(pm + inpl) : zero, pq ? vload<T, V>(pq + inpl) : zero, nm1 ? vload<T, V>(nm1) : zero,
+                vload<T, V>(nc), w.wz, false);
+        } else {
+            const T* pm = zplane<T>(g, x, xp, xn, 2, c.zl - 2);
+            const T* pq = zplane<T>(g, x, xp, xn, 2, c.zl + 2);
+            cen(gz, g.nzg, pm ? vload<T, V>(pm + inpl) : zero, pq ? vload<T, V>(pq + inpl) : zero, nm1 ? vload<T, V>(nm1) : zero,
+                np1 ? vload<T, V>(np1) : zero, w.wz, true, false);
+        }
+    }
+    if (g.ta) {
+        if (g.t_two)
+            fwd(c.t, g.m, (c.t >= 1) ? vload<T, V>(pc - g.s_t) : zero, (c.t + 1 < g.m) ? vload<T, V>(pc + g.s_t) : zero,
+                (c.t >= 1) ? vload<T, V>(nc - g.s_t) : zero, vload<T, V>(nc), w.wt, true);
+        else
+            cen(c.t, g.m, (c.t >= 2) ? vload<T, V>(pc - 2 * g.s_t) : zero, (c.t + 2 < g.m) ? vload<T, V>(pc + 2 * g.s_t) : zero,
+                (c.t >= 1) ? vload<T, V>(nc - g.s_t) : zero, (c.t + 1 < g.m) ? vload<T, V>(nc + g.s_t) : zero, w.wt, true, true);
+    }
+    vstore<T, V>(G + (long long)c.zl * g.s_z + inpl, h * r);
+}
+
 // =============================================================================================
 // l2,1 norm of a materialised gradient (pytv/tv_operators_GPU.py:75-81 as ONE pass)
 // =============================================================================================
@@ -660,10 +751,22 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
                 hipLaunchKernelGGL((k_subgrad_vec<S, T, 1>), lg.grid, lg.block, 0, st, d, w, (const T*)x, (const T*)x_prev,
                                    (const T*)x_next, (const T*)norms_ext, (T*)G);
             }
-        } else {
+        } else if (env_int("TV_SCALAR_GATHER", 0)) {
+            // reference-style scalar evaluation of the radius-2 stencil (kept as an in-library cross-check)
             LC lg = launch_cfg(d, 1, d.nz);
             XA<T> X{d, (const T*)x, (const T*)x_prev, (const T*)x_next, 2};
             hipLaunchKernelGGL((k_gather<S, T, 0>), lg.grid, lg.block, 0, st, X, w, (const T*)norms_ext, T(0), (T*)G, (double*)nullptr);
+        } else {
+            const bool v2 = vec && aligned16({G});
+            if (v2 && V == 4) {
+                LC lg = launch_cfg(d, V, d.nz);
+                hipLaunchKernelGGL((k_subgrad_central_vec<T, V>), lg.grid, lg.block, 0, st, d, w, (const T*)x, (const T*)x_prev,
+                                   (const T*)x_next, (const T*)norms_ext, (T*)G);
+            } else {
+                LC lg = launch_cfg(d, 1, d.nz);
+                hipLaunchKernelGGL((k_subgrad_central_vec<T, 1>), lg.grid, lg.block, 0, st, d, w, (const T*)x, (const T*)x_prev,
+                                   (const T*)x_next, (const T*)norms_ext, (T*)G);
+            }
         }
         HIP_TRY(hipGetLastError());
         return 0;
@@ -687,6 +790,13 @@ int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void
         if constexpr (S != CENTRAL) {
             hipLaunchKernelGGL((k_normal_vec<S, T, V>), lg.grid, lg.block, 0, st, d, make_w<T>(g), (const T*)x, (const T*)x_prev,
                                (const T*)x_next, (T)rho, (T*)out, (double*)ws);
+        } else if (env_int("TV_SCALAR_GATHER", 0)) {
+            LC l1 = launch_cfg(d, 1, d.nz);
+            XA<T> X{d, (const T*)x, (const T*)x_prev, (const T*)x_next, 2};
+            hipLaunchKernelGGL((k_gather<S, T, 1>), l1.grid, l1.block, 0, st, X, make_w<T>(g), (const T*)nullptr, (T)rho, (T*)out,
+                               (double*)ws);
+            HIP_TRY(hipGetLastError());
+            return reduce_partials((double*)ws, l1.nblocks, nmax, dot, st);
         } else {
             hipLaunchKernelGGL((k_normal_central_vec<T, V>), lg.grid, lg.block, 0, st, d, make_w<T>(g), (const T*)x, (const T*)x_prev,
                                (const T*)x_next, (T)rho, (T*)out, (double*)ws);
