@@ -84,9 +84,9 @@ int tv_l21(const tv_geom* g, const void* d, int32_t nd, void* norms, double* res
 /* ---- direct TV API: replaces pytv.tv_GPU.tv_* ------------------------------------------------ */
 /* *tv (device fp64) = TV of the local planes; G = the reference's sub-gradient
  * (pytv/tv_GPU.py:47-375).  norms_ext: REQUIRED scratch/output of (nz + 2) planes; on return
- * plane k+1 holds |D x| of local plane k with zeros replaced by +inf (pytv/tv_GPU.py:88), i.e.
- * the reference's grad_norms is norms_ext + one plane.  x_prev / x_next: TWO planes each
- * (z0-2, z0-1) / (z0+nz, z0+nz+1) when sharded, else NULL. */
+ * plane k+1 holds 1 / |D x| of local plane k, 0 where |D x| == 0 -- the reciprocal of the
+ * reference's grad_norms (which has those zeros replaced by +inf, pytv/tv_GPU.py:88).
+ * x_prev / x_next: TWO planes each (z0-2, z0-1) / (z0+nz, z0+nz+1) when sharded, else NULL. */
 int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* x_next,
                void* G, void* norms_ext, double* tv, void* ws, void* stream);
 

@@ -446,4 +446,98 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
     if (threadIdx.x == 0 && threadIdx.y == 0) partials[linear_block_id()] = acc;
 }
 
+
+// =============================================================================================
+// sub-gradient pass 2, marching (radius-1 schemes, fp32): G from x and 1/|Dx| (norms_ext, one ghost plane in
+// front), both fields fetched once: x planes z-1, z in registers, |Dx| planes z-1, z in per-thread LDS slots,
+// row / column neighbours of both by lane shuffles inside the 4-row x 64-col wave tile (halo rows / edge
+// columns: predicated loads).  No fix-up needed: this is a pure gather.
+// =============================================================================================
+template <int S, int M>
+__global__ __launch_bounds__(256, 2) void k_subgrad_march(DG g, WT<float> w, const float* __restrict__ x, const float* __restrict__ xp,
+                                                          const float* __restrict__ xn, const float* __restrict__ norms_ext,
+                                                          float* __restrict__ G, int zchunk) {
+    static_assert(S != CENTRAL, "radius-2 scheme");
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    const FusedCoord c = fused_coord(g, zchunk, 0);
+    const F4 zero = vsplat<float, 4>(0.f), one = vsplat<float, 4>(1.f);
+    const F4 mf = g.ta ? mask_factor<float, 4>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : one;
+    __shared__ F4 lds_WC[M][256];
+    __shared__ F4 lds_WP[M][256];
+    const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
+    auto nplane = [&](int zl) -> const float* {          // |Dx| plane of LOCAL index zl (ghosts at -1 and nz), or nullptr
+        const int gz = g.z0 + zl;
+        return (gz >= 0 && gz < g.nzg) ? norms_ext + (long long)(zl + 1) * g.s_z : nullptr;
+    };
+    F4 XC[M], XP[M];
+    {
+        const float* pc = zplane<float>(g, x, xp, xn, 2, c.zs);
+        const float* pp = g.za ? zplane<float>(g, x, xp, xn, 2, c.zs - 1) : nullptr;
+        const float* qc = nplane(c.zs);
+        const float* qp = g.za ? nplane(c.zs - 1) : nullptr;
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const long long off = (long long)t * g.s_t + c.inpl;
+            XC[t] = c.ok ? vload<float, 4>(pc + off) : zero;
+            XP[t] = (c.ok && pp) ? vload<float, 4>(pp + off) : zero;
+            lds_WC[t][tid] = c.ok ? vload<float, 4>(qc + off) : one;
+            lds_WP[t][tid] = (c.ok && qp && UP) ? vload<float, 4>(qp + off) : one;
+        }
+    }
+    // neighbourhood of a field whose plane-z value of this frame is `cv`
+    auto neighbourhood = [&](XN<float, 4>& n, const F4& cv, const float* plane_c, long long off, const F4& nzv, const F4& pzv,
+                             const F4& ntv, const F4& ptv, bool h_nz, bool h_pz, bool h_nt, bool h_pt) {
+        n.c = cv;
+        n.col0 = c.col0;
+        const bool want_up = (c.row == 0) && c.ok && (c.y > 0);
+        const bool want_dn = (c.row == 3) && c.ok && (c.y + 1 < g.ny);
+        F4 halo = zero;
+        if (want_up || want_dn) halo = vload<float, 4>(plane_c + off + (want_up ? -(long long)g.nx : (long long)g.nx));
+        n.h_nr = c.ok && (c.y + 1 < g.ny);
+        n.h_pr = c.ok && (c.y > 0);
+        const F4 sdn = shfl_down16(cv), sup = shfl_up16(cv);
+        n.nr = (c.row == 3) ? halo : sdn;
+        n.pr = (c.row == 0) ? halo : sup;
+        const bool le = (c.lx == 0) && c.ok && (c.col0 > 0), re = (c.lx == 15) && c.ok && (c.col0 + 4 < g.nx);
+        float edge = 0.f;
+        if (le || re) edge = le ? plane_c[off - 1] : plane_c[off + 4];
+        const float shr = __shfl_down(cv.v[0], 1, 64), shl = __shfl_up(cv.v[3], 1, 64);
+        n.nc = shift_left<float, 4>(cv, (c.lx == 15) ? edge : shr);
+        n.pc = shift_right<float, 4>(cv, (c.lx == 0) ? edge : shl);
+        n.nz = nzv; n.pz = pzv; n.nt = ntv; n.pt = ptv;
+        n.h_nz = h_nz; n.h_pz = h_pz; n.h_nt = h_nt; n.h_pt = h_pt;
+    };
+    for (int z = c.zs; z < c.ze; ++z) {
+        const int gz = g.z0 + z;
+        const float* pc = zplane<float>(g, x, xp, xn, 2, z);
+        const float* pn = zplane<float>(g, x, xp, xn, 2, z + 1);
+        const float* qc = nplane(z);
+        const float* qn = nplane(z + 1);
+        const bool has_pz = g.za && (gz > 0), has_nz = g.za && (pn != nullptr);
+        const bool more = (z + 1 < c.ze);
+        F4 xcold = zero, wcold = one;
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const long long off = (long long)t * g.s_t + c.inpl;
+            const F4 XNv = (pn != nullptr && c.ok && (has_nz || more)) ? vload<float, 4>(pn + off) : zero;
+            const F4 WNv = (qn != nullptr && c.ok && ((has_nz && DN) || more)) ? vload<float, 4>(qn + off) : one;
+            const F4 wc = lds_WC[t][tid], wp = lds_WP[t][tid];
+            const bool h_nt = g.ta && (t + 1 < M), h_pt = g.ta && (t > 0);
+            XN<float, 4> xs, ns;
+            neighbourhood(xs, XC[t], pc, off, XNv, XP[t], XC[(t + 1 < M) ? t + 1 : t], xcold, has_nz, has_pz, h_nt, h_pt);
+            neighbourhood(ns, wc, qc, off, WNv, wp, lds_WC[(t + 1 < M) ? t + 1 : t][tid], wcold, has_nz, has_pz, h_nt, h_pt);
+            if (c.ok) {
+                const F4 r = subgrad_site<S, float, 4>(g, w, xs, ns, mf);
+                vstore<float, 4>(G + (long long)z * g.s_z + off, r);
+            }
+            xcold = XC[t];
+            wcold = wc;
+            XP[t] = XC[t];
+            XC[t] = XNv;
+            lds_WP[t][tid] = wc;
+            lds_WC[t][tid] = WNv;
+        }
+    }
+}
+
 }  // namespace tv

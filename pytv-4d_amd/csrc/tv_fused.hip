@@ -21,6 +21,21 @@ template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
     return fail(TV_E_ARG, "unsupported (scheme, M) for the one-sweep path");
 }
 
+namespace tvm {
+bool subgrad_pass2_ok(const tv_geom* g, const DG& d) { return g->scheme != TV_CENTRAL && fused_m_ok(d.m); }
+int subgrad_pass2(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st,
+                  const float* norms_ext, float* G) {
+    const int zc = march_zchunk(d);
+    const LC lc = march_cfg(d, zc);
+    return dispatch_fused(g->scheme, d.m, [&]<int S, int M>() -> int {
+        hipLaunchKernelGGL((k_subgrad_march<S, M>), lc.grid, lc.block, 0, st, d, make_w<float>(g), (const float*)x, (const float*)xp,
+                           (const float*)xn, norms_ext, G, zc);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    });
+}
+}  // namespace tvm
+
 extern "C" {
 
 int tv_cp_fused_supported(const tv_geom* g) {

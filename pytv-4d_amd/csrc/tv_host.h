@@ -197,6 +197,13 @@ namespace tvm {
 int D_store(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb, float* dout);
 int D_cp_dual(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
               float* q, float sigma, float inv_lambda, double* partials);
+// sub-gradient passes on the marching path: pass 1 = |Dx| (0 -> +inf) on the local planes plus ghost planes,
+// pass 2 = G from x and |Dx| (radius-1 schemes only); x halo buffers hold TWO planes each
+int D_norms(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
+            float* norms_ext, double* partials, int ghost_lo, int ghost_hi);
+int subgrad_pass2(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st,
+                  const float* norms_ext, float* G);
+bool subgrad_pass2_ok(const tv_geom* g, const DG& d);
 int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
               float* z, float* u, float thresh, double* partials);
 int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb, float* out);

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_gather(XA<T> X, WT<T> w, const T* norms
             const T d = dval<S, T>(X, w, axis, type, qz, qt, qy, qc);
             if (MODE == 0) {
                 const T n = norms_ext[(long long)(qz + 1) * g.s_z + (long long)qt * g.s_t + (long long)qy * g.nx + qc];
-                return d / n;           // n == +inf where |Dx| == 0  ->  exactly 0
+                return d * n;           // n = 1/|Dx| from pass 1 (0 where |Dx| == 0)
             }
             return d;
         };
@@ -252,22 +252,10 @@ __global__ __launch_bounds__(256) void k_gather(XA<T> X, WT<T> w, const T* norms
 //   D^T D x   = sum_a w_a^2 (b_a - f_a)           (identical for the three schemes)
 // where d_f = ((w f) mf) s, d_b = ((w b) mf) s reproduce the arithmetic of D exactly.
 // =============================================================================================
-template <typename T, int V>
-__device__ __forceinline__ Vec<T, V> div_where(const Vec<T, V>& d, const Vec<T, V>& n, bool valid) {
-    Vec<T, V> r = vsplat<T, V>(T(0));
-    if (valid) {
-#pragma unroll
-        for (int i = 0; i < V; ++i) r.v[i] = d.v[i] / n.v[i];       // n == +inf where |Dx| == 0 -> 0
-    }
-    return r;
-}
-
 template <int S, typename T, int V>
 __global__ __launch_bounds__(256) void k_subgrad_vec(DG g, WT<T> w, const T* x, const T* xp, const T* xn, const T* norms_ext, T* G) {
-    static_assert(S != CENTRAL, "radius-2 scheme: use k_gather");
     const Coord c = thread_coord<V>(g, 0);
     if (!c.ok) return;
-    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
     const T* pc = zplane<T>(g, x, xp, xn, 2, c.zl);
     const T* pp = g.za ? zplane<T>(g, x, xp, xn, 2, c.zl - 1) : nullptr;
     const T* pn = g.za ? zplane<T>(g, x, xp, xn, 2, c.zl + 1) : nullptr;
@@ -275,37 +263,8 @@ __global__ __launch_bounds__(256) void k_subgrad_vec(DG g, WT<T> w, const T* x, 
     load_xn<T, V, true, true>(g, pc, pp, pn, c, xs);
     const T* nc = norms_ext + (long long)(c.zl + 1) * g.s_z;
     load_xn<T, V, true, true>(g, nc, pp ? nc - g.s_z : nullptr, pn ? nc + g.s_z : nullptr, c, ns);
-    const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : T(1);
     const Vec<T, V> mf = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
-    const Vec<T, V> zero = vsplat<T, V>(T(0));
-    Vec<T, V> r = zero;
-    auto axis = [&](const Vec<T, V>& nxt, const Vec<T, V>& prv, bool hn, bool hp, const Vec<T, V>& n_nxt, const Vec<T, V>& n_prv,
-                    T wa, bool weighted, bool timeax) {
-        Vec<T, V> f = hn ? nxt - xs.c : zero, b = hp ? xs.c - prv : zero;
-        if (weighted) { f = wa * f; b = wa * b; }
-        if (timeax) { f = f * mf; b = b * mf; }
-        if (S == HYBRID) { f = s * f; b = s * b; }
-        if (UP) r = r + (div_where<T, V>(b, n_prv, hp) - div_where<T, V>(f, ns.c, hn));
-        if (DN) r = r + (div_where<T, V>(b, ns.c, hp) - div_where<T, V>(f, n_nxt, hn));
-    };
-    axis(xs.nr, xs.pr, xs.h_nr, xs.h_pr, ns.nr, ns.pr, T(1), false, false);
-    {   // columns: validity per element
-        Vec<T, V> f, b, t1 = zero, t2 = zero;
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const int col = c.col0 + i;
-            const bool hn = col < g.nx - 1, hp = col > 0;
-            T fi = hn ? xs.nc.v[i] - xs.c.v[i] : T(0), bi = hp ? xs.c.v[i] - xs.pc.v[i] : T(0);
-            if (S == HYBRID) { fi *= s; bi *= s; }
-            T acc = T(0);
-            if (UP) acc += (hp ? bi / ns.pc.v[i] : T(0)) - (hn ? fi / ns.c.v[i] : T(0));
-            if (DN) acc += (hp ? bi / ns.c.v[i] : T(0)) - (hn ? fi / ns.nc.v[i] : T(0));
-            r.v[i] += acc;
-        }
-    }
-    if (g.za) axis(xs.nz, xs.pz, xs.h_nz, xs.h_pz, ns.nz, ns.pz, w.wz, true, false);
-    if (g.ta) axis(xs.nt, xs.pt, xs.h_nt, xs.h_pt, ns.nt, ns.pt, w.wt, true, true);
-    if (S == HYBRID) r = s * r;
+    const Vec<T, V> r = subgrad_site<S, T, V>(g, w, xs, ns, mf);
     vstore<T, V>(G + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, r);
 }
 
@@ -431,7 +390,7 @@ __global__ __launch_bounds__(256) void k_normal_central_vec(DG g, WT<T> w, const
 }
 
 // central scheme sub-gradient, vectorised:  G(p) = 1/2 sum_a [ g_a(p-e) - g_a(p+e) ],  g_a(q) = d_a(q) / |D x|(q),
-// d_a(q) = 1/2 w_a (x(q+e) - x(q-e)) at interior q (mask factor on the time channel); two-point z / t axes use
+// (norms_ext holds 1/|Dx|)  d_a(q) = 1/2 w_a (x(q+e) - x(q-e)) at interior q (mask factor on the time channel); two-point z / t axes use
 // the forward stencil: G += g_a(p-e) - g_a(p), d_a(q) = 1/2 w_a (x(q+e) - x(q)).   (pytv/tv_CPU.py:302-330)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, const T* x, const T* xp, const T* xn, const T* norms_ext,
@@ -455,7 +414,7 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
             if (timeax) d = d * mf;
             d = h * d;
 #pragma unroll
-            for (int i = 0; i < V; ++i) r.v[i] += d.v[i] / nm1.v[i];
+            for (int i = 0; i < V; ++i) r.v[i] += d.v[i] * nm1.v[i];
         }
         if (pos + 1 > 0 && pos + 1 < n - 1) {
             Vec<T, V> d = xp2 - xc;
@@ -463,7 +422,7 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
             if (timeax) d = d * mf;
             d = h * d;
 #pragma unroll
-            for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] / np1.v[i];
+            for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] * np1.v[i];
         }
     };
     auto fwd = [&](int pos, int n, const Vec<T, V>& xm1, const Vec<T, V>& xp1, const Vec<T, V>& nm1, const Vec<T, V>& n0, T wa,
@@ -473,14 +432,14 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
             if (timeax) d = d * mf;
             d = h * d;
 #pragma unroll
-            for (int i = 0; i < V; ++i) r.v[i] += d.v[i] / nm1.v[i];
+            for (int i = 0; i < V; ++i) r.v[i] += d.v[i] * nm1.v[i];
         }
         if (pos <= n - 2) {         // - g(p), d(p) = 1/2 w (x(p+e) - x(p))
             Vec<T, V> d = wa * (xp1 - xc);
             if (timeax) d = d * mf;
             d = h * d;
 #pragma unroll
-            for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] / n0.v[i];
+            for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] * n0.v[i];
         }
     };
     const long long nx = g.nx;
@@ -490,8 +449,8 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const int col = c.col0 + i;
-            if (col - 1 > 0 && col - 1 < g.nx - 1) r.v[i] += (h * (xc.v[i] - pc[i - 2])) / nc[i - 1];
-            if (col + 1 > 0 && col + 1 < g.nx - 1) r.v[i] -= (h * (pc[i + 2] - xc.v[i])) / nc[i + 1];
+            if (col - 1 > 0 && col - 1 < g.nx - 1) r.v[i] += (h * (xc.v[i] - pc[i - 2])) * nc[i - 1];
+            if (col + 1 > 0 && col + 1 < g.nx - 1) r.v[i] -= (h * (pc[i + 2] - xc.v[i])) * nc[i + 1];
         }
     }
     if (g.za) {
@@ -729,6 +688,21 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
     const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, norms_ext});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
+    if (march_ok(g, d, vec && aligned16({G})) && !env_int("TV_NO_MARCH_SUBGRAD", 0)) {
+        // plane-marching passes: every field is fetched once (tv_march.h / tv_fused.h)
+        const int glo = d.za ? e_lo : 0, ghi = d.za ? e_hi : 0;
+        long long nb;
+        if (int rc = tvm::D_norms(g, d, x, x_prev, x_next, st, &nb, (float*)norms_ext, (double*)ws, glo, ghi)) return rc;
+        if (int rc = reduce_partials((double*)ws, nb, nmax, tvout, st)) return rc;
+        if (tvm::subgrad_pass2_ok(g, d))
+            return tvm::subgrad_pass2(g, d, x, x_prev, x_next, st, (const float*)norms_ext, (float*)G);
+        // central: radius-2 gather, one site per thread
+        LC lg = launch_cfg(d, 4, d.nz);
+        hipLaunchKernelGGL((k_subgrad_central_vec<float, 4>), lg.grid, lg.block, 0, st, d, make_w<float>(g), (const float*)x,
+                           (const float*)x_prev, (const float*)x_next, (const float*)norms_ext, (float*)G);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         WT<T> w = make_w<T>(g);
         // pass 1: norms on the local planes plus one ghost plane per interior side

@@ -30,4 +30,20 @@ int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, cons
               float* z, float* u, float thresh, double* partials) {
     return launch_D_march<AdmmZU>(g, d, x, xp, xn, st, nb, z, u, thresh, partials);
 }
+int D_norms(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
+            float* norms_ext, double* partials, int ghost_lo, int ghost_hi) {
+    const int zc = march_zchunk(d);
+    LC lc = march_cfg(d, zc);
+    const int planes = d.nz + ghost_lo + ghost_hi;
+    lc.grid.y = (unsigned)((planes + zc - 1) / zc);
+    lc.nblocks = (long long)lc.grid.x * lc.grid.y;
+    *nb = lc.nblocks;
+    return dispatch_sm(g->scheme, d.m, [&]<int S, int M>() -> int {
+        NormEpi<S, float, 4> epi{norms_ext, partials};
+        hipLaunchKernelGGL((k_D_march<S, M, NormEpi<S, float, 4>>), lc.grid, lc.block, 0, st, d, make_w<float>(g), (const float*)x,
+                           (const float*)xp, (const float*)xn, zc, epi, 2, -ghost_lo, d.nz + ghost_hi);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    });
+}
 }  // namespace tvm

@@ -155,7 +155,12 @@ template <int S, typename T, int V> struct StoreD {
     }
 };
 
-// |Dx| per voxel (0 -> +inf, pytv/tv_GPU.py:88) into an array with one extra plane in front
+// 1/|Dx| per voxel into an array with one extra plane in front; 0 where |Dx| == 0 (the reference sets
+// |Dx| := +inf there so that the site contributes nothing, pytv/tv_GPU.py:88 -- same effect), and also where
+// |Dx| is so small that its reciprocal would overflow.  Storing the reciprocal makes pass 2 division-free.
+template <typename T> __device__ __forceinline__ T tiny_norm();
+template <> __device__ __forceinline__ float tiny_norm<float>() { return 1e-30f; }
+template <> __device__ __forceinline__ double tiny_norm<double>() { return 1e-300; }
 template <int S, typename T, int V> struct NormEpi {
     static constexpr bool REDUCES = true;
     T* norms_ext;
@@ -168,7 +173,7 @@ template <int S, typename T, int V> struct NormEpi {
         for (int i = 0; i < V; ++i) {
             const T r = tsqrt(s.v[i]);
             acc += (double)r;
-            n.v[i] = (r == T(0)) ? (T)INFINITY : r;
+            n.v[i] = (r > tiny_norm<T>()) ? T(1) / r : T(0);
         }
         vstore<T, V>(norms_ext + (long long)(c.zl + 1) * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, n);
         return (c.zl >= 0 && c.zl < g.nz) ? acc : 0.0;
@@ -240,6 +245,55 @@ template <int S, typename T, int V> struct AdmmZU {
         return acc;
     }
 };
+
+// =============================================================================================
+// sub-gradient of one site (radius-1 schemes):  with f = forward, b = backward difference at the site,
+//   D up-channel at p-e equals (w b)(p), D down-channel at p+e equals (w f)(p), so
+//   G(p) = s * sum_a [ up: d_b/n(p-e) - d_f/n(p) ] + [ down: d_b/n(p) - d_f/n(p+e) ],  d = ((w diff) mf) s as in D;
+//   1/n comes precomputed from pass 1 (NormEpi), so this is multiplications only
+// =============================================================================================
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> div_where(const Vec<T, V>& d, const Vec<T, V>& inv_n, bool valid) {
+    Vec<T, V> r = vsplat<T, V>(T(0));
+    if (valid) r = d * inv_n;                                         // inv_n == 0 where |Dx| == 0
+    return r;
+}
+
+// sub-gradient of one site-vector from the radius-1 neighbourhoods of x (xs) and of 1/|Dx| (ns)
+template <int S, typename T, int V>
+__device__ __forceinline__ Vec<T, V> subgrad_site(const DG& g, const WT<T>& w, const XN<T, V>& xs, const XN<T, V>& ns,
+                                                  const Vec<T, V>& mf) {
+    static_assert(S != CENTRAL, "radius-2 scheme");
+    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : T(1);
+    const Vec<T, V> zero = vsplat<T, V>(T(0));
+    Vec<T, V> r = zero;
+    auto axis = [&](const Vec<T, V>& nxt, const Vec<T, V>& prv, bool hn, bool hp, const Vec<T, V>& n_nxt, const Vec<T, V>& n_prv,
+                    T wa, bool weighted, bool timeax) {
+        Vec<T, V> f = hn ? nxt - xs.c : zero, b = hp ? xs.c - prv : zero;
+        if (weighted) { f = wa * f; b = wa * b; }
+        if (timeax) { f = f * mf; b = b * mf; }
+        if (S == HYBRID) { f = s * f; b = s * b; }
+        if (UP) r = r + (div_where<T, V>(b, n_prv, hp) - div_where<T, V>(f, ns.c, hn));
+        if (DN) r = r + (div_where<T, V>(b, ns.c, hp) - div_where<T, V>(f, n_nxt, hn));
+    };
+    axis(xs.nr, xs.pr, xs.h_nr, xs.h_pr, ns.nr, ns.pr, T(1), false, false);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {      // columns: validity per element
+        const int col = xs.col0 + i;
+        const bool hn = col < g.nx - 1, hp = col > 0;
+        T fi = hn ? xs.nc.v[i] - xs.c.v[i] : T(0), bi = hp ? xs.c.v[i] - xs.pc.v[i] : T(0);
+        if (S == HYBRID) { fi *= s; bi *= s; }
+        T acc = T(0);
+        if (UP) acc += (hp ? bi * ns.pc.v[i] : T(0)) - (hn ? fi * ns.c.v[i] : T(0));
+        if (DN) acc += (hp ? bi * ns.c.v[i] : T(0)) - (hn ? fi * ns.nc.v[i] : T(0));
+        r.v[i] += acc;
+    }
+    if (g.za) axis(xs.nz, xs.pz, xs.h_nz, xs.h_pz, ns.nz, ns.pz, w.wz, true, false);
+    if (g.ta) axis(xs.nt, xs.pt, xs.h_nt, xs.h_pt, ns.nt, ns.pt, w.wt, true, true);
+    if (S == HYBRID) r = s * r;
+    return r;
+}
 
 // =============================================================================================
 // transposed operator: sources and epilogues

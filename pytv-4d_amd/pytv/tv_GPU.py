@@ -26,7 +26,8 @@ def _has_mask(mask):
 
 def tv_subgradient_device(x, scheme, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0):
     """Device-resident core: x is a contiguous fp32/fp64 device tensor (Nz, M, Ny, Nx).
-    Returns (tv 0-d fp64 device tensor, G, grad_norms view) without any host synchronisation."""
+    Returns (tv 0-d fp64 device tensor, G, inverse-norm view 1/|Dx| with 0 where |Dx| == 0) without any
+    host synchronisation."""
     geo = _nv.Geometry(tuple(x.shape), scheme, x.dtype, x.device, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
     nz, m, ny, nx = geo.shape
     G = torch.empty_like(x)
@@ -44,10 +45,11 @@ def _tv(scheme, img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_sta
     x, _ = _to_device(img)
     if x.dim() != 4:
         raise ValueError("img must be 4-D (Nz, M, N, N), got shape %s" % (tuple(x.shape),))
-    tv, G, gn = tv_subgradient_device(x, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
+    tv, G, inv_n = tv_subgradient_device(x, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
     tv = tv.detach().cpu().numpy()          # 0-d numpy, always (tv_GPU.py:85 via compute_L21_norm)
     if not return_grad_norms:
         return (tv, G) if return_pytorch_tensor else (tv, G.detach().cpu().numpy())
+    gn = torch.reciprocal(inv_n)            # the reference's grad_norms: |Dx| with zeros replaced by +inf (tv_GPU.py:88)
     if return_pytorch_tensor:
         return tv, G, gn
     return tv, G.detach().cpu().numpy(), gn.detach().cpu().numpy()
