@@ -20,5 +20,7 @@ from . import tv_operators_GPU   # noqa: E402
 from . import tv_GPU             # noqa: E402
 from . import solvers            # noqa: E402
 from . import slab               # noqa: E402
+from . import restoration        # noqa: E402
+from .restoration import denoise_tv_chambolle   # noqa: E402
 
-__all__ = ["tv_GPU", "tv_operators_GPU", "solvers", "slab"]
+__all__ = ["tv_GPU", "tv_operators_GPU", "solvers", "slab", "restoration", "denoise_tv_chambolle"]

@@ -21,7 +21,7 @@ import torch
 from . import _native as _nv
 from .slab import HaloPlan, Slab
 
-__all__ = ["ChambollePock", "ADMM", "SubgradientDescent", "cp_step_size"]
+__all__ = ["ChambollePock", "ChambollePockOperator", "ADMM", "SubgradientDescent", "cp_step_size"]
 
 
 def cp_step_size(nz_global, m, reg_z_over_reg, reg_time):
@@ -237,6 +237,59 @@ class ChambollePock(_SlabProblem):
             return None
         self.slab.allreduce_sum_(hist)
         return self.loss_from_slots(hist.cpu().numpy(), self.reg)
+
+    def result(self):
+        return self.x
+
+
+# =================================================================================================
+class ChambollePockOperator(_SlabProblem):
+    """min_x 1/2 |A x - b|^2 + regularization * TV(x) for a user-supplied linear operator A (the CT use case the
+    reference is written for: README.md:2; its CP snippet is the special case A = I, README.md:148 ``sigma_A``).
+
+        p <- (p + sigma_A (A x - b)) / (1 + sigma_A)
+        q <- proj_{|.|_2 <= reg}(q + sigma_D D x)                       HIP: tv_cp_dual  (D + prox, fused)
+        x <- x - tau A^T p - tau D^T q                                   HIP: tv_DT_axpy  (D^T + axpy, fused)
+
+    ``A`` and ``AT`` are callables taking and returning DEVICE tensors (``A``: image (Nz, M, Ny, Nx) -> data of any
+    shape, ``AT``: data -> image); they stay the user's code, the TV part runs in the HIP kernels.  ``tau`` must
+    satisfy tau (sigma_A |A|^2 + sigma_D |D|^2) <= 1; the default assumes |A| <= 1.  Single GPU.
+    """
+
+    def __init__(self, A, AT, b, x_init, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
+                 mask_static=False, factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None):
+        super().__init__(x_init, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, None)
+        self.A, self.AT = A, AT
+        self.b = b
+        self.reg = float(regularization)
+        self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
+        self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x_init.shape[1], reg_z_over_reg, reg_time)
+        self.x = self.x0.clone()
+        self.p = torch.zeros_like(b)
+        self.q = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
+        self.ws = self.geo.workspace()
+        self.x_new = torch.empty_like(self.x)
+
+    def step(self, out):
+        """out: fp64 device tensor [tv, fid] (fid = 1/2 |A x_new - b|^2)."""
+        g = self.geo
+        r = self.A(self.x) - self.b
+        self.p = (self.p + self.sigma_A * r) / (1.0 + self.sigma_A)
+        _nv.check(self.lib.tv_cp_dual(g.ref, _nv.ptr(self.x), None, None, _nv.ptr(self.q), self.sigma_D, self.reg,
+                                      out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        base = (self.x - self.tau * self.AT(self.p)).contiguous()
+        _nv.check(self.lib.tv_DT_axpy(g.ref, _nv.ptr(self.q), None, None, None, _nv.ptr(base), -self.tau, _nv.ptr(self.x_new),
+                                      self.stream))
+        self.x, self.x_new = self.x_new, self.x
+        res = self.A(self.x) - self.b
+        out[1:2] = 0.5 * torch.sum(res.double() ** 2)
+
+    def run(self, n_iter):
+        hist = torch.zeros((n_iter, 2), dtype=torch.float64, device=self.device)
+        for it in range(n_iter):
+            self.step(hist[it])
+        h = hist.cpu().numpy()
+        return h[:, 1] + self.reg * h[:, 0]
 
     def result(self):
         return self.x
