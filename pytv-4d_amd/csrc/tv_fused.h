@@ -122,7 +122,15 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
     // the neighbouring wave adds them one plane later (after the per-plane barrier), double-buffered
     __shared__ float edge_cu[XW ? 2 : 1][XW ? M : 1][4][4];
     __shared__ float edge_cd[XW ? 2 : 1][XW ? M : 1][4][4];
+    // edge_flag[w] = number of planes of this chunk whose edge columns wave w has published.  A wave starts
+    // plane z only after both neighbours published plane z-1, so neighbouring waves stay within one plane of
+    // each other (that is what makes two buffers enough) -- a pairwise hand-off, not a block-wide barrier.
+    __shared__ volatile int edge_flag[4];
     const int wave = (int)threadIdx.y;
+    if (XW) {
+        if (c.lane == 0) edge_flag[wave] = 0;
+        __syncthreads();
+    }
     const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
     F4 C[M], P[M];
     {
@@ -161,7 +169,15 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         if (!fused_needs_fixup<S, XW>(g, zf, c.y, c.col0, zchunk)) acc_fid += e2;
     };
 
+    // wait until the neighbouring waves have published `planes` planes (all waves of a block are resident and
+    // a wave never waits for a plane its neighbour can only reach after this wave moves on: no deadlock)
+    auto wait_neighbours = [&](int planes) {
+        if (wave > 0) while (edge_flag[wave - 1] < planes) __builtin_amdgcn_s_sleep(1);
+        if (wave < 3) while (edge_flag[wave + 1] < planes) __builtin_amdgcn_s_sleep(1);
+        __threadfence_block();
+    };
     for (int z = c.zs; z < c.ze; ++z) {
+        if (XW && z > c.zs) wait_neighbours(z - c.zs);
         const int gz = g.z0 + z;
         const float* pc = zplane<float>(g, a.x_in, a.xp, a.xn, 1, z);
         const float* pn = zplane<float>(g, a.x_in, a.xp, a.xn, 1, z + 1);
@@ -308,9 +324,13 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             P[t] = C[t];
             C[t] = N;
         }
-        if (XW) __syncthreads();      // edge columns of plane z are published before anyone finalises plane z
+        if (XW) {                     // publish: edge columns of plane z are visible before the counter moves
+            __threadfence_block();
+            if (c.lane == 0) edge_flag[wave] = z - c.zs + 1;
+        }
     }
     // last plane of the chunk: its z+1 term (if any) is the fix-up kernel's
+    if (XW) wait_neighbours(c.ze - c.zs);
 #pragma unroll
     for (int t = 0; t < M; ++t) finalize(c.ze - 1, t, P[t], lds_R[t][tid]);
 
