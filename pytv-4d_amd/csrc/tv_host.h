@@ -40,6 +40,7 @@ inline int make_dg(const tv_geom* g, DG& d) {
     if (g->dtype != TV_F32 && g->dtype != TV_F64) return fail(TV_E_ARG, "unknown dtype");
     if (g->nz_global > 60000 || g->m > 65535 || g->ny > (1 << 24) || g->nx > (1 << 24))
         return fail(TV_E_ARG, "dimension too large for the launch grid");
+    if ((long long)g->ny * g->nx > (1ll << 31)) return fail(TV_E_ARG, "a frame larger than 2^31 pixels does not fit the launch grid");
     if (!(g->reg_z_over_reg >= 0.0) || !(g->reg_time >= 0.0) || !(g->factor_reg_static >= 0.0))
         return fail(TV_E_ARG, "weights must be non-negative numbers");
     d.nz = (int)g->nz; d.m = (int)g->m; d.ny = (int)g->ny; d.nx = (int)g->nx;
