@@ -610,3 +610,52 @@ def test_full_size_properties_config1(pytv):
     gfield = torch.where(n > 0, d / n, torch.zeros_like(d))
     nv.check(lib.tv_DT(geo.ref, nv.ptr(gfield), None, None, nv.ptr(o), st))
     assert torch.allclose(G, o, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# the north-star shape itself: 2^31 voxels, a 2^34-element dual variable (64-bit offsets everywhere)
+# ------------------------------------------------------------------------------------------------
+def test_full_size_northstar_64bit_indexing_and_paths_agree(pytv):
+    import torch
+    from pytv import _native as nv
+    if torch.cuda.get_device_properties(0).total_memory < 230 * 2 ** 30:
+        pytest.skip("needs ~200 GiB of HBM")
+    shape = (256, 8, 1024, 1024)
+    kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x0 = torch.empty(shape, device="cuda")
+    for k in range(shape[0]):
+        x0[k] = 100.0 * torch.rand(shape[1:], device="cuda", generator=gen)
+    # (a) one-sweep CP == two-kernel CP after 3 iterations, at full size
+    a = pytv.solvers.ChambollePock(x0, 25.0, **kw)
+    la = a.run(3)
+    xa, qa_probe = a.result().clone(), a.q[200:202].clone()
+    del a
+    torch.cuda.empty_cache()
+    b = pytv.solvers.ChambollePock(x0, 25.0, fused=False, **kw)
+    lb = b.run(3)
+    np.testing.assert_allclose(la, lb, rtol=1e-7)
+    assert torch.allclose(xa, b.result(), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(qa_probe, b.q[200:202], rtol=1e-5, atol=1e-4)
+    # (b) planes deep inside the arrays against the oracle (element offsets beyond 2^32 in q, 2^31 in x)
+    q = b.q
+    x = b.result()
+    d = torch.empty((4, 8) + shape[1:], device="cuda")                      # D of planes 252..255 as a slab with a halo
+    g = nv.Geometry((4,) + shape[1:], "hybrid", x.dtype, x.device, nz_global=shape[0], z0=252, **kw)
+    nv.check(nv.lib().tv_D(g.ref, nv.ptr(x[252:256]), nv.ptr(x[251:252]), None, nv.ptr(d), nv.current_stream(x.device)))
+    xs = x[250:256, :, 500:540, 470:550].double().cpu().numpy()
+    want = orc.D(xs, "hybrid", **kw)                                          # window: trust only its interior
+    got = d[:, :, :, 500:540, 470:550].cpu().numpy()
+    np.testing.assert_allclose(got[:, :, :, 1:-1, 1:-1], want[2:, :, :, 1:-1, 1:-1], rtol=1e-5, atol=1e-4)
+    # D^T of the dual variable on the last planes (offsets > 2^33 elements into q)
+    o = torch.empty((4,) + shape[1:], device="cuda")
+    nv.check(nv.lib().tv_DT(g.ref, nv.ptr(q[252:256]), nv.ptr(q[251, 4]), None, nv.ptr(o), nv.current_stream(x.device)))
+    qs = q[250:256, :, :, 500:540, 470:550].double().cpu().numpy()
+    want = orc.D_T(qs, "hybrid", **kw)
+    np.testing.assert_allclose(o[:, :, 500:540, 470:550].cpu().numpy()[:, :, 2:-2, 2:-2], want[2:, :, 2:-2, 2:-2], rtol=1e-5, atol=1e-4)
+    # (c) the l2,1 norm of the whole 64 GiB dual variable three ways
+    v1 = float(pytv.tv_operators_GPU.compute_L21_norm(q))
+    v2 = 0.0
+    for k in range(0, shape[0], 32):
+        v2 += torch.sqrt((q[k:k + 32].double() ** 2).sum(dim=1)).sum().item()
+    assert abs(v1 - v2) <= 1e-6 * v2
