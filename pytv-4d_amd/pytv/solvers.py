@@ -373,15 +373,32 @@ class ADMM(_SlabProblem):
         self.ws_prev = self.new_plane() if pl.g_send_prev else None
         self.ws_next = self.new_plane() if pl.g_send_next else None
         self.sc = torch.zeros(4, dtype=torch.float64, device=self.device)   # rs, dAd, rs_new, spare
+        self.dots3 = torch.zeros(3, dtype=torch.float64, device=self.device)
 
     def _halo2(self, v):
         self.slab.wait(self.plan.exchange_image2(v, self.h2_prev, self.h2_next))
         return self.h2_prev, self.h2_next
 
-    def _normal(self, v, out, dot):
-        hp, hn = self._halo2(v)
-        _nv.check(self.lib.tv_normal_op(self.geo.ref, _nv.ptr(v), _nv.ptr(hp), _nv.ptr(hn), self.rho, _nv.ptr(out),
+    def _normal_range(self, v, out, a, b, hp, hn, dot):
+        """out[a:b] = (I + rho D^T D) v on local planes [a, b); hp / hn: two-plane halos of that range."""
+        g = self.geom(a, b)
+        _nv.check(self.lib.tv_normal_op(g.ref, _nv.ptr(v[a:b]), _nv.ptr(hp), _nv.ptr(hn), self.rho, _nv.ptr(out[a:b]),
                                         dot.data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def _normal(self, v, out, dot):
+        nz = self.slab.nz
+        if self.sh and nz >= 6:
+            # interior planes first (their two-plane halos are this rank's own planes) while the exchange is in
+            # flight, then the two 2-plane edges
+            h = self.plan.exchange_image2(v, self.h2_prev, self.h2_next)
+            self._normal_range(v, out, 2, nz - 2, v[0:2], v[nz - 2:nz], self.dots3[0:1])
+            self.slab.wait(h)
+            self._normal_range(v, out, 0, 2, self.h2_prev, v[2:4], self.dots3[1:2])
+            self._normal_range(v, out, nz - 2, nz, v[nz - 4:nz - 2], self.h2_next, self.dots3[2:3])
+            torch.sum(self.dots3, dim=0, keepdim=True, out=dot)
+        else:
+            hp, hn = self._halo2(v)
+            self._normal_range(v, out, 0, nz, hp, hn, dot)
         self.slab.allreduce_sum_(dot)
 
     def step(self, out):
