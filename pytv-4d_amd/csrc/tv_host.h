@@ -110,6 +110,10 @@ inline bool aligned16(std::initializer_list<const void*> ps) {
 }
 
 // call f.template operator()<S, T, V>() for the run-time (scheme, dtype, vec)
+// lanes of a 16-byte vector for this dtype: `vec` at the call sites means "Nx is a multiple of it and every
+// pointer is 16-byte aligned"
+inline int vec_lanes(const tv_geom* g) { return g->dtype == TV_F32 ? 4 : 2; }
+
 template <typename F> inline int dispatch(int scheme, int dtype, bool vec, F&& f) {
 #define TV_CASE(SC)                                                                  \
     case SC:                                                                         \
@@ -117,6 +121,7 @@ template <typename F> inline int dispatch(int scheme, int dtype, bool vec, F&& f
             if (vec) return f.template operator()<SC, float, 4>();                   \
             return f.template operator()<SC, float, 1>();                            \
         }                                                                            \
+        if (vec) return f.template operator()<SC, double, 2>();                      \
         return f.template operator()<SC, double, 1>();
     switch (scheme) {
         TV_CASE(0) TV_CASE(1) TV_CASE(2) TV_CASE(3)

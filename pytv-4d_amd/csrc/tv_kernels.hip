@@ -1,19 +1,24 @@
-// tv_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the PyTV-4D hot path and the
-// C-ABI declared in include/pytv4d.h.
+// tv_kernels.hip -- one-site-per-thread HIP kernels (gfx950 / CDNA4) for the PyTV-4D hot path and most of the
+// C-ABI declared in include/pytv4d.h.  (Plane-marching kernels: tv_march.h + tv_march_D/DT.hip; the one-sweep
+// Chambolle-Pock iteration and the marching sub-gradient gather: tv_fused.h + tv_fused.hip.)
 //
-//   k_D      : forward operator D (all four schemes) with a fused epilogue
+//   k_D      : forward operator D (all four schemes) with a fused epilogue (tv_stencil.h)
 //                StoreD   -> materialise the gradient            (tv_D)
-//                NormEpi  -> |Dx|_2 per voxel + TV partial sums  (tv_subgrad pass 1)
+//                NormEpi  -> 1/|Dx|_2 per voxel + TV partials    (tv_subgrad pass 1)
 //                CpDual   -> q <- proj(q + sigma D x)            (tv_cp_dual)
 //                AdmmZU   -> z/u update of ADMM                  (tv_admm_zu)
 //   k_DT     : transposed operator as a GATHER (no atomics, no scratch time buffer) with
 //                StoreDT / AxpyDT / CpPrimal epilogues           (tv_DT, tv_DT_axpy, tv_cp_primal)
-//   k_gather : radius-2 stencils evaluated from x alone          (tv_subgrad pass 2, tv_normal_op)
+//   k_subgrad_vec / k_subgrad_central_vec : sub-gradient from x and 1/|Dx| (tv_subgrad pass 2)
+//   k_normal_vec  / k_normal_central_vec  : x + rho D^T D x from x alone   (tv_normal_op)
+//   k_gather : scalar reference evaluation of the last two (TV_SCALAR_GATHER=1)
 //   k_l21, k_dot, k_sub, k_cg1, k_cg2, k_sgstep, k_reduce        small streaming / reduction kernels
 //
 // Per-voxel definitions follow SURVEY 8a-1 / 8a-2, i.e. pytv/tv_operators_CPU.py:117-154,198-218,
 // 264-284,330-358 (D) and :398-448,487-516,554-583,622-658 (D^T); the sub-gradient follows
 // pytv/tv_CPU.py:91-126,176-190,239-253,302-330.
+#include <hip/hip_runtime.h>
+
 #include "tv_host.h"
 #include "tv_stencil.h"
 
@@ -598,7 +603,7 @@ int tv_D(const tv_geom* g, const void* x, const void* x_prev, const void* x_next
     if (int rc = make_dg(g, d)) return rc;
     if (x == nullptr || dout == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, dout});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, dout});
     hipStream_t st = (hipStream_t)stream;
     // tv_D is write dominated (1 word read, Nd written): the one-site-per-thread kernel is faster than the
     // marching one here (measured 4.85 vs 5.66 ms on 64x8x1024x1024 hybrid); TV_MARCH_D=1 forces marching
@@ -626,7 +631,7 @@ int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_pr
     if (int rc = make_dg(g, d)) return rc;
     if (a == nullptr || out == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_y_halos(g, d, ab_prev, ab_next)) return rc;
-    const bool vec = (d.nx % 4 == 0) && aligned16({a, b, ab_prev, ab_next, base, out});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({a, b, ab_prev, ab_next, base, out});
     hipStream_t st = (hipStream_t)stream;
     const bool plain_store = (base == nullptr && alpha == 1.0);
     if (b == nullptr && march_ok(g, d, vec)) {
@@ -664,7 +669,7 @@ int tv_l21(const tv_geom* g, const void* dimg, int32_t nd, void* norms, double* 
     // the l2,1 norm does not care which scheme produced the channels: honour the caller's nd
     d.nd = nd;
     d.s_dz = d.s_z * nd;
-    const bool vec = (d.nx % 4 == 0) && aligned16({dimg, norms});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({dimg, norms});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     return dispatch(0, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
@@ -685,7 +690,7 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
     if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr)))
         return fail(TV_E_HALO, "tv_subgrad on a slab needs two halo planes on each interior side");
-    const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, norms_ext});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, norms_ext});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec && aligned16({G})) && !env_int("TV_NO_MARCH_SUBGRAD", 0)) {
@@ -716,7 +721,7 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
         // pass 2: gather (vectorised for the radius-1 schemes, scalar radius-2 kernel for central)
         if constexpr (S != CENTRAL) {
             const bool v2 = vec && aligned16({G});
-            if (v2 && V == 4) {
+            if (v2 && V > 1) {
                 LC lg = launch_cfg(d, V, d.nz);
                 hipLaunchKernelGGL((k_subgrad_vec<S, T, V>), lg.grid, lg.block, 0, st, d, w, (const T*)x, (const T*)x_prev,
                                    (const T*)x_next, (const T*)norms_ext, (T*)G);
@@ -732,7 +737,7 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
             hipLaunchKernelGGL((k_gather<S, T, 0>), lg.grid, lg.block, 0, st, X, w, (const T*)norms_ext, T(0), (T*)G, (double*)nullptr);
         } else {
             const bool v2 = vec && aligned16({G});
-            if (v2 && V == 4) {
+            if (v2 && V > 1) {
                 LC lg = launch_cfg(d, V, d.nz);
                 hipLaunchKernelGGL((k_subgrad_central_vec<T, V>), lg.grid, lg.block, 0, st, d, w, (const T*)x, (const T*)x_prev,
                                    (const T*)x_next, (const T*)norms_ext, (T*)G);
@@ -757,7 +762,7 @@ int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void
         return fail(TV_E_HALO, "tv_normal_op on a slab needs two halo planes on each interior side");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, out});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out});
     // (a plane-marching variant of this operator was measured: 1.80 vs 1.65 ms on 64x8x1024x1024 -- not kept)
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lg = launch_cfg(d, V, d.nz);
@@ -788,7 +793,7 @@ int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* 
     if (x == nullptr || q == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, q});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, q});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
@@ -814,7 +819,7 @@ int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void
     if (q == nullptr || x == nullptr || x0 == nullptr || p == nullptr || fid == nullptr || ws == nullptr)
         return fail(TV_E_ARG, "NULL array");
     if (int rc = check_y_halos(g, d, q_prev, q_next)) return rc;
-    const bool vec = (d.nx % 4 == 0) && aligned16({q, q_prev, q_next, x, x0, p});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({q, q_prev, q_next, x, x0, p});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
@@ -839,7 +844,7 @@ int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* 
     if (int rc = make_dg(g, d)) return rc;
     if (x == nullptr || z == nullptr || u == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, z, u});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, z, u});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
