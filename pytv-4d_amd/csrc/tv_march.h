@@ -73,11 +73,13 @@ __device__ __forceinline__ void col_neighbours(const V4& v, const float* p, bool
 // =============================================================================================
 // hp: planes per halo buffer (1, or 2 for the radius-2 entry points); [z_first, z_end): local planes to
 // visit (ghost planes outside [0, nz) come from the halo buffers)
-template <int S, int M, typename Epi>
-__global__ __launch_bounds__(256) void k_D_march(DG g, WT<float> w, const float* __restrict__ x, const float* __restrict__ xp,
+// LIGHT: for epilogues with little traffic per site (StoreD, NormEpi): single-buffered tile (two barriers per
+// plane, 32 KiB at M = 8 -> up to 5 blocks/CU) and a register cap of 168 so that 3 waves/SIMD hide the latency
+template <int S, int M, typename Epi, bool LIGHT = false>
+__global__ __launch_bounds__(256, LIGHT ? 3 : 1) void k_D_march(DG g, WT<float> w, const float* __restrict__ x, const float* __restrict__ xp,
                                                  const float* __restrict__ xn, int zchunk, Epi epi, int hp = 1, int z_first = 0,
                                                  int z_end = -1) {
-    __shared__ V4 tile[2][M][4][64];   // double-buffered: one barrier per z step
+    __shared__ V4 tile[LIGHT ? 1 : 2][M][4][64];   // double-buffered: one barrier per z step
     __shared__ double sm[16];
     const MarchCoord c = march_coord(g, zchunk, z_first, z_end);
     constexpr bool NEXT = (S != DOWNWIND), PREV = (S != UPWIND);
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void k_D_march(DG g, WT<float> w, const float*
     }
     for (int z = c.zs; z < c.ze; ++z) {
         // publish plane z for the row neighbours
-        const int buf = (z - c.zs) & 1;
+        const int buf = LIGHT ? 0 : ((z - c.zs) & 1);
 #pragma unroll
         for (int t = 0; t < M; ++t) tile[buf][t][c.ty][c.lane] = C[t];
         __syncthreads();
@@ -149,8 +151,9 @@ __global__ __launch_bounds__(256) void k_D_march(DG g, WT<float> w, const float*
             P[t] = C[t];
             C[t] = N;
         }
-        // no second barrier: the other buffer is written next, and it was last read before this
-        // step's barrier
+        // double-buffered: no second barrier (the other buffer is written next, and it was last read before
+        // this step's barrier); single-buffered: everyone must be done reading before the tile is rewritten
+        if (LIGHT) __syncthreads();
     }
     if (Epi::REDUCES) {
         acc = block_sum(acc, sm);
