@@ -115,6 +115,7 @@ def main():
     backend = os.environ.get("TV_BENCH_BACKEND", "nccl")
     if os.environ.get("TV_BENCH_SHARE_GPU", "0") == "1":
         local_rank = 0
+    local_rank %= max(1, torch.cuda.device_count())      # launchers that pin one visible device per rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
