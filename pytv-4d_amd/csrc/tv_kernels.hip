@@ -511,56 +511,64 @@ __global__ __launch_bounds__(256) void k_l21(DG g, const T* d, T* norms, double*
 }
 
 // =============================================================================================
-// flat streaming kernels (grid-stride, one element per lane per trip; n = nz*m*ny*nx)
+// flat streaming kernels (grid-stride, one V-wide 16-byte vector per lane per trip; nv = n / V vectors)
 // =============================================================================================
-template <typename T> __global__ __launch_bounds__(256) void k_sub(long long n, const T* a, const T* b, T* out) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        out[i] = a[i] - b[i];
+template <typename T, int V> __global__ __launch_bounds__(256) void k_sub(long long nv, const T* a, const T* b, T* out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x)
+        vstore<T, V>(out + i * V, vload<T, V>(a + i * V) - vload<T, V>(b + i * V));
 }
-template <typename T> __global__ __launch_bounds__(256) void k_dot(long long n, const T* a, const T* b, double* partials) {
+template <typename T, int V> __global__ __launch_bounds__(256) void k_dot(long long nv, const T* a, const T* b, double* partials) {
     __shared__ double sm[16];
     double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        acc += (double)a[i] * (double)b[i];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const Vec<T, V> av = vload<T, V>(a + i * V), bv = vload<T, V>(b + i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc += (double)av.v[k] * (double)bv.v[k];
+    }
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 // alpha = rs/dAd;  x += alpha d;  r -= alpha Ad;  partial <r, r>
-template <typename T>
-__global__ __launch_bounds__(256) void k_cg1(long long n, T* x, T* r, const T* d, const T* Ad, const double* rs,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_cg1(long long nv, T* x, T* r, const T* d, const T* Ad, const double* rs,
                                               const double* dAd, double* partials) {
     __shared__ double sm[16];
     const double den = *dAd;
     const T alpha = (den > 0.0) ? (T)(*rs / den) : T(0);
     double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        x[i] = x[i] + alpha * d[i];
-        const T rn = r[i] - alpha * Ad[i];
-        r[i] = rn;
-        acc += (double)rn * (double)rn;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        vstore<T, V>(x + i * V, vload<T, V>(x + i * V) + alpha * vload<T, V>(d + i * V));
+        const Vec<T, V> rn = vload<T, V>(r + i * V) - alpha * vload<T, V>(Ad + i * V);
+        vstore<T, V>(r + i * V, rn);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc += (double)rn.v[k] * (double)rn.v[k];
     }
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 // beta = rs_new/rs;  d = r + beta d
-template <typename T>
-__global__ __launch_bounds__(256) void k_cg2(long long n, T* d, const T* r, const double* rs_new, const double* rs) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_cg2(long long nv, T* d, const T* r, const double* rs_new, const double* rs) {
     const double den = *rs;
     const T beta = (den > 0.0) ? (T)(*rs_new / den) : T(0);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        d[i] = r[i] + beta * d[i];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x)
+        vstore<T, V>(d + i * V, vload<T, V>(r + i * V) + beta * vload<T, V>(d + i * V));
 }
 // README.md:122-123: x <- x - step * ((x - x0) + lambda G); partial 1/2 |x - x0|^2
-template <typename T>
-__global__ __launch_bounds__(256) void k_sgstep(long long n, T* x, const T* x0, const T* G, T step, T lambda, double* partials) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_sgstep(long long nv, T* x, const T* x0, const T* G, T step, T lambda, double* partials) {
     __shared__ double sm[16];
     double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const T xv = x[i], x0v = x0[i];
-        const T xn = xv - step * ((xv - x0v) + lambda * G[i]);
-        x[i] = xn;
-        const double e = (double)xn - (double)x0v;
-        acc += 0.5 * e * e;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const Vec<T, V> xv = vload<T, V>(x + i * V), x0v = vload<T, V>(x0 + i * V), gv = vload<T, V>(G + i * V);
+        Vec<T, V> xn;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            xn.v[k] = xv.v[k] - step * ((xv.v[k] - x0v.v[k]) + lambda * gv.v[k]);
+            const double e = (double)xn.v[k] - (double)x0v.v[k];
+            acc += 0.5 * e * e;
+        }
+        vstore<T, V>(x + i * V, xn);
     }
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
@@ -866,13 +874,27 @@ int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* 
 // ---------------------------------------------------------------------------------------------
 static long long nvox(const DG& d) { return d.s_z * d.nz; }
 
+// launch a flat kernel template KERN<T, V> with the widest 16-byte vector that n and the pointers allow
+#define TV_FLAT_LAUNCH(KERN, dtype, n, ptrs, ...)                                                                             \
+    do {                                                                                                                      \
+        const bool al__ = aligned16 ptrs;                                                                                     \
+        if ((dtype) == TV_F32) {                                                                                              \
+            using T = float;                                                                                                  \
+            if (al__ && (n) % 4 == 0) hipLaunchKernelGGL((KERN<T, 4>), dim3(kFlatBlocks), dim3(256), 0, st, (long long)(n) / 4, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERN<T, 1>), dim3(kFlatBlocks), dim3(256), 0, st, (long long)(n), __VA_ARGS__);            \
+        } else {                                                                                                              \
+            using T = double;                                                                                                 \
+            if (al__ && (n) % 2 == 0) hipLaunchKernelGGL((KERN<T, 2>), dim3(kFlatBlocks), dim3(256), 0, st, (long long)(n) / 2, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERN<T, 1>), dim3(kFlatBlocks), dim3(256), 0, st, (long long)(n), __VA_ARGS__);            \
+        }                                                                                                                     \
+    } while (0)
+
 int tv_sub(int32_t dtype, int64_t n, const void* a, const void* b, void* out, void* stream) {
     if (n < 0 || a == nullptr || b == nullptr || out == nullptr) return fail(TV_E_ARG, "bad argument");
     if (dtype != TV_F32 && dtype != TV_F64) return fail(TV_E_ARG, "unknown dtype");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return 0;
-    if (dtype == TV_F32) hipLaunchKernelGGL(k_sub<float>, dim3(kFlatBlocks), dim3(256), 0, st, (long long)n, (const float*)a, (const float*)b, (float*)out);
-    else hipLaunchKernelGGL(k_sub<double>, dim3(kFlatBlocks), dim3(256), 0, st, (long long)n, (const double*)a, (const double*)b, (double*)out);
+    TV_FLAT_LAUNCH(k_sub, dtype, n, ({a, b, out}), (const T*)a, (const T*)b, (T*)out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -882,8 +904,7 @@ int tv_dot(const tv_geom* g, const void* a, const void* b, double* result, void*
     if (int rc = make_dg(g, d)) return rc;
     if (a == nullptr || b == nullptr || result == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     hipStream_t st = (hipStream_t)stream;
-    if (g->dtype == TV_F32) hipLaunchKernelGGL(k_dot<float>, dim3(kFlatBlocks), dim3(256), 0, st, nvox(d), (const float*)a, (const float*)b, (double*)ws);
-    else hipLaunchKernelGGL(k_dot<double>, dim3(kFlatBlocks), dim3(256), 0, st, nvox(d), (const double*)a, (const double*)b, (double*)ws);
+    TV_FLAT_LAUNCH(k_dot, g->dtype, nvox(d), ({a, b}), (const T*)a, (const T*)b, (double*)ws);
     HIP_TRY(hipGetLastError());
     return reduce_partials((double*)ws, kFlatBlocks, max_partials(d), result, st);
 }
@@ -894,8 +915,7 @@ int tv_cg_step1(const tv_geom* g, void* x, void* r, const void* dvec, const void
     if (int rc = make_dg(g, d)) return rc;
     if (!x || !r || !dvec || !Ad || !rs || !dAd || !rs_new || !ws) return fail(TV_E_ARG, "NULL array");
     hipStream_t st = (hipStream_t)stream;
-    if (g->dtype == TV_F32) hipLaunchKernelGGL(k_cg1<float>, dim3(kFlatBlocks), dim3(256), 0, st, nvox(d), (float*)x, (float*)r, (const float*)dvec, (const float*)Ad, rs, dAd, (double*)ws);
-    else hipLaunchKernelGGL(k_cg1<double>, dim3(kFlatBlocks), dim3(256), 0, st, nvox(d), (double*)x, (double*)r, (const double*)dvec, (const double*)Ad, rs, dAd, (double*)ws);
+    TV_FLAT_LAUNCH(k_cg1, g->dtype, nvox(d), ({x, r, dvec, Ad}), (T*)x, (T*)r, (const T*)dvec, (const T*)Ad, rs, dAd, (double*)ws);
     HIP_TRY(hipGetLastError());
     return reduce_partials((double*)ws, kFlatBlocks, max_partials(d), rs_new, st);
 }
@@ -905,8 +925,7 @@ int tv_cg_step2(const tv_geom* g, void* dvec, const void* r, const double* rs_ne
     if (int rc = make_dg(g, d)) return rc;
     if (!dvec || !r || !rs_new || !rs) return fail(TV_E_ARG, "NULL array");
     hipStream_t st = (hipStream_t)stream;
-    if (g->dtype == TV_F32) hipLaunchKernelGGL(k_cg2<float>, dim3(kFlatBlocks), dim3(256), 0, st, nvox(d), (float*)dvec, (const float*)r, rs_new, rs);
-    else hipLaunchKernelGGL(k_cg2<double>, dim3(kFlatBlocks), dim3(256), 0, st, nvox(d), (double*)dvec, (const double*)r, rs_new, rs);
+    TV_FLAT_LAUNCH(k_cg2, g->dtype, nvox(d), ({dvec, r}), (T*)dvec, (const T*)r, rs_new, rs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -917,8 +936,7 @@ int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, do
     if (int rc = make_dg(g, d)) return rc;
     if (!x || !x0 || !G || !fid || !ws) return fail(TV_E_ARG, "NULL array");
     hipStream_t st = (hipStream_t)stream;
-    if (g->dtype == TV_F32) hipLaunchKernelGGL(k_sgstep<float>, dim3(kFlatBlocks), dim3(256), 0, st, nvox(d), (float*)x, (const float*)x0, (const float*)G, (float)step, (float)lambda, (double*)ws);
-    else hipLaunchKernelGGL(k_sgstep<double>, dim3(kFlatBlocks), dim3(256), 0, st, nvox(d), (double*)x, (const double*)x0, (const double*)G, step, lambda, (double*)ws);
+    TV_FLAT_LAUNCH(k_sgstep, g->dtype, nvox(d), ({x, x0, G}), (T*)x, (const T*)x0, (const T*)G, (T)step, (T)lambda, (double*)ws);
     HIP_TRY(hipGetLastError());
     return reduce_partials((double*)ws, kFlatBlocks, max_partials(d), fid, st);
 }

@@ -42,12 +42,12 @@ int D_norms(const tv_geom* g, const DG& d, const void* x, const void* xp, const 
         NormEpi<S, float, 4> epi{norms_ext, partials};
         // LIGHT variant (3 waves/SIMD, single-buffered tile): 15-20 % faster than the default one for this
         // low-traffic epilogue (measured); M = 16 does not fit its register cap
-        if (M <= 8)
+        if constexpr (M <= 8)
             hipLaunchKernelGGL((k_D_march<S, M, NormEpi<S, float, 4>, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g),
                                (const float*)x, (const float*)xp, (const float*)xn, zc, epi, 2, -ghost_lo, d.nz + ghost_hi);
         else
-        hipLaunchKernelGGL((k_D_march<S, M, NormEpi<S, float, 4>>), lc.grid, lc.block, 0, st, d, make_w<float>(g), (const float*)x,
-                           (const float*)xp, (const float*)xn, zc, epi, 2, -ghost_lo, d.nz + ghost_hi);
+            hipLaunchKernelGGL((k_D_march<S, M, NormEpi<S, float, 4>>), lc.grid, lc.block, 0, st, d, make_w<float>(g), (const float*)x,
+                               (const float*)xp, (const float*)xn, zc, epi, 2, -ghost_lo, d.nz + ghost_hi);
         HIP_TRY(hipGetLastError());
         return 0;
     });
