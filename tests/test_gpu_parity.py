@@ -659,3 +659,67 @@ def test_full_size_northstar_64bit_indexing_and_paths_agree(pytv):
     for k in range(0, shape[0], 32):
         v2 += torch.sqrt((q[k:k + 32].double() ** 2).sum(dim=1)).sum().item()
     assert abs(v1 - v2) <= 1e-6 * v2
+
+
+# ------------------------------------------------------------------------------------------------
+# memory safety: every array lives inside a larger buffer whose padding is NaN (reads of it would poison the
+# results) and is checked afterwards (writes to it would show)
+# ------------------------------------------------------------------------------------------------
+def _guarded(shape, dtype, fill=None, pad=4099):
+    import torch
+    n = int(np.prod(shape))
+    pad = (pad + 3) // 4 * 4            # keep the payload 16-byte aligned
+    buf = torch.full((n + 2 * pad,), float("nan"), dtype=dtype, device="cuda")
+    view = buf[pad:pad + n].view(shape)
+    if fill is not None:
+        view.copy_(fill)
+    return buf, view, pad
+
+
+def _guards_intact(buf, pad):
+    import torch
+    return bool(torch.isnan(buf[:pad]).all() and torch.isnan(buf[-pad:]).all())
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape,dtype", [((5, 3, 7, 132), np.float32), ((4, 8, 6, 256), np.float32), ((5, 2, 9, 22), np.float64),
+                                         ((3, 4, 5, 9), np.float32)])
+def test_no_out_of_bounds_access(pytv, scheme, shape, dtype):
+    import torch
+    from pytv import _native as nv
+    lib = nv.lib()
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.default_rng(81)
+    kw = dict(reg_z_over_reg=1.2, reg_time=0.8)
+    g = nv.Geometry(shape, scheme, tdt, "cuda", **kw)
+    st = nv.current_stream(torch.device("cuda", 0))
+    xb, x, px = _guarded(shape, tdt, torch.as_tensor(rng.standard_normal(shape).astype(dtype)).cuda())
+    x0b, x0, p0 = _guarded(shape, tdt, torch.as_tensor(rng.standard_normal(shape).astype(dtype)).cuda())
+    pb, p, pp = _guarded(shape, tdt, torch.zeros(shape, dtype=tdt, device="cuda"))
+    ob, o, po = _guarded(shape, tdt, torch.zeros(shape, dtype=tdt, device="cuda"))
+    qb, q, pq = _guarded(g.grad_shape, tdt, torch.as_tensor(rng.standard_normal(g.grad_shape).astype(dtype)).cuda())
+    ub, u, pu = _guarded(g.grad_shape, tdt, torch.zeros(g.grad_shape, dtype=tdt, device="cuda"))
+    nb_, ne, pn = _guarded((shape[0] + 2,) + shape[1:], tdt, torch.ones((shape[0] + 2,) + shape[1:], dtype=tdt, device="cuda"))
+    sc, ws = g.scalar(), g.workspace()
+    ck = nv.check
+    ck(lib.tv_D(g.ref, nv.ptr(x), None, None, nv.ptr(u), st))
+    ck(lib.tv_DT(g.ref, nv.ptr(q), None, None, nv.ptr(o), st))
+    ck(lib.tv_l21(g.ref, nv.ptr(q), g.nd, nv.ptr(o), nv.ptr(sc), nv.ptr(ws), st))
+    ck(lib.tv_subgrad(g.ref, nv.ptr(x), None, None, nv.ptr(o), nv.ptr(ne), nv.ptr(sc), nv.ptr(ws), st))
+    ck(lib.tv_normal_op(g.ref, nv.ptr(x), None, None, 0.3, nv.ptr(o), nv.ptr(sc), nv.ptr(ws), st))
+    ck(lib.tv_cp_dual(g.ref, nv.ptr(x), None, None, nv.ptr(q), 0.5, 5.0, nv.ptr(sc), nv.ptr(ws), st))
+    ck(lib.tv_cp_primal(g.ref, nv.ptr(q), None, None, nv.ptr(x), nv.ptr(x0), nv.ptr(p), 0.05, 1.0, nv.ptr(sc), nv.ptr(ws), st))
+    ck(lib.tv_admm_zu(g.ref, nv.ptr(x), None, None, nv.ptr(q), nv.ptr(u), 0.7, nv.ptr(sc), nv.ptr(ws), st))
+    ck(lib.tv_DT_axpy(g.ref, nv.ptr(q), nv.ptr(u), None, None, nv.ptr(x0), 0.2, nv.ptr(o), st))
+    if lib.tv_cp_fused_supported(g.ref):
+        sc2 = g.scalar()
+        ck(lib.tv_cp_fused(g.ref, nv.ptr(x), None, None, nv.ptr(q), nv.ptr(x0), nv.ptr(p), nv.ptr(o), 0.5, 5.0, 0.05, 1.0, 0, -1,
+                           nv.ptr(sc), nv.ptr(sc2), nv.ptr(ws), st))
+        ck(lib.tv_cp_fixup(g.ref, nv.ptr(q), None, None, nv.ptr(o), nv.ptr(x0), 0.05, 0, -1, nv.ptr(sc2), nv.ptr(ws), st))
+    torch.cuda.synchronize()
+    for name, buf, view, pad in (("x", xb, x, px), ("x0", x0b, x0, p0), ("p", pb, p, pp), ("out", ob, o, po), ("q", qb, q, pq),
+                                 ("u", ub, u, pu), ("norms", nb_, ne, pn)):
+        assert _guards_intact(buf, pad), "%s: padding was written (%s %s)" % (name, scheme, shape)
+        body = view if name != "norms" else view[1:-1]
+        assert bool(torch.isfinite(body).all()), "%s: padding leaked into the result (%s %s)" % (name, scheme, shape)
+    assert np.isfinite(float(sc))
