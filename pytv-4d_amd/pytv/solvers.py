@@ -235,16 +235,53 @@ class ChambollePock(_SlabProblem):
             ev[2].record()
         self.it += 1
 
-    def run(self, n_iter, record_loss=True):
+    GRAPH_BLOCK = 10            # iterations captured per hipGraph (even: the x ping-pong returns to its start)
+    GRAPH_MAX_VOXELS = 1 << 23  # below this an iteration is launch-bound (tens of microseconds of kernels)
+
+    def run(self, n_iter, record_loss=True, graph=None):
         """n_iter iterations; returns the README's loss history (README.md:157) as a numpy array
-        (global over all ranks), or None."""
+        (global over all ranks), or None.  graph: None = capture the loop in a hipGraph when the problem is
+        small enough to be launch-bound and not sharded; True / False force it."""
         hist = torch.zeros((n_iter, self.SLOTS), dtype=torch.float64, device=self.device)
-        for it in range(n_iter):
+        use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS and not self.slab.sharded and self.timing is None) if graph is None else bool(graph)
+        start = 0
+        if use_graph and n_iter >= 2 + 2 * self.GRAPH_BLOCK and not self.slab.sharded:
+            # two eager iterations (also the warm-up of the capture), then graph replays, then an eager tail
+            self.step(hist[0])
+            self.step(hist[1])
+            done = self._run_graphed_from(hist, 2, n_iter)
+            start = 2 + max(done, 0)
+        for it in range(start, n_iter):
             self.step(hist[it])
         if not record_loss:
             return None
         self.slab.allreduce_sum_(hist)
         return self.loss_from_slots(hist.cpu().numpy(), self.reg)
+
+    def _run_graphed_from(self, hist, first, n_iter):
+        """Capture GRAPH_BLOCK iterations (not executed during capture) and replay them over hist[first:]."""
+        K = self.GRAPH_BLOCK
+        nrep = (n_iter - first) // K
+        if nrep < 1:
+            return 0
+        it0, x_ref, xalt_ref = self.it, self.x, self.x_alt
+        try:
+            buf = torch.zeros((K, self.SLOTS), dtype=torch.float64, device=self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for k in range(K):
+                    self.step(buf[k])
+        except Exception:
+            self.it, self.x, self.x_alt = it0, x_ref, xalt_ref      # nothing ran: undo the bookkeeping, stay eager
+            return 0
+        self.it = it0
+        done = 0
+        for r in range(nrep):
+            graph.replay()
+            hist[first + done:first + done + K].copy_(buf)
+            done += K
+            self.it += K
+        return done
 
     def result(self):
         return self.x
