@@ -88,6 +88,26 @@ def cpu_baseline(shape, reg_z, reg_time, nd):
             "host_cpus": os.cpu_count(), "numpy": np.__version__}
 
 
+def cpu_baseline_openmp(shape, reg_z, reg_time):
+    """The C / OpenMP oracle (oracle/tv_oracle_c.c, cross-checked against the NumPy oracle) on all host cores."""
+    from oracle import tv_oracle_c as occ
+    Nz, M, Ny, Nx = shape
+    nz_cpu = max(2, min(Nz, int(round(6.7e7 / (M * Ny * Nx)))))
+    sub = (nz_cpu, M, Ny, Nx)
+    rng = np.random.default_rng(0)
+    x0 = (100.0 * rng.random(sub)).astype(np.float32)
+    occ.chambolle_pock(x0[:2], 1, 25.0, scheme="hybrid", reg_z_over_reg=reg_z, reg_time=reg_time)      # build + warm up
+    n_it = 3
+    t0 = time.perf_counter()
+    occ.chambolle_pock(x0, n_it, 25.0, scheme="hybrid", reg_z_over_reg=reg_z, reg_time=reg_time)
+    dt = (time.perf_counter() - t0) / n_it
+    vox = float(np.prod(sub))
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": vox / dt / float(np.prod(shape)), "unit": "it/s", "cores": threads, "kind": "port", "mvox_per_s": vox / dt / 1e6,
+            "sample": "oracle C/OpenMP chambolle_pock (fp32) on a %s z-sub-slab, %d iterations, %.2f s/iteration; it/s extrapolated "
+                      "linearly in Nz to %s" % (sub, n_it, dt, tuple(shape))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +244,10 @@ def main():
         del cp, x0
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(shape, wl["reg_z"], wl["reg_time"], nd)
+        try:
+            out["cpu_baseline_openmp"] = cpu_baseline_openmp(shape, wl["reg_z"], wl["reg_time"])
+        except Exception as exc:                      # no gcc / OpenMP on this host: the NumPy baseline stands alone
+            out["cpu_baseline_openmp"] = {"error": str(exc)[:200]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
