@@ -69,6 +69,18 @@ __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, in
     return f;
 }
 
+// uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: lets the compiler use the scalar-base form of
+// global_load / global_store (one VGPR of address for every stream of the site instead of a 64-bit VGPR pair each)
+__device__ __forceinline__ F4 ldu(const float* ubase, unsigned voff) {
+    return *reinterpret_cast<const F4*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+__device__ __forceinline__ float ldu1(const float* ubase, unsigned voff) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+__device__ __forceinline__ void stu(float* ubase, unsigned voff, const F4& v) {
+    *reinterpret_cast<F4*>(reinterpret_cast<char*>(ubase) + voff) = v;
+}
+
 __device__ __forceinline__ F4 shfl_up16(const F4& v) {
     F4 r;
 #pragma unroll
@@ -101,6 +113,8 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
     static_assert(S != CENTRAL, "central has a radius-2 adjoint: two-kernel path");
     __shared__ double sm[16];
     const FusedCoord c = fused_coord(g, zchunk, chunk0);
+    const unsigned voff = (unsigned)c.inpl * 4u;          // byte offset of this lane's vector inside a frame (frames <= 2^30 px)
+    const unsigned row_bytes = (unsigned)g.nx * 4u;
     constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
     constexpr bool NEXT = UP, PREV = DN;       // forward differences need x(+e), backward x(-e)
     const F4 zero = vsplat<float, 4>(0.f);
@@ -138,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         const float* pp = (PREV && g.za) ? zplane<float>(g, a.x_in, a.xp, a.xn, 1, c.zs - 1) : nullptr;
 #pragma unroll
         for (int t = 0; t < M; ++t) {
-            C[t] = c.ok ? vload<float, 4>(pc + (long long)t * g.s_t + c.inpl) : zero;
-            P[t] = (c.ok && pp != nullptr) ? vload<float, 4>(pp + (long long)t * g.s_t + c.inpl) : zero;
+            C[t] = c.ok ? ldu(pc + (long long)t * g.s_t, voff) : zero;
+            P[t] = (c.ok && pp != nullptr) ? ldu(pp + (long long)t * g.s_t, voff) : zero;
             lds_R[t][tid] = zero;
             lds_U[t][tid] = zero;
         }
@@ -153,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             if (UP && c.lx == 0 && wave > 0) racc.v[0] += edge_cu[eb][t][wave - 1][c.row];
             if (DN && c.lx == 15 && wave < 3) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
         }
-        const long long off = (long long)zf * g.s_z + (long long)t * g.s_t + c.inpl;
-        const F4 x0v = vload<float, 4>(a.x0 + off), pv = vload<float, 4>(a.p + off);
+        const long long foff = (long long)zf * g.s_z + (long long)t * g.s_t;      // uniform
+        const F4 x0v = ldu(a.x0 + foff, voff), pv = ldu(a.p + foff, voff);
         F4 pn, xo;
         double e2 = 0.0;
 #pragma unroll
@@ -164,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             const double e = (double)xo.v[i] - (double)x0v.v[i];
             e2 += 0.5 * e * e;
         }
-        vstore<float, 4>(a.p + off, pn);
-        vstore<float, 4>(a.x_out + off, xo);
+        stu(a.p + foff, voff, pn);
+        stu(a.x_out + foff, voff, xo);
         if (!fused_needs_fixup<S, XW>(g, zf, c.y, c.col0, zchunk)) acc_fid += e2;
     };
 
@@ -189,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         F4 r_prev = zero;      // accumulator of frame t-1 of THIS plane, still missing its time-down term
 #pragma unroll
         for (int t = 0; t < M; ++t) {
-            const long long off = (long long)t * g.s_t + c.inpl;
-            const F4 N = load_next ? vload<float, 4>(pn + off) : zero;
+            const long long toff = (long long)t * g.s_t;                          // uniform
+            const F4 N = load_next ? ldu(pn + toff, voff) : zero;
             // ------------------------------------------------ neighbourhood of x(z, t)
             XN<float, 4> n;
             n.c = C[t];
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
                 const bool want_up = PREV && (c.row == 0) && c.ok && (c.y > 0);
                 const bool want_dn = NEXT && (c.row == 3) && c.ok && (c.y + 1 < g.ny);
                 F4 halo = zero;
-                if (want_up || want_dn) halo = vload<float, 4>(pc + off + (want_up ? -(long long)g.nx : (long long)g.nx));
+                if (want_up || want_dn) halo = ldu(pc + toff, want_up ? voff - row_bytes : voff + row_bytes);
                 if (NEXT) {
                     n.h_nr = c.ok && (c.y + 1 < g.ny);
                     const F4 sdn = shfl_down16(C[t]);
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
                 const bool le = PREV && (c.lx == 0) && c.ok && (c.col0 > 0);
                 const bool re = NEXT && (c.lx == 15) && c.ok && (c.col0 + 4 < g.nx);
                 float edge = 0.f;
-                if (le || re) edge = le ? pc[off - 1] : pc[off + 4];
+                if (le || re) edge = ldu1(pc + toff, le ? voff - 4u : voff + 16u);
                 if (NEXT) {
                     const float sh = __shfl_down(C[t].v[0], 1, 64);
                     n.nc = shift_left<float, 4>(C[t], (c.lx == 15) ? edge : sh);
@@ -241,12 +255,12 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             F4 v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = zero;
-            float* qbase = a.q + (long long)z * g.s_dz + off;
+            float* qbase = a.q + (long long)z * g.s_dz + toff;                    // uniform
             F4 vs = zero;
             if (c.ok) {
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
-                    v[k] = vload<float, 4>(qbase + (long long)ch * g.s_z) + a.sigma * o[k];
+                    v[k] = ldu(qbase + (long long)ch * g.s_z, voff) + a.sigma * o[k];
                     vs = vs + v[k] * v[k];
                 });
                 const F4 ds = sumsq_slots<float, 4>(o);
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
                     v[k] = v[k] * scale;
-                    vstore<float, 4>(qbase + (long long)ch * g.s_z, v[k]);
+                    stu(qbase + (long long)ch * g.s_z, voff, v[k]);
                 });
             }
             // slots: non-hybrid 0 rows, 1 cols, 2 z, 3 t ; hybrid 0 ru, 1 cu, 2 rd, 3 cd, 4 zu, 5 zd, 6 tu, 7 td

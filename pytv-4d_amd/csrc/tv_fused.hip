@@ -42,6 +42,7 @@ int tv_cp_fused_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
     if (g->dtype != TV_F32 || g->scheme == TV_CENTRAL || d.nx % 4 != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;
+    if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_FUSED", 0)) return 0;
     return 1;
 }
@@ -88,7 +89,7 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     FusedArgs a{(const float*)x_in, (const float*)x_prev, (const float*)x_next, (float*)q, (const float*)x0, (float*)p,
                 (float*)x_out, (float)sigma_D, (float)(1.0 / lambda), (float)tau, (float)sigma_A,
                 (float)(1.0 / (1.0 + sigma_A)), w0, w1};
-    const bool xw = env_int("TV_FUSED_XW", 0) != 0;
+    const bool xw = env_int("TV_FUSED_XW", 1) != 0;
     int rc = dispatch_fused(g->scheme, d.m, [&]<int S, int M>() -> int {
         if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
         else hipLaunchKernelGGL((k_cp_fused<S, M, false>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
@@ -122,7 +123,7 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau, chunk_lo};
     const long long tiles_x = (d.nx / 4 + 63) / 64, tiles_y = (d.ny + 3) / 4, nch = (d.nz + zc - 1) / zc;
     const long long ngrp = (g->scheme == TV_HYBRID) ? (d.ny + 7) / 8 : (d.ny + 15) / 16;
-    const bool xw = env_int("TV_FUSED_XW", 0) != 0;
+    const bool xw = env_int("TV_FUSED_XW", 1) != 0;
     const long long ncand = xw ? 2ll * ((d.nx + 255) / 256) : 2ll * ((d.nx + 63) / 64);
     const dim3 blk(64, 4, 1);
     const dim3 g0((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)zn);

@@ -206,7 +206,7 @@ FUSED_SHAPES = [(1, 1, 64, 64), (5, 1, 9, 64), (6, 2, 7, 68), (7, 3, 10, 256), (
 
 
 @pytest.mark.parametrize("scheme", ["upwind", "downwind", "hybrid"])
-@pytest.mark.parametrize("zchunk,xw", [("2", "0"), ("16", "0"), ("0", "1"), ("3", "1")])
+@pytest.mark.parametrize("zchunk,xw", [("2", "1"), ("16", "1"), ("0", "0"), ("3", "0")])
 def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, monkeypatch):
     """tv_cp_fused + tv_cp_fixup (q read/written once) against tv_cp_dual + tv_cp_primal and the oracle:
     ragged rows (Ny % 4 != 0), partial wave tiles (Nx % 64 != 0), chunk edges inside the volume."""
