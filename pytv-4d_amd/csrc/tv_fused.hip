@@ -121,7 +121,7 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     const int zb = (int)z_begin, zn = (int)z_count;
     const int chunk_lo = zb / zc, chunk_hi = (zb + zn - 1) / zc;           // chunks intersecting the plane range
     FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau, chunk_lo};
-    const long long tiles_x = (d.nx / 4 + 63) / 64, tiles_y = (d.ny + 3) / 4, nch = (d.nz + zc - 1) / zc;
+    const long long tiles_x = (d.nx / 4 + 63) / 64, tiles_y = (d.ny + 3) / 4;
     const long long ngrp = (g->scheme == TV_HYBRID) ? (d.ny + 7) / 8 : (d.ny + 15) / 16;
     const bool xw = env_int("TV_FUSED_XW", 1) != 0;
     const long long ncand = xw ? 2ll * ((d.nx + 255) / 256) : 2ll * ((d.nx + 63) / 64);

@@ -5,7 +5,6 @@ scikit-image minimises  sum |grad u| + (1 / (2 weight)) |u - f|^2  with forward 
 1/2 |u - f|^2 + weight * TV_upwind(u): the same objective as ``solvers.ChambollePock(f, weight, scheme="upwind")``.
 Its iteration (Chambolle 2004) differs from Chambolle-Pock 2011, so iterates differ; the minimiser is the same.
 """
-import numpy as np
 import torch
 
 from .solvers import ChambollePock

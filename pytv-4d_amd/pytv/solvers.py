@@ -15,7 +15,6 @@ neighbour is exchanged per operator apply (two for the radius-2 kernels) and, fo
 hidden behind the interior planes' kernel.  Scalars (TV, fidelity, CG dots) stay on the device as
 fp64 and are all-reduced there; nothing synchronises with the host inside the loop.
 """
-import numpy as np
 import torch
 
 from . import _native as _nv

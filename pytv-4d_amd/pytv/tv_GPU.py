@@ -10,7 +10,6 @@ Conventions kept: ``mask`` zeroes the caller's array i
 value is always a 0-d numpy array; G (and grad_norms) are numpy unless ``return_pytorch_tensor``;
 grad_norms has zeros replaced by +inf; the sub-gradient uses unit weights in the adjoint.
 """
-import numpy as np
 import torch
 
 from . import _native as _nv

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Achieved bandwidth of every C-ABI operator (device resident, fp32) against its algorithmic bytes.
 usage: python tools/op_bench.py [NzxMxNyxNx] [scheme ...]"""
-import os, sys, time
-import numpy as np
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
-import torch, pytv
+import torch
+import pytv  # noqa: F401  (loads the library)
 from pytv import _native as nv
 shape = tuple(int(v) for v in sys.argv[1].split("x")) if len(sys.argv) > 1 else (64, 8, 1024, 1024)
 schemes = sys.argv[2:] or ["hybrid", "upwind", "downwind", "central"]
