@@ -348,6 +348,35 @@ def test_return_conventions(pytv):
         ops.D_T_hybrid(np.zeros((3, 2, 2, 8, 8)), reg_time=1.0)   # too few channels
 
 
+def test_input_kinds_accepted_like_the_reference(pytv):
+    """CPU torch tensors, non-contiguous views, float16 and integer inputs (type_like contract: float32 stays
+    float32, everything else is computed in float64, pytv/tv_operators_GPU.py:114-129)."""
+    import torch
+    ops = pytv.tv_operators_GPU
+    rng = np.random.default_rng(2)
+    base = rng.standard_normal((4, 2, 10, 24)).astype(np.float32)
+    want = orc.D(base.astype(np.float64), "hybrid", reg_time=1.0)
+    out = ops.D_hybrid(torch.as_tensor(base), reg_time=1.0)                       # CPU torch tensor -> device tensor
+    assert isinstance(out, torch.Tensor) and out.is_cuda and out.dtype == torch.float32
+    np.testing.assert_allclose(out.cpu().numpy(), want, **F32)
+    view = np.asfortranarray(base)                                                 # non-contiguous numpy
+    np.testing.assert_allclose(ops.D_hybrid(view, reg_time=1.0), want, **F32)
+    tview = torch.as_tensor(base).cuda().transpose(2, 3).transpose(2, 3)[:, :, :, ::1]
+    np.testing.assert_allclose(ops.D_hybrid(tview, reg_time=1.0).cpu().numpy(), want, **F32)
+    strided = torch.as_tensor(np.repeat(base, 2, axis=3)).cuda()[:, :, :, ::2]     # genuinely strided device view
+    assert not strided.is_contiguous()
+    np.testing.assert_allclose(ops.D_hybrid(strided, reg_time=1.0).cpu().numpy(), want, **F32)
+    half = base.astype(np.float16)
+    o16 = ops.D_hybrid(half, reg_time=1.0)
+    assert o16.dtype == np.float64
+    np.testing.assert_allclose(o16, orc.D(half.astype(np.float64), "hybrid", reg_time=1.0), **F64)
+    ints = (rng.integers(0, 255, size=(1, 1, 9, 9))).astype(np.uint8)
+    tv, G = pytv.tv_GPU.tv_upwind(ints)
+    wtv, wG = orc.tv(ints.astype(np.float64), "upwind")
+    assert G.dtype == np.float64 and abs(float(tv) - wtv) < 1e-9
+    np.testing.assert_allclose(G, wG, **F64)
+
+
 # ------------------------------------------------------------------------------------------------
 # solvers: Chambolle-Pock / sub-gradient descent / ADMM against the oracle loops
 # ------------------------------------------------------------------------------------------------
