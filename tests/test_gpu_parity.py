@@ -348,6 +348,25 @@ def test_return_conventions(pytv):
         ops.D_T_hybrid(np.zeros((3, 2, 2, 8, 8)), reg_time=1.0)   # too few channels
 
 
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_cp_medium_volume_against_the_openmp_oracle(pytv, scheme):
+    """8.4 Mvox, 25 iterations, marching / one-sweep kernels with their production chunking, against the C / OpenMP
+    oracle in fp64 (itself cross-checked with the NumPy oracle in tests/test_oracle_c.py)."""
+    import torch
+    from oracle import tv_oracle_c as occ
+    shape = (16, 8, 256, 256)
+    x0 = _noisy(shape, 9, np.float32)
+    kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
+    wx, wloss = occ.chambolle_pock(x0.astype(np.float64), 25, 25.0, scheme=scheme, **kw)
+    cp = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 25.0, scheme=scheme, **kw)
+    loss = cp.run(25)
+    np.testing.assert_allclose(loss, wloss, rtol=1e-5)
+    np.testing.assert_allclose(cp.result().cpu().numpy(), wx, rtol=1e-5, atol=2e-3)
+    tv, G = getattr(pytv.tv_GPU, "tv_" + scheme)(x0, **kw)
+    d = occ.D(x0.astype(np.float64), scheme, **kw)
+    assert abs(float(tv) - np.sqrt((d ** 2).sum(axis=1)).sum()) <= 1e-6 * float(tv)
+
+
 def test_input_kinds_accepted_like_the_reference(pytv):
     """CPU torch tensors, non-contiguous views, float16 and integer inputs (type_like contract: float32 stays
     float32, everything else is computed in float64, pytv/tv_operators_GPU.py:114-129)."""
