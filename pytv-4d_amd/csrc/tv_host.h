@@ -210,6 +210,9 @@ int D_norms(const tv_geom* g, const DG& d, const void* x, const void* xp, const 
 int subgrad_pass2(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st,
                   const float* norms_ext, float* G);
 bool subgrad_pass2_ok(const tv_geom* g, const DG& d);
+// x + rho D^T D x (radius-1 schemes, M <= 8): LIGHT marching kernel with the hybrid stencil; two-plane halo buffers
+int D_normal_op(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
+                float* out, float rho, double* partials);
 int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
               float* z, float* u, float thresh, double* partials);
 int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb, float* out);

@@ -771,7 +771,11 @@ int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out});
-    // (a plane-marching variant of this operator was measured: 1.80 vs 1.65 ms on 64x8x1024x1024 -- not kept)
+    if (g->scheme != TV_CENTRAL && d.m <= 8 && march_ok(g, d, vec) && !env_int("TV_NO_MARCH_NORMAL", 0)) {
+        long long nb;
+        if (int rc = tvm::D_normal_op(g, d, x, x_prev, x_next, st, &nb, (float*)out, (float)rho, (double*)ws)) return rc;
+        return reduce_partials((double*)ws, nb, nmax, dot, st);
+    }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lg = launch_cfg(d, V, d.nz);
         if constexpr (S != CENTRAL) {

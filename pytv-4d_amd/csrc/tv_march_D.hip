@@ -52,4 +52,21 @@ int D_norms(const tv_geom* g, const DG& d, const void* x, const void* xp, const 
         return 0;
     });
 }
+int D_normal_op(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
+                float* out, float rho, double* partials) {
+    const int zc = march_zchunk(d);
+    const LC lc = march_cfg(d, zc);
+    *nb = lc.nblocks;
+    const WT<float> w = make_w<float>(g);
+    NormalEpi<HYBRID, float, 4> epi{out, rho, w.wz, w.wt, w.sf, d.mask, partials};
+    return dispatch_sm(TV_HYBRID, d.m, [&]<int S, int M>() -> int {
+        if constexpr (S == HYBRID && M <= 8) {
+            hipLaunchKernelGGL((k_D_march<HYBRID, M, NormalEpi<HYBRID, float, 4>, true>), lc.grid, lc.block, 0, st, d, w,
+                               (const float*)x, (const float*)xp, (const float*)xn, zc, epi, 2, 0, -1);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        return fail(TV_E_ARG, "marching normal operator: M > 8");
+    });
+}
 }  // namespace tvm

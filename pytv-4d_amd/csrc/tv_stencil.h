@@ -246,6 +246,40 @@ template <int S, typename T, int V> struct AdmmZU {
     }
 };
 
+// out = x + rho * D^T D x from the HYBRID channel slots (D^T D is the same operator for upwind, downwind and
+// hybrid: sum_a w_a^2 (bwd_a - fwd_a)); the slots hold s*w*fwd / s*w*bwd with s = 1/sqrt(2).  Marching path only.
+template <int S, typename T, int V> struct NormalEpi {
+    static constexpr bool REDUCES = true;
+    static_assert(S == HYBRID, "evaluated with the hybrid channel slots");
+    T* out;
+    T rho, wz, wt, sf;
+    const uint8_t* mask;
+    double* partials;
+    __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8], const Vec<T, V>& xc) const {
+        const T inv_s = T(1.4142135623730950488);
+        Vec<T, V> r = (o[2] - o[0]) + (o[3] - o[1]);
+        if (g.za) r = r + wz * (o[5] - o[4]);
+        if (g.ta) {
+            Vec<T, V> rt = wt * (o[7] - o[6]);                     // the slots already carry one mask factor
+            if (mask != nullptr) {
+                const uint8_t* mp = mask + (long long)c.y * g.nx + c.col0;
+#pragma unroll
+                for (int i = 0; i < V; ++i) rt.v[i] = mp[i] ? rt.v[i] * sf : rt.v[i];
+            }
+            r = r + rt;
+        }
+        Vec<T, V> ov;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            ov.v[i] = xc.v[i] + rho * (inv_s * r.v[i]);
+            acc += (double)xc.v[i] * (double)ov.v[i];
+        }
+        vstore<T, V>(out + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, ov);
+        return acc;
+    }
+};
+
 // =============================================================================================
 // sub-gradient of one site (radius-1 schemes):  with f = forward, b = backward difference at the site,
 //   D up-channel at p-e equals (w b)(p), D down-channel at p+e equals (w f)(p), so
