@@ -99,8 +99,8 @@ int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* 
 int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x,
                  const void* x0, void* p, double tau, double sigma_A, double* fid, void* ws, void* stream);
 
-/* One-sweep form of the same iteration for the radius-1 schemes (upwind, downwind, hybrid; fp32,
- * nx % 4 == 0, m in {1,2,3,4,8}): q is read and written ONCE per iteration.  x is ping-ponged.
+/* One-sweep form of the same iteration (all four schemes; fp32, nx % 4 == 0, nx >= 64,
+ * m in {1,2,3,4,8}): q is read and written ONCE per iteration.  x is ping-ponged.
  *   tv_cp_fused_supported : 1 if this geometry can take the one-sweep path, else 0
  *   tv_cp_fused           : q <- proj(q + sigma_D D x_in); p <- (p + sigma_A (x_in - x0)) / (1 + sigma_A);
  *                           x_out <- x_in - tau p - tau D^T q   EXCEPT the adjoint terms that cross a

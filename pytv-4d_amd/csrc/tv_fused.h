@@ -1,5 +1,5 @@
-// tv_fused.h -- ONE-SWEEP Chambolle-Pock iteration (README.md:145-157 of the reference) for the
-// radius-1 schemes (upwind, downwind, hybrid), fp32, 16-byte lanes.
+// tv_fused.h -- ONE-SWEEP Chambolle-Pock iteration (README.md:145-157 of the reference) for all four schemes,
+// fp32, 16-byte lanes.
 //
 // The two-kernel form (tv_cp_dual + tv_cp_primal) reads the dual variable q twice and writes it once
 // per iteration: 30 words/voxel at Nd = 8.  Here the primal update of plane z-1 is done in the same
@@ -50,9 +50,10 @@ __device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk, int c
 }
 
 // does the sweep leave a term of this site-vector to the fix-up kernel?  (shared by both kernels)
+// (central: the adjoint of every channel reaches both ways, so it counts as "up" and "down" here)
 template <int S, bool XW>
 __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, int col0, int zchunk) {
-    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND);
     constexpr int CM = XW ? 255 : 63;          // column period of the tiles whose edges are left to the fix-up
     bool f = false;
     // rows: every wave tile (4 rows); columns: only the 256-column BLOCK tile edges -- the four waves
@@ -110,16 +111,19 @@ struct FusedArgs {
 // XW: the four waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
 template <int S, int M, bool XW>
 __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk, int chunk0) {
-    static_assert(S != CENTRAL, "central has a radius-2 adjoint: two-kernel path");
     __shared__ double sm[16];
     const FusedCoord c = fused_coord(g, zchunk, chunk0);
     const unsigned voff = (unsigned)c.inpl * 4u;          // byte offset of this lane's vector inside a frame (frames <= 2^30 px)
     const unsigned row_bytes = (unsigned)g.nx * 4u;
-    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    // UP: some channel's adjoint takes y^(p-e) (forward differences; central: every channel); DN: ... y^(p+e).
+    // CEN: central -- ONE channel per axis plays both roles, has no own-site term and is defined on interior
+    // points only; its two-point z / t axes (z_fwd / t_fwd) behave like upwind axes.
+    constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
     constexpr bool NEXT = UP, PREV = DN;       // forward differences need x(+e), backward x(-e)
+    const bool z_fwd = CEN && g.z_two, t_fwd = CEN && g.t_two;
     const F4 zero = vsplat<float, 4>(0.f);
     const F4 mf = g.ta ? mask_factor<float, 4>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<float, 4>(1.f);
-    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : 1.f;
+    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : (CEN ? 0.5f : 1.f);
     double acc_tv = 0.0, acc_fid = 0.0;
     // x planes z (C) and z-1 (P) live in registers; the adjoint accumulators R (plane z-1 waiting
     // for its z+1 term) and the carried z-up terms U live in LDS, private per thread ([frame][thread]:
@@ -279,18 +283,20 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             // channel where it has a previous one; everything else counts as zero
             F4 qru = zero, qrd = zero, qcu = zero, qcd = zero, qzu = zero, qzd = zero, qtu = zero, qtd = zero;
             if (UP) {
-                if (c.ok && c.y + 1 < g.ny) qru = v[k_ru];
+                if (c.ok && c.y + 1 < g.ny && (!CEN || c.y > 0)) qru = v[k_ru];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) qcu.v[i] = (c.ok && c.col0 + i < g.nx - 1) ? v[k_cu].v[i] : 0.f;
-                if (g.za && c.ok && gz + 1 < g.nzg) qzu = w.wz * v[k_zu];
-                if (g.ta && c.ok && t + 1 < M) qtu = (w.wt * v[k_tu]) * mf;
+                for (int i = 0; i < 4; ++i)
+                    qcu.v[i] = (c.ok && c.col0 + i < g.nx - 1 && (!CEN || c.col0 + i > 0)) ? v[k_cu].v[i] : 0.f;
+                if (g.za && c.ok && gz + 1 < g.nzg && (!CEN || z_fwd || gz > 0)) qzu = w.wz * v[k_zu];
+                if (g.ta && c.ok && t + 1 < M && (!CEN || t_fwd || t > 0)) qtu = (w.wt * v[k_tu]) * mf;
             }
             if (DN) {
-                if (c.ok && c.y > 0) qrd = v[k_rd];
+                if (c.ok && c.y > 0 && (!CEN || c.y + 1 < g.ny)) qrd = v[k_rd];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) qcd.v[i] = (c.ok && c.col0 + i > 0) ? v[k_cd].v[i] : 0.f;
-                if (g.za && c.ok && gz > 0) qzd = w.wz * v[k_zd];
-                if (g.ta && c.ok && t > 0) qtd = (w.wt * v[k_td]) * mf;
+                for (int i = 0; i < 4; ++i)
+                    qcd.v[i] = (c.ok && c.col0 + i > 0 && (!CEN || c.col0 + i < g.nx - 1)) ? v[k_cd].v[i] : 0.f;
+                if (g.za && c.ok && gz > 0 && (!CEN || (!z_fwd && gz + 1 < g.nzg))) qzd = w.wz * v[k_zd];
+                if (g.ta && c.ok && t > 0 && (!CEN || (!t_fwd && t + 1 < M))) qtd = (w.wt * v[k_td]) * mf;
             }
             // ------------------------------------------------ lagged primal update of plane z-1
             if (z > c.zs) {
@@ -301,7 +307,11 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             // ------------------------------------------------ adjoint accumulator of plane z
             F4 r = zero;
             if (UP) {
-                r = r - qru - qcu - qzu - qtu;
+                if (!CEN) r = r - qru - qcu - qzu - qtu;              // own-site terms (central has none ...
+                else {
+                    if (z_fwd) r = r - qzu;                           // ... except on its two-point axes)
+                    if (t_fwd) r = r - qtu;
+                }
                 const F4 above = shfl_up16(qru);                      // q'_rowup of the row above
                 if (c.row > 0) r = r + above;
                 const float lft = __shfl_up(qcu.v[3], 1, 64);         // q'_colup one column to the left
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
                 ut_prev = qtu;
             }
             if (DN) {
-                r = r + qrd + qcd + qzd + qtd;
+                if (!CEN) r = r + qrd + qcd + qzd + qtd;
                 const F4 below = shfl_down16(qrd);                    // q'_rowdown of the row below
                 if (c.row < 3) r = r - below;
                 const float rgt = __shfl_down(qcd.v[0], 1, 64);       // q'_coldown one column to the right
@@ -368,33 +378,35 @@ struct FixupArgs {
 template <int S, bool XW>
 __device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, const FixupArgs& a, int zchunk, int zl, int t, int y,
                                              int col0) {
-    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
     if (!fused_needs_fixup<S, XW>(g, zl, y, col0, zchunk)) return 0.0;
     constexpr int CM = XW ? 255 : 63;
     const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
     const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
+    const bool z_fwd = CEN && g.z_two;
     const long long inpl = (long long)t * g.s_t + (long long)y * g.nx + col0;
     const float* qb = a.q + (long long)zl * g.s_dz + inpl;
     const F4 zero = vsplat<float, 4>(0.f);
     F4 m = zero;
-    if (UP && (y & 3) == 0 && y >= 1) m = m + vload<float, 4>(qb + (long long)c_ru * g.s_z - g.nx);
-    if (DN && (y & 3) == 3 && y <= g.ny - 2) m = m - vload<float, 4>(qb + (long long)c_rd * g.s_z + g.nx);
-    if (UP && (col0 & CM) == 0 && col0 >= 1) m.v[0] += qb[(long long)c_cu * g.s_z - 1];
-    if (DN && (col0 & CM) == CM - 3 && col0 + 4 <= g.nx - 1) m.v[3] -= qb[(long long)c_cd * g.s_z + 4];
+    // a missing term counts only where the neighbour's channel is defined (central: interior points of the axis)
+    if (UP && (y & 3) == 0 && y >= (CEN ? 2 : 1)) m = m + vload<float, 4>(qb + (long long)c_ru * g.s_z - g.nx);
+    if (DN && (y & 3) == 3 && y <= g.ny - (CEN ? 3 : 2)) m = m - vload<float, 4>(qb + (long long)c_rd * g.s_z + g.nx);
+    if (UP && (col0 & CM) == 0 && col0 >= (CEN ? 2 : 1)) m.v[0] += qb[(long long)c_cu * g.s_z - 1];
+    if (DN && (col0 & CM) == CM - 3 && col0 + 4 <= g.nx - (CEN ? 2 : 1)) m.v[3] -= qb[(long long)c_cd * g.s_z + 4];
     if (g.za) {
         const int gz = g.z0 + zl;
         const int zs = (zl / zchunk) * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
-        if (UP && zl == zs && gz >= 1) {
+        if (UP && zl == zs && gz >= ((CEN && !z_fwd) ? 2 : 1)) {
             const F4 u = (zl >= 1) ? vload<float, 4>(qb + (long long)c_zu * g.s_z - g.s_dz) : vload<float, 4>(a.qp + inpl);
             m = m + w.wz * u;
         }
-        if (DN && zl == ze - 1 && gz <= g.nzg - 2) {
+        if (DN && !z_fwd && zl == ze - 1 && gz <= g.nzg - (CEN ? 3 : 2)) {
             const F4 d = (zl + 1 < g.nz) ? vload<float, 4>(qb + (long long)c_zd * g.s_z + g.s_dz) : vload<float, 4>(a.qn + inpl);
             m = m - w.wz * d;
         }
     }
-    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : 1.f;
+    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : (CEN ? 0.5f : 1.f);
     const long long off = (long long)zl * g.s_z + inpl;
     const F4 xv = vload<float, 4>(a.x_out + off), x0v = vload<float, 4>(a.x0 + off);
     F4 xo;
@@ -411,12 +423,12 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, co
 
 // is row y one of the rows whose every vector misses a row term ("fix-up rows")?
 template <int S> __device__ __forceinline__ bool is_fix_row(const DG& g, int y) {
-    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND);
     return (UP && (y & 3) == 0 && y >= 1) || (DN && (y & 3) == 3 && y <= g.ny - 2);
 }
 // is local plane zl a z-chunk edge plane with a missing z term?
 template <int S> __device__ __forceinline__ bool is_fix_plane(const DG& g, int zl, int zchunk) {
-    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND);
     if (!g.za) return false;
     const int gz = g.z0 + zl;
     const int zs = (zl / zchunk) * zchunk;
@@ -431,10 +443,10 @@ template <int S> __device__ __forceinline__ bool is_fix_plane(const DG& g, int z
 // grid: CLS 0 (tiles_x * row groups, m, nz); CLS 1 (tiles_x * tiles_y, m, 2 * nchunks); CLS 2 (ceil(cands/256), m, nz)
 template <int S, int CLS, bool XW>
 __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a, int zchunk, int zb, int zn, double* partials) {
+    // (central row groups are laid out like hybrid ones: both the top and the bottom row of every wave tile)
     // the call covers local planes [zb, zb + zn): classes 0 and 2 have grid z = zn; class 1 has two grid-z
     // slots (first / last plane) per z-chunk intersecting the range, starting at chunk a.chunk0
     __shared__ double sm[16];
-    constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
     const int nxv = g.nx / 4;
     const int tiles_x = (nxv + 63) / 64;
     double acc = 0.0;
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
         const int bx = (int)blockIdx.x % tiles_x, grp = (int)blockIdx.x / tiles_x;
         const int ty = (int)threadIdx.y;
         int y;
-        if (S == HYBRID) y = grp * 8 + ((ty & 1) ? 3 : 0) + ((ty & 2) ? 4 : 0);      // rows 8k + {0, 3, 4, 7}
+        if (S == HYBRID || S == CENTRAL) y = grp * 8 + ((ty & 1) ? 3 : 0) + ((ty & 2) ? 4 : 0);      // rows 8k + {0, 3, 4, 7}
         else y = grp * 16 + 4 * ty + (S == DOWNWIND ? 3 : 0);                         // rows 16k + 4j (+3)
         const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
         if (col0 < g.nx && y < g.ny && is_fix_row<S>(g, y))

@@ -16,7 +16,7 @@ template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
             case 8: return f.template operator()<SC, 8>();         \
         }                                                          \
         break;
-    switch (scheme) { TV_CASE_F(0) TV_CASE_F(1) TV_CASE_F(3) }
+    switch (scheme) { TV_CASE_F(0) TV_CASE_F(1) TV_CASE_F(2) TV_CASE_F(3) }
 #undef TV_CASE_F
     return fail(TV_E_ARG, "unsupported (scheme, M) for the one-sweep path");
 }
@@ -28,10 +28,14 @@ int subgrad_pass2(const tv_geom* g, const DG& d, const void* x, const void* xp, 
     const int zc = march_zchunk(d);
     const LC lc = march_cfg(d, zc);
     return dispatch_fused(g->scheme, d.m, [&]<int S, int M>() -> int {
-        hipLaunchKernelGGL((k_subgrad_march<S, M>), lc.grid, lc.block, 0, st, d, make_w<float>(g), (const float*)x, (const float*)xp,
-                           (const float*)xn, norms_ext, G, zc);
-        HIP_TRY(hipGetLastError());
-        return 0;
+        if constexpr (S != CENTRAL) {
+            hipLaunchKernelGGL((k_subgrad_march<S, M>), lc.grid, lc.block, 0, st, d, make_w<float>(g), (const float*)x,
+                               (const float*)xp, (const float*)xn, norms_ext, G, zc);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        } else {
+            return fail(TV_E_ARG, "central: radius-2 gather, not a marching kernel");
+        }
     });
 }
 }  // namespace tvm
@@ -41,7 +45,7 @@ extern "C" {
 int tv_cp_fused_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
-    if (g->dtype != TV_F32 || g->scheme == TV_CENTRAL || d.nx % 4 != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;
+    if (g->dtype != TV_F32 || d.nx % 4 != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_FUSED", 0)) return 0;
     return 1;
@@ -122,7 +126,7 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     const int chunk_lo = zb / zc, chunk_hi = (zb + zn - 1) / zc;           // chunks intersecting the plane range
     FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau, chunk_lo};
     const long long tiles_x = (d.nx / 4 + 63) / 64, tiles_y = (d.ny + 3) / 4;
-    const long long ngrp = (g->scheme == TV_HYBRID) ? (d.ny + 7) / 8 : (d.ny + 15) / 16;
+    const long long ngrp = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL) ? (d.ny + 7) / 8 : (d.ny + 15) / 16;
     const bool xw = env_int("TV_FUSED_XW", 1) != 0;
     const long long ncand = xw ? 2ll * ((d.nx + 255) / 256) : 2ll * ((d.nx + 63) / 64);
     const dim3 blk(64, 4, 1);
@@ -144,6 +148,7 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     switch (g->scheme) {
         case TV_UPWIND: rc = xw ? launch.template operator()<UPWIND, true>() : launch.template operator()<UPWIND, false>(); break;
         case TV_DOWNWIND: rc = xw ? launch.template operator()<DOWNWIND, true>() : launch.template operator()<DOWNWIND, false>(); break;
+        case TV_CENTRAL: rc = xw ? launch.template operator()<CENTRAL, true>() : launch.template operator()<CENTRAL, false>(); break;
         default: rc = xw ? launch.template operator()<HYBRID, true>() : launch.template operator()<HYBRID, false>(); break;
     }
     if (rc) return rc;

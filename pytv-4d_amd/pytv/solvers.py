@@ -118,7 +118,7 @@ class ChambollePock(_SlabProblem):
         self.fused = bool(fused)
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
             raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry "
-                             "(needs fp32, Nx % 4 == 0, M in {1,2,3,4,8}, a non-central scheme)")
+                             "(needs fp32, Nx % 4 == 0, Nx >= 64, M in {1,2,3,4,8})")
         self.x_alt = torch.empty_like(self.x) if self.fused else None      # ping-pong partner of x
         self.overlap = bool(overlap) and sh and self.slab.nz >= 3 and not self.fused
         self.hist = None

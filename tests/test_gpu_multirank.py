@@ -89,7 +89,7 @@ def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, z
         np.testing.assert_allclose(ret[r]["cp_x"], wx[z0:z0 + nz], rtol=1e-5, atol=2e-3, err_msg="rank %d" % r)
         np.testing.assert_allclose(ret[r]["cp2_loss"], wloss, rtol=1e-5, err_msg="rank %d (default path)" % r)
         np.testing.assert_allclose(ret[r]["cp2_x"], wx[z0:z0 + nz], rtol=1e-5, atol=2e-3, err_msg="rank %d (default path)" % r)
-    if scheme != "central" and shape[-1] % 4 == 0 and shape[-1] >= 64:
+    if shape[-1] % 4 == 0 and shape[-1] >= 64:
         assert all(ret[r]["cp2_fused"] for r in range(world))
         if overlap and zchunk in ("1", "2"):
             assert all(ret[r]["cp2_overlap"] for r in range(world))     # interior-first one-sweep path exercised

@@ -202,10 +202,11 @@ def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, mo
         np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=1e-4, atol=2e-3)
 
 
-FUSED_SHAPES = [(1, 1, 64, 64), (5, 1, 9, 64), (6, 2, 7, 68), (7, 3, 10, 256), (9, 4, 5, 132), (5, 8, 6, 320), (20, 8, 4, 64)]
+FUSED_SHAPES = [(1, 1, 64, 64), (5, 1, 9, 64), (6, 2, 7, 68), (7, 3, 10, 256), (9, 4, 5, 132), (5, 8, 6, 320), (20, 8, 4, 64),
+                (2, 3, 6, 64), (3, 2, 3, 72)]
 
 
-@pytest.mark.parametrize("scheme", ["upwind", "downwind", "hybrid"])
+@pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("zchunk,xw", [("2", "1"), ("16", "1"), ("0", "0"), ("3", "0")])
 def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, monkeypatch):
     """tv_cp_fused + tv_cp_fixup (q read/written once) against tv_cp_dual + tv_cp_primal and the oracle:
@@ -233,8 +234,8 @@ def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, 
             np.testing.assert_allclose(a.p.cpu().numpy(), b.p.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
     g = nv.Geometry((4, 5, 8, 64), "hybrid", torch.float32, "cuda")
     assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # M = 5 is not instantiated
-    g = nv.Geometry((4, 4, 8, 64), "central", torch.float32, "cuda")
-    assert nv.lib().tv_cp_fused_supported(g.ref) == 0
+    g = nv.Geometry((4, 4, 8, 64), "central", torch.float64, "cuda")
+    assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # fp32 only
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)

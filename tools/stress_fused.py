@@ -12,7 +12,7 @@ shapes = [(7, 8, 9, 320), (5, 3, 13, 260), (33, 8, 64, 512), (4, 4, 6, 1028), (9
 bad = 0
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     for shape in shapes:
-        for scheme in ("hybrid", "upwind", "downwind"):
+        for scheme in ("hybrid", "upwind", "downwind", "central"):
             x0 = torch.as_tensor((50 * rng.random(shape)).astype(np.float32)).cuda()
             a = pytv.solvers.ChambollePock(x0, 5.0, scheme=scheme, reg_time=0.7)
             b = pytv.solvers.ChambollePock(x0, 5.0, scheme=scheme, reg_time=0.7, fused=False)
