@@ -90,6 +90,13 @@ int tv_l21(const tv_geom* g, const void* d, int32_t nd, void* norms, double* res
 int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* x_next,
                void* G, void* norms_ext, double* tv, void* ws, void* stream);
 
+/* The same TV value and sub-gradient in ONE pass over x (1/|Dx| never leaves the chip): upwind, downwind and
+ * hybrid schemes, fp32, Nx % 4 == 0, M in {1,2,3,4,8}, 16-byte aligned arrays (tv_subgrad_fused_supported).  Use it
+ * when the per-voxel norms are not wanted (return_grad_norms=False, pytv/tv_GPU.py:47).  Halos as for tv_subgrad. */
+int tv_subgrad_fused_supported(const tv_geom* g);
+int tv_subgrad_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, double* tv,
+                     void* ws, void* stream);
+
 /* ---- fused Chambolle-Pock inner loop (README.md:141-157) ----------------------------------- */
 /* q <- proj_{|.|_2 <= lambda}(q + sigma_D * D x); *tv (device fp64) = |D x|_{2,1} of local planes. */
 int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* q,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build libpytv4d_hip.so (gfx950) in-tree with hipcc.  No cmake, no JIT cache: the .so sits next
-to the Python package so that it travels with the repository snapshot to the GPU box.  The three
+to the Python package so that it travels with the repository snapshot to the GPU box.  The
 translation units are compiled in parallel and linked with hipcc."""
 import os
 import subprocess
@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip", "tv_fused.hip"]
-HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h", "tv_fused.h"]
+UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip", "tv_fused.hip", "tv_subgrad.hip"]
+HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h", "tv_fused.h", "tv_subgrad.h"]
 DEPS = [os.path.join(CSRC, f) for f in UNITS + HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "pytv4d.h")]
 OUT = os.path.join(HERE, "pytv", "libpytv4d_hip.so")
 OBJDIR = os.path.join(HERE, "build")

@@ -75,8 +75,11 @@ __device__ __forceinline__ void col_neighbours(const V4& v, const float* p, bool
 // visit (ghost planes outside [0, nz) come from the halo buffers)
 // LIGHT: for epilogues with little traffic per site (StoreD, NormEpi): single-buffered tile (two barriers per
 // plane, 32 KiB at M = 8 -> up to 5 blocks/CU) and a register cap of 168 so that 3 waves/SIMD hide the latency
-template <int S, int M, typename Epi, bool LIGHT = false>
-__global__ __launch_bounds__(256, LIGHT ? 3 : 1) void k_D_march(DG g, WT<float> w, const float* __restrict__ x, const float* __restrict__ xp,
+// PF: 1 = all M frames of plane z+1 are requested at the top of the z step (M independent loads in flight per wave
+// instead of one exposed latency per frame: the epilogue's stores may alias x as far as the compiler knows, so it never
+// hoists the next frame's load above them); 2 = the halo row of the first / last tile row as well
+template <int S, int M, typename Epi, bool LIGHT = false, int PF = 0>
+__global__ __launch_bounds__(256, LIGHT ? 3 : (PF ? 2 : 1)) void k_D_march(DG g, WT<float> w, const float* __restrict__ x, const float* __restrict__ xp,
                                                  const float* __restrict__ xn, int zchunk, Epi epi, int hp = 1, int z_first = 0,
                                                  int z_end = -1) {
     __shared__ V4 tile[LIGHT ? 1 : 2][M][4][64];   // double-buffered: one barrier per z step
@@ -98,22 +101,36 @@ __global__ __launch_bounds__(256, LIGHT ? 3 : 1) void k_D_march(DG g, WT<float> 
         }
     }
     for (int z = c.zs; z < c.ze; ++z) {
-        // publish plane z for the row neighbours
-        const int buf = LIGHT ? 0 : ((z - c.zs) & 1);
-#pragma unroll
-        for (int t = 0; t < M; ++t) tile[buf][t][c.ty][c.lane] = C[t];
-        __syncthreads();
         const float* pc = zplane<float>(g, x, xp, xn, hp, z);
         const float* pn = zplane<float>(g, x, xp, xn, hp, z + 1);
         const bool has_pz = PREV && g.za && (g.z0 + z > 0);
         const bool has_nz = NEXT && g.za && (pn != nullptr);
         // the next plane is needed as a z neighbour and/or as the next centre
         const bool load_next = (pn != nullptr) && c.ok && (has_nz || (z + 1 < c.ze));
+        V4 Nn[PF ? M : 1], H[PF == 2 ? M : 1];
+        const bool halo_up = PREV && (c.ty == 0) && c.ok && (c.y > 0);
+        const bool halo_dn = NEXT && (c.ty == 3) && c.ok && (c.y + 1 < g.ny);
+        if (PF) {
+#pragma unroll
+            for (int t = 0; t < M; ++t) Nn[t] = load_next ? vload<float, 4>(pn + (long long)t * g.s_t + c.inpl) : zero;
+        }
+        if (PF == 2) {
+#pragma unroll
+            for (int t = 0; t < M; ++t)
+                H[t] = (halo_up || halo_dn) ? vload<float, 4>(pc + (long long)t * g.s_t + c.inpl + (halo_up ? -(long long)g.nx : (long long)g.nx)) : zero;
+        }
+        // publish plane z for the row neighbours
+        const int buf = LIGHT ? 0 : ((z - c.zs) & 1);
+#pragma unroll
+        for (int t = 0; t < M; ++t) tile[buf][t][c.ty][c.lane] = C[t];
+        __syncthreads();
         V4 cold = zero;                   // plane-z value of frame t-1 (C[t-1] is already overwritten)
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const long long off = (long long)t * g.s_t + c.inpl;
-            const V4 N = load_next ? vload<float, 4>(pn + off) : zero;
+            V4 N;
+            if constexpr (PF != 0) N = Nn[t];
+            else N = load_next ? vload<float, 4>(pn + off) : zero;
             XN<float, 4> n;
             n.c = C[t];
             n.col0 = c.col0;
@@ -122,6 +139,7 @@ __global__ __launch_bounds__(256, LIGHT ? 3 : 1) void k_D_march(DG g, WT<float> 
             if (NEXT) {
                 n.h_nr = c.ok && (c.y + 1 < g.ny);
                 if (c.ty < 3) n.nr = tile[buf][t][c.ty + 1][c.lane];
+                else if (PF == 2) n.nr = H[t];
                 else if (n.h_nr) n.nr = vload<float, 4>(pc + off + g.nx);
                 n.h_nz = has_nz;
                 n.nz = N;
@@ -130,6 +148,7 @@ __global__ __launch_bounds__(256, LIGHT ? 3 : 1) void k_D_march(DG g, WT<float> 
             if (PREV) {
                 n.h_pr = c.ok && (c.y > 0);
                 if (c.ty > 0) n.pr = tile[buf][t][c.ty - 1][c.lane];
+                else if (PF == 2) n.pr = H[t];
                 else if (n.h_pr) n.pr = vload<float, 4>(pc + off - g.nx);
                 n.h_pz = has_pz;
                 n.pz = P[t];

@@ -15,6 +15,8 @@ neighbour is exchanged per operator apply (two for the radius-2 kernels) and, fo
 hidden behind the interior planes' kernel.  Scalars (TV, fidelity, CG dots) stay on the device as
 fp64 and are all-reduced there; nothing synchronises with the host inside the loop.
 """
+import os
+
 import torch
 
 from . import _native as _nv
@@ -111,7 +113,6 @@ class ChambollePock(_SlabProblem):
             # one-sweep kernel where supported -- except on small planes (z / t neighbours stay L2-resident there and
             # the one-site-per-thread kernel pair is faster: 840 vs 778 it/s on 256x1x512x512); same threshold and
             # override (TV_MARCH_MIN_PLANE_KB) as the marching kernels
-            import os
             min_plane = int(os.environ.get("TV_MARCH_MIN_PLANE_KB", "4096")) * 1024
             plane_bytes = self.geo.plane * self.x0.element_size()
             fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) and plane_bytes >= min_plane
@@ -344,13 +345,18 @@ class SubgradientDescent(_SlabProblem):
     """README.md:118-124 with the state on the GPU: x <- x - step ((x - x0) + reg * G(x))."""
 
     def __init__(self, x0, regularization, step_size, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None):
+                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None):
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.reg, self.step_size = float(regularization), float(step_size)
         self.x = self.x0.clone()
         nz, m, ny, nx = self.x0.shape
         self.G = torch.empty_like(self.x0)
-        self.norms_ext = torch.empty((nz + 2, m, ny, nx), dtype=self.dtype, device=self.device)
+        if one_pass is None:      # TV + G in one pass over x where the geometry allows (tv_subgrad_fused)
+            min_plane = int(os.environ.get("TV_MARCH_MIN_PLANE_KB", "4096")) * 1024
+            one_pass = bool(self.lib.tv_subgrad_fused_supported(self.geo.ref)) and \
+                self.geo.plane * self.x0.element_size() >= min_plane
+        self.one_pass = bool(one_pass)
+        self.norms_ext = None if self.one_pass else torch.empty((nz + 2, m, ny, nx), dtype=self.dtype, device=self.device)
         self.ws = self.geo.workspace()
         self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
         sh = self.plan.on
@@ -364,8 +370,12 @@ class SubgradientDescent(_SlabProblem):
         nz, s, x = self.slab.nz, self.slab, self.x
         s.wait(self.plan.exchange_image2(x, self.xh_prev, self.xh_next))
         g = self.geo
-        _nv.check(self.lib.tv_subgrad(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.G),
-                                      _nv.ptr(self.norms_ext), out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        if self.one_pass:
+            _nv.check(self.lib.tv_subgrad_fused(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.G),
+                                                out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        else:
+            _nv.check(self.lib.tv_subgrad(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.G),
+                                          _nv.ptr(self.norms_ext), out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
         _nv.check(self.lib.tv_subgrad_step(g.ref, _nv.ptr(x), _nv.ptr(self.x0), _nv.ptr(self.G), self.step_size, self.reg,
                                            out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
 

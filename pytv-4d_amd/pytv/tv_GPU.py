@@ -4,12 +4,16 @@
 (pytv/tv_GPU.py:47,142,217,290).  The reference materialises D(img) (Nd x the image), then runs
 3..14 sliced ``G[...] += +-D/norm`` updates; here one fused HIP pass writes |D img| per voxel and the
 TV partial sums, a second one gathers G straight from ``img`` and the norms -- the gradient array is
-never stored (C-ABI ``tv_subgrad``, include/pytv4d.h).
+never stored (C-ABI ``tv_subgrad``, include/pytv4d.h).  When the norms are not asked for
+(``return_grad_norms=False``) and the geometry allows, TV and G come from a single pass over ``img``
+(``tv_subgrad_fused``): the norms never leave the chip either.
 
 Conventions kept: ``mask`` zeroes the caller's array in place; the TV
 value is always a 0-d numpy array; G (and grad_norms) are numpy unless ``return_pytorch_tensor``;
 grad_norms has zeros replaced by +inf; the sub-gradient uses unit weights in the adjoint.
 """
+import os
+
 import torch
 
 from . import _native as _nv
@@ -23,13 +27,31 @@ def _has_mask(mask):
     return mask is not None and not isinstance(mask, bool) and len(mask) > 0
 
 
-def tv_subgradient_device(x, scheme, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0):
+def one_pass_ok(geo, itemsize):
+    """Use the one-pass kernel (``tv_subgrad_fused``)?  Supported geometry, and planes large enough for the
+    plane-marching kernels to pay (same threshold and override, TV_MARCH_MIN_PLANE_KB, as the solvers)."""
+    min_plane = int(os.environ.get("TV_MARCH_MIN_PLANE_KB", "4096")) * 1024
+    return bool(_nv.lib().tv_subgrad_fused_supported(geo.ref)) and geo.plane * itemsize >= min_plane
+
+
+def tv_subgradient_device(x, scheme, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0,
+                          want_norms=True, one_pass=None):
     """Device-resident core: x is a contiguous fp32/fp64 device tensor (Nz, M, Ny, Nx).
     Returns (tv 0-d fp64 device tensor, G, inverse-norm view 1/|Dx| with 0 where |Dx| == 0) without any
-    host synchronisation."""
+    host synchronisation.  With ``want_norms=False`` the third item is None and, where the geometry allows,
+    TV and G come from ONE pass over x (``one_pass``: None = automatic, True / False = force)."""
     geo = _nv.Geometry(tuple(x.shape), scheme, x.dtype, x.device, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
     nz, m, ny, nx = geo.shape
     G = torch.empty_like(x)
+    if one_pass is None:
+        one_pass = (not want_norms) and one_pass_ok(geo, x.element_size())
+    if one_pass:
+        if want_norms:
+            raise ValueError("the one-pass kernel does not produce the per-voxel norms")
+        tv = geo.scalar()
+        _nv.check(_nv.lib().tv_subgrad_fused(geo.ref, _nv.ptr(x), None, None, _nv.ptr(G), _nv.ptr(tv),
+                                             _nv.ptr(geo.workspace()), _nv.current_stream(x.device)))
+        return tv, G, None
     norms_ext = torch.empty((nz + 2, m, ny, nx), dtype=x.dtype, device=x.device)
     tv = geo.scalar()
     _nv.check(_nv.lib().tv_subgrad(geo.ref, _nv.ptr(x), None, None, _nv.ptr(G), _nv.ptr(norms_ext), _nv.ptr(tv),
@@ -44,7 +66,8 @@ def _tv(scheme, img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_sta
     x, _ = _to_device(img)
     if x.dim() != 4:
         raise ValueError("img must be 4-D (Nz, M, N, N), got shape %s" % (tuple(x.shape),))
-    tv, G, inv_n = tv_subgradient_device(x, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
+    tv, G, inv_n = tv_subgradient_device(x, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static,
+                                         want_norms=bool(return_grad_norms))
     tv = tv.detach().cpu().numpy()          # 0-d numpy, always (tv_GPU.py:85 via compute_L21_norm)
     if not return_grad_norms:
         return (tv, G) if return_pytorch_tensor else (tv, G.detach().cpu().numpy())

@@ -1,0 +1,188 @@
+"""GPU parity of the ONE-PASS TV value + sub-gradient (C-ABI ``tv_subgrad_fused``, csrc/tv_subgrad.h) against the
+CPU oracle (pytv/tv_CPU.py:47-375 restated), the golden vectors captured from the reference, and the two-pass
+``tv_subgrad``.  fp32 kernel: ``rtol = atol = 1e-5`` against the fp64 oracle on the same up-cast input (the
+reference's own bar, pytv/tests.py:88-109, and BASELINE.json's north_star tolerance)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import tv_oracle as orc
+
+pytestmark = pytest.mark.gpu
+os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+
+ONE_PASS_SCHEMES = ["upwind", "downwind", "hybrid"]
+F32 = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def pytv():
+    import pytv
+    return pytv
+
+
+def _one_pass(pytv, x, scheme, **kw):
+    tv, G, none = pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=False, one_pass=True, **kw)
+    assert none is None
+    return float(tv), G
+
+
+# tile geometry of the kernel: 14 useful rows x 56 useful columns per block, ring of one row / one 4-column vector
+@pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
+@pytest.mark.parametrize("zchunk", ["0", "3"])
+@pytest.mark.parametrize("shape,lz,mu,use_mask", [
+    ((1, 1, 16, 64), 1.0, 0.0, False),        # 2-D, one tile row, two tile columns
+    ((1, 1, 33, 132), 0.0, 0.0, False),       # ragged in both directions
+    ((5, 1, 14, 56), 1.0, 0.0, False),        # exactly one tile
+    ((6, 1, 15, 60), 2.5, 0.0, False),        # one row / one vector more than a tile
+    ((7, 2, 29, 116), 0.3, 0.7, False),
+    ((4, 3, 17, 72), 1.0, 1.5, True),
+    ((9, 4, 30, 64), 1.0, 2.0 ** -5, False),
+    ((5, 8, 20, 128), 1.7, 0.6, True),
+    ((3, 8, 9, 64), 0.0, 1.0, False),         # time axis only
+    ((2, 2, 5, 68), 1.0, 1.0, False),
+    ((3, 2, 6, 8), 1.0, 1.0, False),          # frame narrower than a tile
+    ((2, 1, 3, 4), 1.0, 0.0, False),
+])
+def test_one_pass_matches_oracle_and_two_pass(pytv, scheme, zchunk, shape, lz, mu, use_mask, monkeypatch):
+    import torch
+    monkeypatch.setenv("TV_ZCHUNK", zchunk)
+    rng = np.random.default_rng(20 + shape[0] + shape[3])
+    img = (rng.standard_normal(shape) * 10).astype(np.float32)
+    img[:, :, 2:4, 2:20] = 3.0                  # a flat patch: |Dx| == 0 there (the 0 -> +inf rule)
+    mask = (rng.random(shape[2:]) < 0.4) if use_mask else False
+    kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=2.3 if use_mask else 0)
+    x = torch.as_tensor(img).cuda()
+    tv1, G1 = _one_pass(pytv, x, scheme, **kw)
+    tv_ref, G_ref = orc.tv(img.astype(np.float64), scheme, **kw)
+    np.testing.assert_allclose(G1.cpu().numpy(), G_ref, **F32)
+    assert abs(tv1 - float(tv_ref)) <= 1e-6 * abs(float(tv_ref))
+    tv2, G2, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, **kw)
+    np.testing.assert_allclose(G1.cpu().numpy(), G2.cpu().numpy(), rtol=2e-6, atol=2e-5)
+    assert abs(tv1 - float(tv2)) <= 1e-6 * abs(tv1)
+
+
+@pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
+def test_one_pass_on_reference_golden(pytv, scheme):
+    """Inputs / outputs captured from the real reference (tests/golden/make_golden.py), fp32 cases the kernel supports."""
+    import torch
+    from pytv import _native as nv
+    z = np.load(os.path.join(GOLDEN, "ops_%s.npz" % scheme))
+    done = 0
+    for name in z["case_names"]:
+        name = str(name)
+        img = z[name + "/x"]
+        lz, mu, factor = z[name + "/params"]
+        mask = z[name + "/mask"]
+        mask = False if mask.ndim == 0 else mask
+        kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=factor)
+        x = torch.as_tensor(img.astype(np.float32)).cuda()
+        geo = nv.Geometry(tuple(x.shape), scheme, x.dtype, x.device, **kw)
+        if not nv.lib().tv_subgrad_fused_supported(geo.ref):
+            continue
+        tv1, G1 = _one_pass(pytv, x, scheme, **kw)
+        if img.dtype == np.float32:      # the reference's own fp32 outputs on this very input
+            wtv, wG = float(z[name + "/tv"]), z[name + "/G"]
+        else:                            # fp64 case: the kernel sees the fp32 rounding of the input
+            wtv, wG = orc.tv(img.astype(np.float32).astype(np.float64), scheme, **kw)
+        np.testing.assert_allclose(G1.cpu().numpy(), wG, err_msg="%s %s" % (scheme, name), **F32)
+        assert abs(tv1 - float(wtv)) <= 1e-5 * abs(float(wtv)), (scheme, name)
+        done += 1
+    assert done >= 2      # the two fp32 golden cases (8 x 8 frames); the others have Nx % 4 != 0
+
+
+@pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
+@pytest.mark.parametrize("cuts", [(0, 3, 7), (0, 2, 4, 7), (0, 1, 2, 3, 4, 5, 6, 7)])
+@pytest.mark.parametrize("zchunk", ["16", "2"])
+def test_one_pass_slab_calls_equal_unsharded(pytv, scheme, cuts, zchunk, monkeypatch):
+    import torch
+    from pytv import _native as nv
+    monkeypatch.setenv("TV_ZCHUNK", zchunk)
+    lib = nv.lib()
+    shape = (7, 3, 17, 132)
+    rng = np.random.default_rng(5)
+    kw = dict(reg_z_over_reg=1.7, reg_time=0.6)
+    x = torch.as_tensor(rng.standard_normal(shape).astype(np.float32)).cuda()
+    tv_full, G_full = _one_pass(pytv, x, scheme, **kw)
+    nzg, st, tv_sum = shape[0], nv.current_stream(x.device), 0.0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g = nv.Geometry((b - a,) + shape[1:], scheme, x.dtype, x.device, nz_global=nzg, z0=a, **kw)
+
+        def two(lo):     # two-plane halo, NaN where the global plane does not exist (must never be read)
+            buf = torch.full((2,) + shape[1:], float("nan"), dtype=x.dtype, device=x.device)
+            for k in range(2):
+                if 0 <= lo + k < nzg:
+                    buf[k] = x[lo + k]
+            return buf
+        xp2 = two(a - 2) if a > 0 else None
+        xn2 = two(b) if b < nzg else None
+        xs = x[a:b].contiguous()
+        G = torch.empty_like(xs)
+        tvs = g.scalar()
+        nv.check(lib.tv_subgrad_fused(g.ref, nv.ptr(xs), nv.ptr(xp2), nv.ptr(xn2), nv.ptr(G), nv.ptr(tvs), nv.ptr(g.workspace()), st))
+        assert torch.equal(G, G_full[a:b]), (scheme, a, b)
+        tv_sum += float(tvs)
+    assert abs(tv_sum - tv_full) <= 1e-12 * abs(tv_full)
+
+
+def test_one_pass_rejects_what_it_does_not_support(pytv):
+    import torch
+    from pytv import _native as nv
+    lib = nv.lib()
+    for shape, scheme, dt in (((2, 1, 8, 64), "central", torch.float32), ((2, 1, 8, 64), "hybrid", torch.float64),
+                              ((2, 1, 8, 66), "hybrid", torch.float32), ((2, 5, 8, 64), "hybrid", torch.float32),
+                              ((2, 1, 8, 7), "downwind", torch.float32),
+                              ((2, 16, 8, 64), "upwind", torch.float32)):
+        g = nv.Geometry(shape, scheme, dt, torch.device("cuda", 0))
+        assert lib.tv_subgrad_fused_supported(g.ref) == 0
+        x = torch.zeros(shape, dtype=dt, device="cuda")
+        G = torch.empty_like(x)
+        rc = lib.tv_subgrad_fused(g.ref, nv.ptr(x), None, None, nv.ptr(G), nv.ptr(g.scalar()), nv.ptr(g.workspace()),
+                                  nv.current_stream(x.device))
+        assert rc < 0
+    # a slab without its halos
+    g = nv.Geometry((3, 1, 8, 64), "hybrid", torch.float32, torch.device("cuda", 0), nz_global=9, z0=3)
+    x = torch.zeros((3, 1, 8, 64), device="cuda")
+    rc = lib.tv_subgrad_fused(g.ref, nv.ptr(x), None, None, nv.ptr(torch.empty_like(x)), nv.ptr(g.scalar()), nv.ptr(g.workspace()),
+                              nv.current_stream(x.device))
+    assert rc == -2
+
+
+@pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
+def test_one_pass_no_out_of_bounds_access(pytv, scheme):
+    import torch
+    from pytv import _native as nv
+    lib = nv.lib()
+    shape = (4, 8, 19, 132)
+    n = int(np.prod(shape))
+    pad = 4100
+    rng = np.random.default_rng(3)
+    xb = torch.full((n + 2 * pad,), float("nan"), device="cuda")
+    ob = torch.full((n + 2 * pad,), float("nan"), device="cuda")
+    x = xb[pad:pad + n].view(shape)
+    x.copy_(torch.as_tensor(rng.standard_normal(shape).astype(np.float32)).cuda())
+    o = ob[pad:pad + n].view(shape)
+    g = nv.Geometry(shape, scheme, torch.float32, torch.device("cuda", 0), reg_z_over_reg=1.2, reg_time=0.8)
+    sc = g.scalar()
+    nv.check(lib.tv_subgrad_fused(g.ref, nv.ptr(x), None, None, nv.ptr(o), nv.ptr(sc), nv.ptr(g.workspace()), nv.current_stream(x.device)))
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(ob[:pad]).all() and torch.isnan(ob[-pad:]).all())
+    assert bool(torch.isfinite(o).all()) and np.isfinite(float(sc))
+
+
+@pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
+def test_subgradient_descent_one_pass_equals_two_pass(pytv, scheme):
+    import torch
+    shape = (6, 2, 20, 64)
+    rng = np.random.default_rng(9)
+    x0 = torch.as_tensor((rng.random(shape) * 50).astype(np.float32)).cuda()
+    kw = dict(scheme=scheme, reg_z_over_reg=1.0, reg_time=0.5)
+    a = pytv.solvers.SubgradientDescent(x0, 2.0, 0.05, one_pass=True, **kw)
+    b = pytv.solvers.SubgradientDescent(x0, 2.0, 0.05, one_pass=False, **kw)
+    la, lb = a.run(15), b.run(15)
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    np.testing.assert_allclose(a.result().cpu().numpy(), b.result().cpu().numpy(), rtol=1e-4, atol=1e-3)
+    ref_x, ref_loss = orc.subgradient_descent(x0.cpu().numpy().astype(np.float64), 15, 2.0, 0.05, **kw)
+    np.testing.assert_allclose(la, ref_loss, rtol=1e-4)

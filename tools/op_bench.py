@@ -27,7 +27,7 @@ def timeit(f, reps=5):
 
 
 print("shape %s  V = %.0f Mvox; GB/s = algorithmic bytes / time; frac of 8000 GB/s" % (shape, V / 1e6))
-print("%-9s %-14s %8s %9s %7s  %s" % ("scheme", "op", "ms", "GB/s", "frac", "algorithmic words/voxel"))
+print("%-9s %-16s %8s %9s %7s  %s" % ("scheme", "op", "ms", "GB/s", "frac", "algorithmic words/voxel"))
 for scheme in schemes:
     kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
     g = nv.Geometry(shape, scheme, x.dtype, dev, **kw)
@@ -42,15 +42,20 @@ for scheme in schemes:
         ("tv_DT", nd + 1, lambda: nv.check(lib.tv_DT(g.ref, nv.ptr(d), None, None, nv.ptr(o), st))),
         ("tv_l21", nd, lambda: nv.check(lib.tv_l21(g.ref, nv.ptr(d), nd, None, nv.ptr(sc), nv.ptr(ws), st))),
         ("tv_subgrad", 2, lambda: nv.check(lib.tv_subgrad(g.ref, nv.ptr(x), None, None, nv.ptr(o), nv.ptr(ne), nv.ptr(sc), nv.ptr(ws), st))),
+        ("tv_subgrad_fused", 2, (lambda: nv.check(lib.tv_subgrad_fused(g.ref, nv.ptr(x), None, None, nv.ptr(o), nv.ptr(sc), nv.ptr(ws), st)))
+         if lib.tv_subgrad_fused_supported(g.ref) else None),
         ("tv_normal_op", 2, lambda: nv.check(lib.tv_normal_op(g.ref, nv.ptr(x), None, None, 0.1, nv.ptr(o), nv.ptr(sc), nv.ptr(ws), st))),
         ("tv_admm_zu", 1 + 3 * nd, lambda: nv.check(lib.tv_admm_zu(g.ref, nv.ptr(x), None, None, nv.ptr(d), nv.ptr(u), 1.0, nv.ptr(sc), nv.ptr(ws), st))),
         ("tv_DT_axpy", 2 * nd + 2, lambda: nv.check(lib.tv_DT_axpy(g.ref, nv.ptr(d), nv.ptr(u), None, None, nv.ptr(x), 0.1, nv.ptr(o), st))),
         ("tv_cp_dual", 1 + 2 * nd, lambda: nv.check(lib.tv_cp_dual(g.ref, nv.ptr(x), None, None, nv.ptr(d), 0.5, 25.0, nv.ptr(sc), nv.ptr(ws), st))),
         ("tv_cp_primal", nd + 5, lambda: nv.check(lib.tv_cp_primal(g.ref, nv.ptr(d), None, None, nv.ptr(o), nv.ptr(x), nv.ptr(o2), 0.05, 1.0, nv.ptr(sc), nv.ptr(ws), st))),
     ]
+    only = [o for o in os.environ.get("OPS", "").split(",") if o]
     for name, words, f in ops:
+        if (only and name not in only) or f is None:
+            continue
         t = timeit(f)
         gbs = words * 4.0 * V / t / 1e9
-        print("%-9s %-14s %8.3f %9.0f %7.3f  %d" % (scheme, name, t * 1e3, gbs, gbs / 8000.0, words))
+        print("%-9s %-16s %8.3f %9.0f %7.3f  %d" % (scheme, name, t * 1e3, gbs, gbs / 8000.0, words))
     del d, u, o, o2, ne
     torch.cuda.empty_cache()
