@@ -35,38 +35,66 @@ namespace tv {
 // to the end of the loop -- 70 VGPRs per frame instead of 20).
 __device__ __forceinline__ void pin(F4& a) { asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3])); }
 
+// value of the lane one to the left / right inside the 16-lane row (= the neighbouring 4-column vector of the same
+// image row): a DPP-modified move, no LDS traffic.  Row-edge lanes get 0 (they are ring lanes: never used).
+__device__ __forceinline__ float from_left_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float from_right_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
+}
+
+// 1/|Dx| from |Dx|^2 with one v_rsq_f32 (1 ulp).  A |Dx|^2 that is not a normal fp32 number (|Dx| < 1.1e-19) counts
+// as a zero gradient: v_rsq_f32 flushes denormal inputs, and fp32 squares carry no information there anyway
+// (the reference's own float32 path loses |Dx| in the same range).
+__device__ __forceinline__ float inv_norm(float ss, bool site_ok) {
+    return (ss >= 0x1p-126f && site_ok) ? __builtin_amdgcn_rsqf(ss) : 0.f;
+}
+
+// The kernel is VALU-bound (hybrid: ~20 vector operations per site and frame on top of the shuffles), so the
+// per-site arithmetic is kept to the minimum: border masks, the 1/sqrt(2) of the hybrid scheme and the axis
+// weights are folded into per-lane multipliers outside the loops; the backward time / z differences are the
+// forward ones of the previous frame / plane and are carried, not recomputed; 1/|Dx| is one v_rsq_f32.
 template <int S, int M, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, const float* __restrict__ x,
                                                             const float* __restrict__ xp, const float* __restrict__ xn,
-                                                            float* __restrict__ G, int zchunk, double* __restrict__ partials) {
+                                                            float* __restrict__ G, int zchunk, int nchunks, double* __restrict__ partials) {
     static_assert(S != CENTRAL, "radius-2 scheme");
     constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
     constexpr bool HALO = (S == HYBRID);   // only the hybrid norm of a ring row looks at the row outside the tile
     constexpr int RB = 4 * NW, UR = RB - 2, UC = 14;
     __shared__ F4 xe[M][NW][2][16];      // x of the first / last row of every wave (cross-wave row neighbours)
     __shared__ F4 ye[M][NW][2][16];      // [0]: PB_r of the first row (for the wave above), [1]: PF_r of the last row
-    __shared__ F4 lds_P[M][64 * NW];     // x(z-1) of every site: per-thread slots (registers are the scarce resource)
+    __shared__ F4 lds_B[M][64 * NW];     // weighted x(z) - x(z-1) of every site: per-thread slots (registers are scarce)
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wv = (int)threadIdx.y;
     const int tid = wv * 64 + lane;
     const int rr = lane >> 4, lx = lane & 15, ry = wv * 4 + rr;
     const int nxv = g.nx / 4;
     const int tiles_x = (nxv + UC - 1) / UC;
-    const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
+    // XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its
+    // own L2).  Neighbouring tiles share their ring rows / columns, so every XCD gets a CONTIGUOUS run of tiles:
+    // logical id = (id % 8) * per_xcd + id / 8  (grid padded to 8 * per_xcd; the padding blocks leave at once)
+    const int tiles_y = (g.ny + UR - 1) / UR;
+    const long long ntiles = (long long)tiles_x * tiles_y, total = ntiles * nchunks, per_xcd = (total + 7) / 8;
+    const long long lid = (long long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (lid >= total) return;
+    const int chunk = (int)(lid / ntiles), tile = (int)(lid % ntiles);
+    const int bx = tile % tiles_x, by = tile / tiles_x;
     const int cv = bx * UC - 1 + lx, y = by * UR - 1 + ry, col0 = cv * 4;
     const bool in = (cv >= 0) && (cv < nxv) && (y >= 0) && (y < g.ny);               // site inside the frame
     const bool useful = in && (ry >= 1) && (ry <= RB - 2) && (lx >= 1) && (lx <= 14);
     const unsigned voff = in ? (unsigned)(((long long)y * g.nx + col0) * 4) : 0u;    // byte offset inside a frame (< 2^32: host)
-    const int zs = (int)blockIdx.y * zchunk;
+    const int zs = chunk * zchunk;
     const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
     const F4 zero = vsplat<float, 4>(0.f);
-    const F4 mf = (g.ta && in) ? mask_factor<float, 4>(g, w.sf, y, col0) : vsplat<float, 4>(1.f);
     const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : 1.f;
-    // frame-border masks as multipliers (straight-line code: every `if` around a vector costs registers here)
-    const float m_pr = (in && y > 0) ? 1.f : 0.f, m_nr = (in && y + 1 < g.ny) ? 1.f : 0.f;
-    const float m_c0 = (in && col0 > 0) ? 1.f : 0.f, m_c3 = (in && col0 + 3 < g.nx - 1) ? 1.f : 0.f;
-    const float m_in = in ? 1.f : 0.f;
-    const float wt = g.ta ? w.wt : 0.f;
+    // frame-border masks as multipliers, with the scheme's scale folded in (straight-line code: every `if` around
+    // a vector costs registers here)
+    const float ms_pr = (in && y > 0) ? s : 0.f, ms_nr = (in && y + 1 < g.ny) ? s : 0.f;
+    const float ms_c0 = (in && col0 > 0) ? s : 0.f, ms_c3 = (in && col0 + 3 < g.nx - 1) ? s : 0.f;
+    F4 mft = zero;                        // time-axis multiplier: s * sqrt(reg_time) * mask factor
+    if (g.ta && in) mft = (s * w.wt) * mask_factor<float, 4>(g, w.sf, y, col0);
     // ring rows of a hybrid tile read the row just outside the tile from memory
     const bool ring_up = HALO && (ry == 0) && in && (y > 0), ring_dn = HALO && (ry == RB - 1) && in && (y + 1 < g.ny);
     const unsigned hoff = ring_up ? voff - (unsigned)g.nx * 4u : voff + (unsigned)g.nx * 4u;
@@ -75,16 +103,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
     const bool take_up = (rr == 0), take_dn = (rr == 3);
     const float m_xup = (rr == 0 && wv > 0) ? 1.f : 0.f, m_xdn = (rr == 3 && wv < NW - 1) ? 1.f : 0.f;
     const float m_iup = (rr > 0) ? 1.f : 0.f, m_idn = (rr < 3) ? 1.f : 0.f;
+    const float wzs = g.za ? s * w.wz : 0.f;
     double acc = 0.0;
 
     F4 C[M], Gp[M], Gc[M];
     {
-        const float* pp = g.za ? zplane<float>(g, x, xp, xn, 2, zs - 2) : nullptr;
-        const float* pc = zplane<float>(g, x, xp, xn, 2, g.za ? zs - 1 : zs);
+        // centre plane of the first step, and the carried backward z difference of that plane
+        const int z_c = g.za ? zs - 1 : zs;
+        const float* pp = g.za ? zplane<float>(g, x, xp, xn, 2, z_c - 1) : nullptr;
+        const float* pc = zplane<float>(g, x, xp, xn, 2, z_c);
+        const float wb = (pp != nullptr && pc != nullptr) ? wzs : 0.f;
 #pragma unroll
         for (int t = 0; t < M; ++t) {
-            lds_P[t][tid] = (in && pp) ? ldu(pp + (long long)t * g.s_t, voff) : zero;
+            const F4 p = (in && pp) ? ldu(pp + (long long)t * g.s_t, voff) : zero;
             C[t] = (in && pc) ? ldu(pc + (long long)t * g.s_t, voff) : zero;
+            lds_B[t][tid] = wb * (C[t] - p);
             Gp[t] = zero;
             Gc[t] = zero;
         }
@@ -104,41 +137,61 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
         for (int t = 0; t < M; ++t)
             if (rr == 0 || rr == 3) xe[t][wv][rr == 3 ? 1 : 0][lx] = C[t];
         __syncthreads();
-        // uniform per step: z weights (0 when the neighbour plane does not exist), validity of this plane
-        const float wzp = (plane_in && g.za && gz > 0) ? w.wz : 0.f, wzn = (plane_in && g.za && gz + 1 < g.nzg) ? w.wz : 0.f;
-        const float m_site = plane_in ? m_in : 0.f;                  // 1/|Dx| of a site that does not exist is 0
+        // uniform per step: forward z weight (0 when the next plane does not exist), validity of this plane
+        const float wzn = (plane_in && gz + 1 < g.nzg) ? wzs : 0.f;
+        const bool site_ok = in && plane_in;                          // 1/|Dx| of a site that does not exist is 0
+        const float m_row = plane_in ? 1.f : 0.f;
         const bool count = useful && plane_in && (zl >= zs) && (zl < ze);
         const bool store = useful && (zl - 1 >= zs) && (zl - 1 < ze);
         const bool halo_here = (ring_up || ring_dn) && (pc != nullptr);
+        // halo rows: two frames ahead of their use (one exposed latency per frame would stall the whole block at
+        // the barrier: only the first and the last wave have these loads)
+        F4 hq[2] = {zero, zero};
+        if (HALO && halo_here) {
+            hq[0] = ldu(pc, hoff);
+            if (M > 1) hq[1] = ldu(pc + g.s_t, hoff);
+        }
         F4 pf_t_prev = zero;                 // PF_t of frame t-1 (up part: added to frame t)
+        F4 f_t_prev = zero;                  // forward time difference of frame t-1 == backward one of frame t
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const F4 c = C[t];
             // ---- neighbourhood of x(zl, t) ------------------------------------------------------------
-            F4 xu = (SG_X & 64) ? c : shfl_up16(c), xd = (SG_X & 64) ? c : shfl_down16(c);
-            {
-                F4 h = zero;
-                if (HALO && halo_here) h = ldu(pc + (long long)t * g.s_t, hoff);
-                const F4 eu = xe[t][w_up][1][lx], ed = xe[t][w_dn][0][lx];
+            // row neighbours: inside the wave by a 16-lane shuffle; first / last row of the wave from the neighbouring
+            // wave's LDS slot (the block's first / last row: from the halo load, hybrid only)
+            F4 xu = zero, xd = zero;
+            F4 h = zero;
+            if (HALO) {
+                h = hq[t & 1];
+                if (halo_here && t + 2 < M) hq[t & 1] = ldu(pc + (long long)(t + 2) * g.s_t, hoff);
+            }
+            if (DN) {
+                xu = shfl_up16(c);
+                F4 eu = xe[t][w_up][1][lx];
+                if (HALO && wv == 0) eu = h;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xu.v[i] = take_up ? ((wv > 0) ? eu.v[i] : h.v[i]) : xu.v[i];
-                    xd.v[i] = take_dn ? ((wv < NW - 1) ? ed.v[i] : h.v[i]) : xd.v[i];
-                }
+                for (int i = 0; i < 4; ++i) xu.v[i] = take_up ? eu.v[i] : xu.v[i];
             }
-            const float xl = __shfl_up(c.v[3], 1, 64), xr = __shfl_down(c.v[0], 1, 64);   // ring lanes: don't care
-            // ---- gradient channels (same arithmetic as d_slots / subgrad_site) -------------------------
-            F4 f_r = m_nr * (xd - c), b_r = m_pr * (c - xu), f_c, b_c;
-            f_c.v[0] = c.v[1] - c.v[0]; f_c.v[1] = c.v[2] - c.v[1]; f_c.v[2] = c.v[3] - c.v[2]; f_c.v[3] = m_c3 * (xr - c.v[3]);
-            b_c.v[0] = m_c0 * (c.v[0] - xl); b_c.v[1] = f_c.v[0]; b_c.v[2] = f_c.v[1]; b_c.v[3] = f_c.v[2];
-            F4 f_z = wzn * (N[t] - c), b_z = wzp * (c - lds_P[t][tid]);
-            F4 f_t = zero, b_t = zero;
-            if (t + 1 < M) f_t = (wt * (C[(t + 1 < M) ? t + 1 : t] - c)) * mf;
-            if (t > 0) b_t = (wt * (c - C[(t > 0) ? t - 1 : 0])) * mf;
-            if (S == HYBRID) {
-                f_r = s * f_r; f_c = s * f_c; b_r = s * b_r; b_c = s * b_c;
-                f_z = s * f_z; b_z = s * b_z; f_t = s * f_t; b_t = s * b_t;
+            if (UP) {
+                xd = shfl_down16(c);
+                F4 ed = xe[t][w_dn][0][lx];
+                if (HALO && wv == NW - 1) ed = h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xd.v[i] = take_dn ? ed.v[i] : xd.v[i];
             }
+            const float xl = from_left_lane(c.v[3]), xr = from_right_lane(c.v[0]);      // ring lanes: don't care
+            // ---- gradient channels ---------------------------------------------------------------------
+            const F4 f_r = (ms_nr * m_row) * (xd - c), b_r = (ms_pr * m_row) * (c - xu);
+            const float e0 = (s * m_row) * (c.v[1] - c.v[0]), e1 = (s * m_row) * (c.v[2] - c.v[1]), e2 = (s * m_row) * (c.v[3] - c.v[2]);
+            F4 f_c, b_c;
+            f_c.v[0] = e0; f_c.v[1] = e1; f_c.v[2] = e2; f_c.v[3] = (ms_c3 * m_row) * (xr - c.v[3]);
+            b_c.v[0] = (ms_c0 * m_row) * (c.v[0] - xl); b_c.v[1] = e0; b_c.v[2] = e1; b_c.v[3] = e2;
+            const F4 f_z = wzn * (N[t] - c), b_z = lds_B[t][tid];
+            lds_B[t][tid] = f_z;                                             // == b_z of the next plane
+            F4 f_t = zero;
+            if (t + 1 < M) f_t = (m_row * mft) * (C[(t + 1 < M) ? t + 1 : t] - c);
+            const F4 b_t = f_t_prev;
+            f_t_prev = f_t;
             F4 ss = zero;
             if (S == HYBRID) ss = ((((((f_r * f_r + f_c * f_c) + b_r * b_r) + b_c * b_c) + f_z * f_z) + b_z * b_z) + f_t * f_t) + b_t * b_t;
             if (S == UPWIND) ss = ((f_r * f_r + f_c * f_c) + f_z * f_z) + f_t * f_t;
@@ -146,17 +199,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             F4 n, rn;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                rn.v[i] = (SG_X & 32) ? __builtin_amdgcn_sqrtf(ss.v[i]) : tsqrt(ss.v[i]);
-                n.v[i] = (SG_X & 32) ? m_site * __builtin_amdgcn_rcpf(rn.v[i]) : ((rn.v[i] > tiny_norm<float>()) ? m_site / rn.v[i] : 0.f);
+                n.v[i] = inv_norm(ss.v[i], site_ok);
+                rn.v[i] = ss.v[i] * n.v[i];
             }
             // four norms in fp32 (each carries its own 2^-24 already), then fp64 across frames / planes / threads
-            if (count && !(SG_X & 4)) acc += (double)((rn.v[0] + rn.v[1]) + (rn.v[2] + rn.v[3]));
+            if (count) acc += (double)((rn.v[0] + rn.v[1]) + (rn.v[2] + rn.v[3]));
             // ---- scatter the products ---------------------------------------------------------------------
             F4 gc = Gc[t], gn = zero;
             if (UP) {
                 const F4 pf_r = f_r * n, pf_c = f_c * n, pf_z = f_z * n, pf_t = f_t * n;
                 const F4 from_up = shfl_up16(pf_r);                       // PF_r of the row above (same wave)
-                const float from_left = __shfl_up(pf_c.v[3], 1, 64);
+                const float from_left = from_left_lane(pf_c.v[3]);
                 if (rr == 3) ye[t][wv][1][lx] = pf_r;
                 gc = gc + (m_iup * from_up - pf_r);
                 gc = gc + (shift_right<float, 4>(pf_c, from_left) - pf_c);
@@ -168,7 +221,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             if (DN) {
                 const F4 pb_r = b_r * n, pb_c = b_c * n, pb_z = b_z * n, pb_t = b_t * n;
                 const F4 from_dn = shfl_down16(pb_r);                     // PB_r of the row below (same wave)
-                const float from_right = __shfl_down(pb_c.v[0], 1, 64);
+                const float from_right = from_right_lane(pb_c.v[0]);
                 if (rr == 0) ye[t][wv][0][lx] = pb_r;
                 gc = gc + (pb_r - m_idn * from_dn);
                 gc = gc + (pb_c - shift_left<float, 4>(pb_c, from_right));
@@ -187,7 +240,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             }
             pin(gn);
             Gp[t] = gn;                      // the slot of the finished plane now carries the start of G(zl+1)
-            if (!(SG_X & 128)) __builtin_amdgcn_sched_barrier(0);   // keep the frames apart (register pressure)
         }
         __syncthreads();
         // cross-wave row products, rotation of the planes
@@ -198,12 +250,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             if (DN) gc = gc - m_xdn * ye[t][w_dn][0][lx];
             Gc[t] = Gp[t];
             Gp[t] = gc;
-            lds_P[t][tid] = C[t];
             C[t] = N[t];
         }
     }
     acc = block_sum(acc, sm);
-    if (threadIdx.x == 0 && threadIdx.y == 0) partials[linear_block_id()] = acc;
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[lid] = acc;
 }
 
 }  // namespace tv

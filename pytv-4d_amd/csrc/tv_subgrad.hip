@@ -44,15 +44,25 @@ int tv_subgrad_fused(const tv_geom* g, const void* x, const void* x_prev, const 
         return fail(TV_E_HALO, "tv_subgrad_fused on a slab needs two halo planes on each interior side");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    const int zc = march_zchunk(d);
     constexpr int NW = 4, UR = 4 * NW - 2, UC = 14;
-    const long long tx = (d.nx / 4 + UC - 1) / UC, ty = (d.ny + UR - 1) / UR, nch = (d.nz + zc - 1) / zc;
-    const dim3 grid((unsigned)(tx * ty), (unsigned)nch, 1), block(64, NW, 1);
-    const long long nb = tx * ty * nch;
+    const long long tx = (d.nx / 4 + UC - 1) / UC, ty = (d.ny + UR - 1) / UR;
+    // planes per z-chunk: every chunk computes two extra planes of norms (and loads four), so chunks are as long as
+    // keeping >= ~2048 blocks (4 rounds of 256 CUs x 2) allows; TV_ZCHUNK overrides
+    int zc = env_int("TV_ZCHUNK", 0);
+    if (zc <= 0) {
+        const long long want = (2048 + tx * ty - 1) / (tx * ty);
+        zc = (int)(d.nz / (want > 0 ? want : 1));
+        if (zc > 32) zc = 32;
+        if (zc < 8) zc = 8;
+    }
+    if (zc > d.nz) zc = d.nz;
+    const long long nch = (d.nz + zc - 1) / zc;
+    const long long nb = tx * ty * nch, per_xcd = (nb + 7) / 8;       // XCD-aware logical ids: see the kernel
+    const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, NW, 1);
     if (nb > nmax) return fail(TV_E_ARG, "internal: partials exceed the workspace");
     int rc = dispatch_sg(g->scheme, d.m, [&]<int S, int M>() -> int {
         hipLaunchKernelGGL((k_subgrad_one<S, M, NW>), grid, block, 0, st, d, make_w<float>(g), (const float*)x, (const float*)x_prev,
-                           (const float*)x_next, (float*)G, zc, (double*)ws);
+                           (const float*)x_next, (float*)G, zc, (int)nch, (double*)ws);
         HIP_TRY(hipGetLastError());
         return 0;
     });
