@@ -90,12 +90,18 @@ int tv_l21(const tv_geom* g, const void* d, int32_t nd, void* norms, double* res
 int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* x_next,
                void* G, void* norms_ext, double* tv, void* ws, void* stream);
 
-/* The same TV value and sub-gradient in ONE pass over x (1/|Dx| never leaves the chip): upwind, downwind and
- * hybrid schemes, fp32, Nx % 4 == 0, M in {1,2,3,4,8}, 16-byte aligned arrays (tv_subgrad_fused_supported).  Use it
- * when the per-voxel norms are not wanted (return_grad_norms=False, pytv/tv_GPU.py:47).  Halos as for tv_subgrad. */
+/* The same TV value and sub-gradient in ONE pass over x (1/|Dx| never leaves the chip): all four schemes (central:
+ * not with a two-point z or time axis), fp32, Nx % 4 == 0, M in {1,2,3,4,8}, 16-byte aligned arrays
+ * (tv_subgrad_fused_supported).  Use it when the per-voxel norms are not wanted (return_grad_norms=False,
+ * pytv/tv_GPU.py:47).  Halos as for tv_subgrad.  A |Dx|^2 below the smallest normal fp32 number counts as 0. */
 int tv_subgrad_fused_supported(const tv_geom* g);
 int tv_subgrad_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, double* tv,
                      void* ws, void* stream);
+/* One iteration of the README's sub-gradient loop (README.md:118-124) in the same single pass, G never stored:
+ *   x_out = x - step * ((x - x0) + lambda * G(x));  *tv = TV(x);  *fid = 1/2 |x_out - x0|^2   (local planes).
+ * x and x_out must be different buffers (ping-pong).  Same geometries as tv_subgrad_fused. */
+int tv_subgrad_step_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, const void* x0,
+                          void* x_out, double step, double lambda, double* tv, double* fid, void* ws, void* stream);
 
 /* ---- fused Chambolle-Pock inner loop (README.md:141-157) ----------------------------------- */
 /* q <- proj_{|.|_2 <= lambda}(q + sigma_D * D x); *tv (device fp64) = |D x|_{2,1} of local planes. */

@@ -2,8 +2,6 @@
 #include "tv_host.h"
 #include "tv_stencil.h"
 #include "tv_march.h"
-#include <cstdlib>
-#include <cstring>
 
 template <template <int, typename, int> class EpiT, typename... Args>
 static int launch_D_march(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st,
@@ -42,21 +40,13 @@ int D_norms(const tv_geom* g, const DG& d, const void* x, const void* xp, const 
     *nb = lc.nblocks;
     return dispatch_sm(g->scheme, d.m, [&]<int S, int M>() -> int {
         NormEpi<S, float, 4> epi{norms_ext, partials};
-        if constexpr (M == 8) {
-            const char* e = getenv("TV_MARCH_PF");
-            if (e && e[0]) {
-#define TV_X(LT, PFV) hipLaunchKernelGGL((k_D_march<S, M, NormEpi<S, float, 4>, LT, PFV>), lc.grid, lc.block, 0, st, d, make_w<float>(g), \
-                               (const float*)x, (const float*)xp, (const float*)xn, zc, epi, 2, -ghost_lo, d.nz + ghost_hi)
-                if (!strcmp(e, "L1")) TV_X(true, 1); else if (!strcmp(e, "L2")) TV_X(true, 2);
-                else if (!strcmp(e, "N1")) TV_X(false, 1); else if (!strcmp(e, "N2")) TV_X(false, 2); else TV_X(false, 0);
-#undef TV_X
-                HIP_TRY(hipGetLastError());
-                return 0;
-            }
-        }
-        // LIGHT variant (3 waves/SIMD, single-buffered tile): 15-20 % faster than the default one for this
-        // low-traffic epilogue (measured); M = 16 does not fit its register cap
-        if constexpr (M <= 8)
+        // low-traffic epilogue: M = 8 requests the whole next plane and the halo rows at the top of the z step
+        // (PF = 2, 2 waves/SIMD); smaller M take the LIGHT variant (3 waves/SIMD, single-buffered tile), 15-20 %
+        // faster than the default one here (measured); M = 16 fits neither
+        if constexpr (M == 8)
+            hipLaunchKernelGGL((k_D_march<S, M, NormEpi<S, float, 4>, false, 2>), lc.grid, lc.block, 0, st, d, make_w<float>(g),
+                               (const float*)x, (const float*)xp, (const float*)xn, zc, epi, 2, -ghost_lo, d.nz + ghost_hi);
+        else if constexpr (M < 8)
             hipLaunchKernelGGL((k_D_march<S, M, NormEpi<S, float, 4>, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g),
                                (const float*)x, (const float*)xp, (const float*)xn, zc, epi, 2, -ghost_lo, d.nz + ghost_hi);
         else
@@ -75,16 +65,11 @@ int D_normal_op(const tv_geom* g, const DG& d, const void* x, const void* xp, co
     NormalEpi<HYBRID, float, 4> epi{out, rho, w.wz, w.wt, w.sf, d.mask, partials};
     return dispatch_sm(TV_HYBRID, d.m, [&]<int S, int M>() -> int {
         if constexpr (S == HYBRID && M == 8) {
-            const char* e = getenv("TV_MARCH_PF");
-            if (e && e[0]) {
-#define TV_X(LT, PFV) hipLaunchKernelGGL((k_D_march<HYBRID, M, NormalEpi<HYBRID, float, 4>, LT, PFV>), lc.grid, lc.block, 0, st, d, w, \
-                               (const float*)x, (const float*)xp, (const float*)xn, zc, epi, 2, 0, -1)
-                if (!strcmp(e, "L1")) TV_X(true, 1); else if (!strcmp(e, "L2")) TV_X(true, 2);
-                else if (!strcmp(e, "N1")) TV_X(false, 1); else if (!strcmp(e, "N2")) TV_X(false, 2); else TV_X(false, 0);
-#undef TV_X
-                HIP_TRY(hipGetLastError());
-                return 0;
-            }
+            // whole next plane + halo rows requested at the top of the z step: 1.61 -> 1.28 ms on 64x8x1024x1024
+            hipLaunchKernelGGL((k_D_march<HYBRID, M, NormalEpi<HYBRID, float, 4>, false, 2>), lc.grid, lc.block, 0, st, d, w,
+                               (const float*)x, (const float*)xp, (const float*)xn, zc, epi, 2, 0, -1);
+            HIP_TRY(hipGetLastError());
+            return 0;
         }
         if constexpr (S == HYBRID && M <= 8) {
             hipLaunchKernelGGL((k_D_march<HYBRID, M, NormalEpi<HYBRID, float, 4>, true>), lc.grid, lc.block, 0, st, d, w,

@@ -51,21 +51,34 @@ __device__ __forceinline__ float inv_norm(float ss, bool site_ok) {
     return (ss >= 0x1p-126f && site_ok) ? __builtin_amdgcn_rsqf(ss) : 0.f;
 }
 
-// The kernel is VALU-bound (hybrid: ~20 vector operations per site and frame on top of the shuffles), so the
-// per-site arithmetic is kept to the minimum: border masks, the 1/sqrt(2) of the hybrid scheme and the axis
-// weights are folded into per-lane multipliers outside the loops; the backward time / z differences are the
-// forward ones of the previous frame / plane and are carried, not recomputed; 1/|Dx| is one v_rsq_f32.
-template <int S, int M, int NW>
+// MODE 1: instead of G the kernel writes the sub-gradient DESCENT step of the README loop (README.md:122-123)
+//     x_out = x - step * ((x - x0) + lambda * G(x)),     fid partial = 1/2 |x_out - x0|^2
+// (x is ping-ponged: neighbouring tiles still read the old image), which saves writing and re-reading G.
+struct SgStepArgs {
+    const float* x0;
+    float* x_out;
+    float step, lambda;
+    double* part_fid;
+};
+
+// The kernel is issue-bound (hybrid: ~200 vector instructions per site-vector and frame), so the per-site
+// arithmetic is kept to the minimum: border masks, the 1/sqrt(2) (hybrid) or 1/2 (central) of the scheme and the
+// axis weights are folded into per-lane multipliers outside the loops; the backward time difference is the forward
+// one of the previous frame and is carried, not recomputed; 1/|Dx| is one v_rsq_f32.
+// central: ONE channel per axis, d = 1/2 w (x(+e) - x(-e)) on interior points, whose product goes to BOTH neighbours
+// (G(v) = 1/2 sum_a P_a(v-e) - P_a(v+e)); two-point z / t axes (forward stencil) are left to the two-pass path.
+template <int S, int M, int NW, int MODE>
 __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, const float* __restrict__ x,
                                                             const float* __restrict__ xp, const float* __restrict__ xn,
-                                                            float* __restrict__ G, int zchunk, int nchunks, double* __restrict__ partials) {
-    static_assert(S != CENTRAL, "radius-2 scheme");
+                                                            float* __restrict__ G, int zchunk, int nchunks, double* __restrict__ partials,
+                                                            SgStepArgs sa) {
+    constexpr bool CEN = (S == CENTRAL);
     constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
-    constexpr bool HALO = (S == HYBRID);   // only the hybrid norm of a ring row looks at the row outside the tile
+    constexpr bool HALO = (S == HYBRID || CEN);   // the norm of a ring row looks at the row outside the tile
     constexpr int RB = 4 * NW, UR = RB - 2, UC = 14;
     __shared__ F4 xe[M][NW][2][16];      // x of the first / last row of every wave (cross-wave row neighbours)
     __shared__ F4 ye[M][NW][2][16];      // [0]: PB_r of the first row (for the wave above), [1]: PF_r of the last row
-    __shared__ F4 lds_B[M][64 * NW];     // weighted x(z) - x(z-1) of every site: per-thread slots (registers are scarce)
+    __shared__ F4 lds_P[M][64 * NW];     // x(z-1) of every site: per-thread slots (registers are the scarce resource)
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wv = (int)threadIdx.y;
     const int tid = wv * 64 + lane;
@@ -88,14 +101,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
     const int zs = chunk * zchunk;
     const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
     const F4 zero = vsplat<float, 4>(0.f);
-    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : 1.f;
+    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : (CEN ? 0.5f : 1.f);
     // frame-border masks as multipliers, with the scheme's scale folded in (straight-line code: every `if` around
-    // a vector costs registers here)
-    const float ms_pr = (in && y > 0) ? s : 0.f, ms_nr = (in && y + 1 < g.ny) ? s : 0.f;
+    // a vector costs registers here).  central: a difference exists on interior points only
+    const bool has_pr = in && (y > 0), has_nr = in && (y + 1 < g.ny);
+    const float ms_pr = (CEN ? (has_pr && has_nr) : has_pr) ? s : 0.f, ms_nr = (CEN ? (has_pr && has_nr) : has_nr) ? s : 0.f;
     const float ms_c0 = (in && col0 > 0) ? s : 0.f, ms_c3 = (in && col0 + 3 < g.nx - 1) ? s : 0.f;
+    const float ms_in = in ? s : 0.f;
     F4 mft = zero;                        // time-axis multiplier: s * sqrt(reg_time) * mask factor
     if (g.ta && in) mft = (s * w.wt) * mask_factor<float, 4>(g, w.sf, y, col0);
-    // ring rows of a hybrid tile read the row just outside the tile from memory
+    // ring rows of a hybrid / central tile read the row just outside the tile from memory
     const bool ring_up = HALO && (ry == 0) && in && (y > 0), ring_dn = HALO && (ry == RB - 1) && in && (y + 1 < g.ny);
     const unsigned hoff = ring_up ? voff - (unsigned)g.nx * 4u : voff + (unsigned)g.nx * 4u;
     // cross-wave row neighbours: slot of the wave above / below (clamped), and whether this lane takes them
@@ -104,20 +119,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
     const float m_xup = (rr == 0 && wv > 0) ? 1.f : 0.f, m_xdn = (rr == 3 && wv < NW - 1) ? 1.f : 0.f;
     const float m_iup = (rr > 0) ? 1.f : 0.f, m_idn = (rr < 3) ? 1.f : 0.f;
     const float wzs = g.za ? s * w.wz : 0.f;
-    double acc = 0.0;
+    double acc = 0.0, acc_fid = 0.0;
 
     F4 C[M], Gp[M], Gc[M];
     {
-        // centre plane of the first step, and the carried backward z difference of that plane
+        // centre plane of the first step and the plane below it
         const int z_c = g.za ? zs - 1 : zs;
         const float* pp = g.za ? zplane<float>(g, x, xp, xn, 2, z_c - 1) : nullptr;
         const float* pc = zplane<float>(g, x, xp, xn, 2, z_c);
-        const float wb = (pp != nullptr && pc != nullptr) ? wzs : 0.f;
 #pragma unroll
         for (int t = 0; t < M; ++t) {
-            const F4 p = (in && pp) ? ldu(pp + (long long)t * g.s_t, voff) : zero;
+            lds_P[t][tid] = (in && pp) ? ldu(pp + (long long)t * g.s_t, voff) : zero;
             C[t] = (in && pc) ? ldu(pc + (long long)t * g.s_t, voff) : zero;
-            lds_B[t][tid] = wb * (C[t] - p);
             Gp[t] = zero;
             Gc[t] = zero;
         }
@@ -137,8 +150,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
         for (int t = 0; t < M; ++t)
             if (rr == 0 || rr == 3) xe[t][wv][rr == 3 ? 1 : 0][lx] = C[t];
         __syncthreads();
-        // uniform per step: forward z weight (0 when the next plane does not exist), validity of this plane
-        const float wzn = (plane_in && gz + 1 < g.nzg) ? wzs : 0.f;
+        // uniform per step: z weights (0 when the neighbour plane does not exist), validity of this plane
+        const bool z_prev = plane_in && (gz > 0), z_next = plane_in && (gz + 1 < g.nzg);
+        const float wzn = (CEN ? (z_prev && z_next) : z_next) ? wzs : 0.f, wzp = z_prev ? wzs : 0.f;
         const bool site_ok = in && plane_in;                          // 1/|Dx| of a site that does not exist is 0
         const float m_row = plane_in ? 1.f : 0.f;
         const bool count = useful && plane_in && (zl >= zs) && (zl < ze);
@@ -151,28 +165,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             hq[0] = ldu(pc, hoff);
             if (M > 1) hq[1] = ldu(pc + g.s_t, hoff);
         }
-        F4 pf_t_prev = zero;                 // PF_t of frame t-1 (up part: added to frame t)
+        F4 pf_t_prev = zero;                 // product of the time channel of frame t-1 (added to frame t)
         F4 f_t_prev = zero;                  // forward time difference of frame t-1 == backward one of frame t
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const F4 c = C[t];
             // ---- neighbourhood of x(zl, t) ------------------------------------------------------------
             // row neighbours: inside the wave by a 16-lane shuffle; first / last row of the wave from the neighbouring
-            // wave's LDS slot (the block's first / last row: from the halo load, hybrid only)
+            // wave's LDS slot (the block's first / last row: from the halo load)
             F4 xu = zero, xd = zero;
             F4 h = zero;
             if (HALO) {
                 h = hq[t & 1];
                 if (halo_here && t + 2 < M) hq[t & 1] = ldu(pc + (long long)(t + 2) * g.s_t, hoff);
             }
-            if (DN) {
+            if (DN || CEN) {
                 xu = shfl_up16(c);
                 F4 eu = xe[t][w_up][1][lx];
                 if (HALO && wv == 0) eu = h;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xu.v[i] = take_up ? eu.v[i] : xu.v[i];
             }
-            if (UP) {
+            if (UP || CEN) {
                 xd = shfl_down16(c);
                 F4 ed = xe[t][w_dn][0][lx];
                 if (HALO && wv == NW - 1) ed = h;
@@ -181,20 +195,30 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             }
             const float xl = from_left_lane(c.v[3]), xr = from_right_lane(c.v[0]);      // ring lanes: don't care
             // ---- gradient channels ---------------------------------------------------------------------
-            const F4 f_r = (ms_nr * m_row) * (xd - c), b_r = (ms_pr * m_row) * (c - xu);
-            const float e0 = (s * m_row) * (c.v[1] - c.v[0]), e1 = (s * m_row) * (c.v[2] - c.v[1]), e2 = (s * m_row) * (c.v[3] - c.v[2]);
-            F4 f_c, b_c;
-            f_c.v[0] = e0; f_c.v[1] = e1; f_c.v[2] = e2; f_c.v[3] = (ms_c3 * m_row) * (xr - c.v[3]);
-            b_c.v[0] = (ms_c0 * m_row) * (c.v[0] - xl); b_c.v[1] = e0; b_c.v[2] = e1; b_c.v[3] = e2;
-            const F4 f_z = wzn * (N[t] - c), b_z = lds_B[t][tid];
-            lds_B[t][tid] = f_z;                                             // == b_z of the next plane
-            F4 f_t = zero;
-            if (t + 1 < M) f_t = (m_row * mft) * (C[(t + 1 < M) ? t + 1 : t] - c);
-            const F4 b_t = f_t_prev;
-            f_t_prev = f_t;
+            // f_*: forward (upwind / hybrid-up) or central channel; b_*: backward channel
+            F4 f_r, b_r = zero, f_c, b_c = zero, f_z, b_z = zero, f_t = zero, b_t = zero;
+            if (CEN) {
+                f_r = (ms_nr * m_row) * (xd - xu);
+                f_c.v[0] = (ms_c0 * m_row) * (c.v[1] - xl); f_c.v[1] = (ms_in * m_row) * (c.v[2] - c.v[0]);
+                f_c.v[2] = (ms_in * m_row) * (c.v[3] - c.v[1]); f_c.v[3] = (ms_c3 * m_row) * (xr - c.v[2]);
+                f_z = wzn * (N[t] - lds_P[t][tid]);
+                if (t > 0 && t + 1 < M) f_t = (m_row * mft) * (C[(t + 1 < M) ? t + 1 : t] - C[(t > 0) ? t - 1 : 0]);
+            } else {
+                f_r = (ms_nr * m_row) * (xd - c);
+                b_r = (ms_pr * m_row) * (c - xu);
+                const float e0 = (ms_in * m_row) * (c.v[1] - c.v[0]), e1 = (ms_in * m_row) * (c.v[2] - c.v[1]),
+                            e2 = (ms_in * m_row) * (c.v[3] - c.v[2]);
+                f_c.v[0] = e0; f_c.v[1] = e1; f_c.v[2] = e2; f_c.v[3] = (ms_c3 * m_row) * (xr - c.v[3]);
+                b_c.v[0] = (ms_c0 * m_row) * (c.v[0] - xl); b_c.v[1] = e0; b_c.v[2] = e1; b_c.v[3] = e2;
+                f_z = wzn * (N[t] - c);
+                if (DN) b_z = wzp * (c - lds_P[t][tid]);
+                if (t + 1 < M) f_t = (m_row * mft) * (C[(t + 1 < M) ? t + 1 : t] - c);
+                b_t = f_t_prev;
+                f_t_prev = f_t;
+            }
             F4 ss = zero;
             if (S == HYBRID) ss = ((((((f_r * f_r + f_c * f_c) + b_r * b_r) + b_c * b_c) + f_z * f_z) + b_z * b_z) + f_t * f_t) + b_t * b_t;
-            if (S == UPWIND) ss = ((f_r * f_r + f_c * f_c) + f_z * f_z) + f_t * f_t;
+            if (S == UPWIND || CEN) ss = ((f_r * f_r + f_c * f_c) + f_z * f_z) + f_t * f_t;
             if (S == DOWNWIND) ss = ((b_r * b_r + b_c * b_c) + b_z * b_z) + b_t * b_t;
             F4 n, rn;
 #pragma unroll
@@ -206,27 +230,47 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             if (count) acc += (double)((rn.v[0] + rn.v[1]) + (rn.v[2] + rn.v[3]));
             // ---- scatter the products ---------------------------------------------------------------------
             F4 gc = Gc[t], gn = zero;
-            if (UP) {
-                const F4 pf_r = f_r * n, pf_c = f_c * n, pf_z = f_z * n, pf_t = f_t * n;
+            if (CEN) {          // one product per axis, to the neighbours on both sides
+                const F4 pf_r = f_r * n;
+                const F4 from_up = shfl_up16(pf_r), from_dn = shfl_down16(pf_r);
+                if (rr == 3) ye[t][wv][1][lx] = pf_r;
+                if (rr == 0) ye[t][wv][0][lx] = pf_r;
+                gc = gc + (m_iup * from_up - m_idn * from_dn);
+                const F4 pf_c = f_c * n;
+                gc = gc + (shift_right<float, 4>(pf_c, from_left_lane(pf_c.v[3])) - shift_left<float, 4>(pf_c, from_right_lane(pf_c.v[0])));
+                const F4 pf_z = f_z * n;
+                gn = pf_z;
+                Gp[t] = Gp[t] - pf_z;
+                const F4 pf_t = f_t * n;
+                gc = gc + pf_t_prev;
+                pf_t_prev = pf_t;
+                if (t > 0) { Gc[t - 1] = Gc[t - 1] - pf_t; pin(Gc[t - 1]); }
+            }
+            if (UP) {           // forward channels: to the next site (+) and to the site itself (-)
+                const F4 pf_r = f_r * n;
                 const F4 from_up = shfl_up16(pf_r);                       // PF_r of the row above (same wave)
-                const float from_left = from_left_lane(pf_c.v[3]);
                 if (rr == 3) ye[t][wv][1][lx] = pf_r;
                 gc = gc + (m_iup * from_up - pf_r);
-                gc = gc + (shift_right<float, 4>(pf_c, from_left) - pf_c);
+                const F4 pf_c = f_c * n;
+                gc = gc + (shift_right<float, 4>(pf_c, from_left_lane(pf_c.v[3])) - pf_c);
+                const F4 pf_z = f_z * n;
                 gc = gc - pf_z;
                 gn = pf_z;
+                const F4 pf_t = f_t * n;
                 gc = gc + (pf_t_prev - pf_t);
                 pf_t_prev = pf_t;
             }
-            if (DN) {
-                const F4 pb_r = b_r * n, pb_c = b_c * n, pb_z = b_z * n, pb_t = b_t * n;
+            if (DN) {           // backward channels: to the site itself (+) and to the previous site (-)
+                const F4 pb_r = b_r * n;
                 const F4 from_dn = shfl_down16(pb_r);                     // PB_r of the row below (same wave)
-                const float from_right = from_right_lane(pb_c.v[0]);
                 if (rr == 0) ye[t][wv][0][lx] = pb_r;
                 gc = gc + (pb_r - m_idn * from_dn);
-                gc = gc + (pb_c - shift_left<float, 4>(pb_c, from_right));
+                const F4 pb_c = b_c * n;
+                gc = gc + (pb_c - shift_left<float, 4>(pb_c, from_right_lane(pb_c.v[0])));
+                const F4 pb_z = b_z * n;
                 gc = gc + pb_z;
                 Gp[t] = Gp[t] - pb_z;
+                const F4 pb_t = b_t * n;
                 gc = gc + pb_t;
                 if (t > 0) { Gc[t - 1] = Gc[t - 1] - pb_t; pin(Gc[t - 1]); }
             }
@@ -235,19 +279,35 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             // ---- plane zl-1 is complete ------------------------------------------------------------------
             if (store) {
                 F4 o = Gp[t];
-                if (S == HYBRID) o = s * o;
-                stu(G + (long long)(zl - 1) * g.s_z + (long long)t * g.s_t, voff, o);
+                if (S == HYBRID || CEN) o = s * o;
+                const long long foff = (long long)(zl - 1) * g.s_z + (long long)t * g.s_t;      // uniform
+                if (MODE == 0) {
+                    stu(G + foff, voff, o);
+                } else {
+                    const F4 x0v = ldu(sa.x0 + foff, voff), p = lds_P[t][tid];      // p = x(zl-1)
+                    F4 xo;
+                    float e2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xo.v[i] = p.v[i] - sa.step * ((p.v[i] - x0v.v[i]) + sa.lambda * o.v[i]);
+                        const float e = xo.v[i] - x0v.v[i];
+                        e2 += e * e;
+                    }
+                    stu(sa.x_out + foff, voff, xo);
+                    acc_fid += 0.5 * (double)e2;
+                }
             }
             pin(gn);
             Gp[t] = gn;                      // the slot of the finished plane now carries the start of G(zl+1)
+            lds_P[t][tid] = c;
         }
         __syncthreads();
         // cross-wave row products, rotation of the planes
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             F4 gc = Gc[t];
-            if (UP) gc = gc + m_xup * ye[t][w_up][1][lx];
-            if (DN) gc = gc - m_xdn * ye[t][w_dn][0][lx];
+            if (UP || CEN) gc = gc + m_xup * ye[t][w_up][1][lx];
+            if (DN || CEN) gc = gc - m_xdn * ye[t][w_dn][0][lx];
             Gc[t] = Gp[t];
             Gp[t] = gc;
             C[t] = N[t];
@@ -255,6 +315,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
     }
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0 && threadIdx.y == 0) partials[lid] = acc;
+    if (MODE == 1) {
+        acc_fid = block_sum(acc_fid, sm);
+        if (threadIdx.x == 0 && threadIdx.y == 0) sa.part_fid[lid] = acc_fid;
+    }
 }
 
 }  // namespace tv

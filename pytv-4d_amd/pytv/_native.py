@@ -46,6 +46,8 @@ _SIGNATURES = {
     "tv_subgrad": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [_c_double_p, _c_void_p, _c_void_p]),
     "tv_subgrad_fused_supported": (ctypes.c_int, [_G]),
     "tv_subgrad_fused": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [_c_double_p, _c_void_p, _c_void_p]),
+    "tv_subgrad_step_fused": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p,
+                                                                      _c_void_p, _c_void_p]),
     "tv_cp_dual": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [ctypes.c_double, ctypes.c_double, _c_double_p, _c_void_p, _c_void_p]),
     "tv_cp_primal": (ctypes.c_int, [_G] + [_c_void_p] * 6 + [ctypes.c_double, ctypes.c_double, _c_double_p, _c_void_p, _c_void_p]),
     "tv_cp_fused_supported": (ctypes.c_int, [_G]),

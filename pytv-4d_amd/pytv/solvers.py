@@ -356,7 +356,12 @@ class SubgradientDescent(_SlabProblem):
             one_pass = bool(self.lib.tv_subgrad_fused_supported(self.geo.ref)) and \
                 self.geo.plane * self.x0.element_size() >= min_plane
         self.one_pass = bool(one_pass)
+        # one pass: TV, G and the descent step in a single kernel, x ping-ponged (G is never stored); else the
+        # two-pass tv_subgrad + tv_subgrad_step
         self.norms_ext = None if self.one_pass else torch.empty((nz + 2, m, ny, nx), dtype=self.dtype, device=self.device)
+        if self.one_pass:
+            self.x_alt = self.G
+            self.G = None
         self.ws = self.geo.workspace()
         self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
         sh = self.plan.on
@@ -371,11 +376,13 @@ class SubgradientDescent(_SlabProblem):
         s.wait(self.plan.exchange_image2(x, self.xh_prev, self.xh_next))
         g = self.geo
         if self.one_pass:
-            _nv.check(self.lib.tv_subgrad_fused(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.G),
-                                                out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
-        else:
-            _nv.check(self.lib.tv_subgrad(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.G),
-                                          _nv.ptr(self.norms_ext), out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+            _nv.check(self.lib.tv_subgrad_step_fused(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next),
+                                                     _nv.ptr(self.x0), _nv.ptr(self.x_alt), self.step_size, self.reg,
+                                                     out[0:1].data_ptr(), out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
+            self.x, self.x_alt = self.x_alt, self.x
+            return
+        _nv.check(self.lib.tv_subgrad(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.G),
+                                      _nv.ptr(self.norms_ext), out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
         _nv.check(self.lib.tv_subgrad_step(g.ref, _nv.ptr(x), _nv.ptr(self.x0), _nv.ptr(self.G), self.step_size, self.reg,
                                            out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
 

@@ -89,10 +89,9 @@ def test_golden_tv_and_subgradient(pytv, scheme, dtype):
         assert np.array_equal(np.isinf(gn), np.isinf(wgn)), (scheme, name)
         fin = np.isfinite(wgn)
         np.testing.assert_allclose(gn[fin], wgn[fin], **_tol(dtype))
-        # without the norms the shim may take the one-pass kernel (fp32, radius-1 schemes): same values up to the
-        # summation order
+        # without the norms the shim may take the one-pass kernel (fp32): same values up to the summation order
         tv2, G2 = getattr(pytv.tv_GPU, "tv_" + scheme)(x.copy(), **kw)
-        if dtype == np.float32 and scheme != "central":
+        if dtype == np.float32:
             np.testing.assert_allclose(G2, wG, err_msg="G (one pass) %s %s" % (scheme, name), **_tol(dtype))
             np.testing.assert_allclose(float(tv2), wtv, rtol=_tol(dtype)["rtol"])
         else:

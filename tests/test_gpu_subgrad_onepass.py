@@ -13,7 +13,7 @@ from oracle import tv_oracle as orc
 pytestmark = pytest.mark.gpu
 os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
 
-ONE_PASS_SCHEMES = ["upwind", "downwind", "hybrid"]
+ONE_PASS_SCHEMES = ["upwind", "downwind", "hybrid", "central"]
 F32 = dict(rtol=1e-5, atol=1e-5)
 
 
@@ -21,6 +21,12 @@ F32 = dict(rtol=1e-5, atol=1e-5)
 def pytv():
     import pytv
     return pytv
+
+
+def _supported(x, scheme, **kw):
+    from pytv import _native as nv
+    geo = nv.Geometry(tuple(x.shape), scheme, x.dtype, x.device, **kw)
+    return bool(nv.lib().tv_subgrad_fused_supported(geo.ref))
 
 
 def _one_pass(pytv, x, scheme, **kw):
@@ -55,6 +61,9 @@ def test_one_pass_matches_oracle_and_two_pass(pytv, scheme, zchunk, shape, lz, m
     mask = (rng.random(shape[2:]) < 0.4) if use_mask else False
     kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=2.3 if use_mask else 0)
     x = torch.as_tensor(img).cuda()
+    if not _supported(x, scheme, **kw):
+        assert scheme == "central" and (shape[0] == 2 or shape[1] == 2)      # two-point axes: two-pass path only
+        pytest.skip("central with a two-point axis")
     tv1, G1 = _one_pass(pytv, x, scheme, **kw)
     tv_ref, G_ref = orc.tv(img.astype(np.float64), scheme, **kw)
     np.testing.assert_allclose(G1.cpu().numpy(), G_ref, **F32)
@@ -90,7 +99,7 @@ def test_one_pass_on_reference_golden(pytv, scheme):
         np.testing.assert_allclose(G1.cpu().numpy(), wG, err_msg="%s %s" % (scheme, name), **F32)
         assert abs(tv1 - float(wtv)) <= 1e-5 * abs(float(wtv)), (scheme, name)
         done += 1
-    assert done >= 2      # the two fp32 golden cases (8 x 8 frames); the others have Nx % 4 != 0
+    assert done >= 2      # the two fp32 golden cases (8 x 8 frames, M = 4 and 3); the others have Nx % 4 != 0
 
 
 @pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
@@ -105,7 +114,18 @@ def test_one_pass_slab_calls_equal_unsharded(pytv, scheme, cuts, zchunk, monkeyp
     rng = np.random.default_rng(5)
     kw = dict(reg_z_over_reg=1.7, reg_time=0.6)
     x = torch.as_tensor(rng.standard_normal(shape).astype(np.float32)).cuda()
+    x0 = torch.as_tensor(rng.standard_normal(shape).astype(np.float32)).cuda()
     tv_full, G_full = _one_pass(pytv, x, scheme, **kw)
+    # the fused descent step on the unsharded volume: x - step ((x - x0) + lam G)
+    gfull = nv.Geometry(shape, scheme, x.dtype, x.device, **kw)
+    xo_full, tvf, fidf = torch.empty_like(x), gfull.scalar(), gfull.scalar()
+    nv.check(lib.tv_subgrad_step_fused(gfull.ref, nv.ptr(x), None, None, nv.ptr(x0), nv.ptr(xo_full), 0.05, 2.0, nv.ptr(tvf),
+                                       nv.ptr(fidf), nv.ptr(gfull.workspace()), nv.current_stream(x.device)))
+    want = x - 0.05 * ((x - x0) + 2.0 * G_full)
+    assert torch.allclose(xo_full, want, rtol=1e-6, atol=1e-6)
+    assert abs(float(tvf) - tv_full) <= 1e-9 * abs(tv_full)       # another instantiation: the compiler contracts differently
+    assert abs(float(fidf) - 0.5 * float(((xo_full.double() - x0.double()) ** 2).sum())) <= 1e-6 * float(fidf)
+    fid_sum = 0.0
     nzg, st, tv_sum = shape[0], nv.current_stream(x.device), 0.0
     for a, b in zip(cuts[:-1], cuts[1:]):
         g = nv.Geometry((b - a,) + shape[1:], scheme, x.dtype, x.device, nz_global=nzg, z0=a, **kw)
@@ -124,24 +144,34 @@ def test_one_pass_slab_calls_equal_unsharded(pytv, scheme, cuts, zchunk, monkeyp
         nv.check(lib.tv_subgrad_fused(g.ref, nv.ptr(xs), nv.ptr(xp2), nv.ptr(xn2), nv.ptr(G), nv.ptr(tvs), nv.ptr(g.workspace()), st))
         assert torch.equal(G, G_full[a:b]), (scheme, a, b)
         tv_sum += float(tvs)
+        xo, fids = torch.empty_like(xs), g.scalar()
+        nv.check(lib.tv_subgrad_step_fused(g.ref, nv.ptr(xs), nv.ptr(xp2), nv.ptr(xn2), nv.ptr(x0[a:b].contiguous()), nv.ptr(xo),
+                                           0.05, 2.0, nv.ptr(tvs), nv.ptr(fids), nv.ptr(g.workspace()), st))
+        assert torch.equal(xo, xo_full[a:b]), (scheme, a, b)
+        fid_sum += float(fids)
     assert abs(tv_sum - tv_full) <= 1e-12 * abs(tv_full)
+    assert abs(fid_sum - float(fidf)) <= 1e-12 * float(fidf)
 
 
 def test_one_pass_rejects_what_it_does_not_support(pytv):
     import torch
     from pytv import _native as nv
     lib = nv.lib()
-    for shape, scheme, dt in (((2, 1, 8, 64), "central", torch.float32), ((2, 1, 8, 64), "hybrid", torch.float64),
-                              ((2, 1, 8, 66), "hybrid", torch.float32), ((2, 5, 8, 64), "hybrid", torch.float32),
-                              ((2, 1, 8, 7), "downwind", torch.float32),
-                              ((2, 16, 8, 64), "upwind", torch.float32)):
-        g = nv.Geometry(shape, scheme, dt, torch.device("cuda", 0))
-        assert lib.tv_subgrad_fused_supported(g.ref) == 0
+    for shape, scheme, dt, kw in (((2, 1, 8, 64), "central", torch.float32, {}),                       # two-point z axis
+                                  ((3, 2, 8, 64), "central", torch.float32, dict(reg_time=1.0)),       # two-point time axis
+                                  ((2, 1, 8, 64), "hybrid", torch.float64, {}), ((2, 1, 8, 66), "hybrid", torch.float32, {}),
+                                  ((2, 5, 8, 64), "hybrid", torch.float32, {}), ((2, 1, 8, 7), "downwind", torch.float32, {}),
+                                  ((2, 16, 8, 64), "upwind", torch.float32, {})):
+        g = nv.Geometry(shape, scheme, dt, torch.device("cuda", 0), **kw)
+        assert lib.tv_subgrad_fused_supported(g.ref) == 0, (shape, scheme)
         x = torch.zeros(shape, dtype=dt, device="cuda")
         G = torch.empty_like(x)
         rc = lib.tv_subgrad_fused(g.ref, nv.ptr(x), None, None, nv.ptr(G), nv.ptr(g.scalar()), nv.ptr(g.workspace()),
                                   nv.current_stream(x.device))
         assert rc < 0
+    # central with a two-point axis that is switched off is fine
+    g = nv.Geometry((3, 2, 8, 64), "central", torch.float32, torch.device("cuda", 0), reg_time=0.0)
+    assert lib.tv_subgrad_fused_supported(g.ref) == 1
     # a slab without its halos
     g = nv.Geometry((3, 1, 8, 64), "hybrid", torch.float32, torch.device("cuda", 0), nz_global=9, z0=3)
     x = torch.zeros((3, 1, 8, 64), device="cuda")
@@ -175,7 +205,7 @@ def test_one_pass_no_out_of_bounds_access(pytv, scheme):
 @pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
 def test_subgradient_descent_one_pass_equals_two_pass(pytv, scheme):
     import torch
-    shape = (6, 2, 20, 64)
+    shape = (6, 3, 20, 64)
     rng = np.random.default_rng(9)
     x0 = torch.as_tensor((rng.random(shape) * 50).astype(np.float32)).cuda()
     kw = dict(scheme=scheme, reg_z_over_reg=1.0, reg_time=0.5)
