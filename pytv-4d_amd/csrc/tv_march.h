@@ -78,11 +78,13 @@ __device__ __forceinline__ void col_neighbours(const V4& v, const float* p, bool
 // PF: 1 = all M frames of plane z+1 are requested at the top of the z step (M independent loads in flight per wave
 // instead of one exposed latency per frame: the epilogue's stores may alias x as far as the compiler knows, so it never
 // hoists the next frame's load above them); 2 = the halo row of the first / last tile row as well
-template <int S, int M, typename Epi, bool LIGHT = false, int PF = 0>
-__global__ __launch_bounds__(256, LIGHT ? 3 : (PF ? 2 : 1)) void k_D_march(DG g, WT<float> w, const float* __restrict__ x, const float* __restrict__ xp,
+// SINGLE: single-buffered tile with two barriers per plane even without the LIGHT register cap (M = 16: the
+// double-buffered tile would take 128 KiB of LDS and leave one block = one wave per SIMD on the CU)
+template <int S, int M, typename Epi, bool LIGHT = false, int PF = 0, bool SINGLE = (LIGHT || M > 8)>
+__global__ __launch_bounds__(256, LIGHT ? 3 : ((PF || M > 8) ? 2 : 1)) void k_D_march(DG g, WT<float> w, const float* __restrict__ x, const float* __restrict__ xp,
                                                  const float* __restrict__ xn, int zchunk, Epi epi, int hp = 1, int z_first = 0,
                                                  int z_end = -1) {
-    __shared__ V4 tile[LIGHT ? 1 : 2][M][4][64];   // double-buffered: one barrier per z step
+    __shared__ V4 tile[SINGLE ? 1 : 2][M][4][64];   // double-buffered: one barrier per z step
     __shared__ double sm[16];
     const MarchCoord c = march_coord(g, zchunk, z_first, z_end);
     constexpr bool NEXT = (S != DOWNWIND), PREV = (S != UPWIND);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, LIGHT ? 3 : (PF ? 2 : 1)) void k_D_march(DG g,
                 H[t] = (halo_up || halo_dn) ? vload<float, 4>(pc + (long long)t * g.s_t + c.inpl + (halo_up ? -(long long)g.nx : (long long)g.nx)) : zero;
         }
         // publish plane z for the row neighbours
-        const int buf = LIGHT ? 0 : ((z - c.zs) & 1);
+        const int buf = SINGLE ? 0 : ((z - c.zs) & 1);
 #pragma unroll
         for (int t = 0; t < M; ++t) tile[buf][t][c.ty][c.lane] = C[t];
         __syncthreads();
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, LIGHT ? 3 : (PF ? 2 : 1)) void k_D_march(DG g,
         }
         // double-buffered: no second barrier (the other buffer is written next, and it was last read before
         // this step's barrier); single-buffered: everyone must be done reading before the tile is rewritten
-        if (LIGHT) __syncthreads();
+        if (SINGLE) __syncthreads();
     }
     if (Epi::REDUCES) {
         acc = block_sum(acc, sm);
