@@ -351,10 +351,8 @@ class SubgradientDescent(_SlabProblem):
         self.x = self.x0.clone()
         nz, m, ny, nx = self.x0.shape
         self.G = torch.empty_like(self.x0)
-        if one_pass is None:      # TV + G in one pass over x where the geometry allows (tv_subgrad_fused)
-            min_plane = int(os.environ.get("TV_MARCH_MIN_PLANE_KB", "4096")) * 1024
-            one_pass = bool(self.lib.tv_subgrad_fused_supported(self.geo.ref)) and \
-                self.geo.plane * self.x0.element_size() >= min_plane
+        if one_pass is None:      # TV + G + step in one pass over x wherever the geometry allows (tv_subgrad_step_fused)
+            one_pass = bool(self.lib.tv_subgrad_fused_supported(self.geo.ref))
         self.one_pass = bool(one_pass)
         # one pass: TV, G and the descent step in a single kernel, x ping-ponged (G is never stored); else the
         # two-pass tv_subgrad + tv_subgrad_step

@@ -12,8 +12,6 @@ Conventions kept: ``mask`` zeroes the caller's array i
 value is always a 0-d numpy array; G (and grad_norms) are numpy unless ``return_pytorch_tensor``;
 grad_norms has zeros replaced by +inf; the sub-gradient uses unit weights in the adjoint.
 """
-import os
-
 import torch
 
 from . import _native as _nv
@@ -27,11 +25,10 @@ def _has_mask(mask):
     return mask is not None and not isinstance(mask, bool) and len(mask) > 0
 
 
-def one_pass_ok(geo, itemsize):
-    """Use the one-pass kernel (``tv_subgrad_fused``)?  Supported geometry, and planes large enough for the
-    plane-marching kernels to pay (same threshold and override, TV_MARCH_MIN_PLANE_KB, as the solvers)."""
-    min_plane = int(os.environ.get("TV_MARCH_MIN_PLANE_KB", "4096")) * 1024
-    return bool(_nv.lib().tv_subgrad_fused_supported(geo.ref)) and geo.plane * itemsize >= min_plane
+def one_pass_ok(geo, itemsize=4):
+    """Use the one-pass kernel (``tv_subgrad_fused``)?  Whenever the geometry is supported: it is as fast as or
+    faster than the two-pass kernels from 512 x 512 2-D images to the north-star volume (tools/sg_small_bench.py)."""
+    return bool(_nv.lib().tv_subgrad_fused_supported(geo.ref))
 
 
 def tv_subgradient_device(x, scheme, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0,

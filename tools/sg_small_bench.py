@@ -1,0 +1,21 @@
+import sys, os, time
+sys.path.insert(0, "pytv-4d_amd"); sys.path.insert(0, ".")
+import torch, pytv
+def bench(f, reps=20):
+    f(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+for shape in [(1,1,512,512), (1,1,2048,2048), (256,1,512,512), (128,8,512,512), (64,1,1024,1024), (16,4,256,256), (32,2,1024,1024)]:
+    x = torch.rand(shape, device="cuda") * 100
+    for scheme in ("hybrid", "upwind"):
+        kw = dict(reg_time=1.0 if shape[1] > 1 else 0.0)
+        t1 = bench(lambda: pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=False, one_pass=True, **kw))
+        os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+        t2m = bench(lambda: pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=True, one_pass=False, **kw))
+        os.environ["TV_MARCH_MIN_PLANE_KB"] = "1000000"
+        t2g = bench(lambda: pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=True, one_pass=False, **kw))
+        os.environ.pop("TV_MARCH_MIN_PLANE_KB")
+        print("%-20s %-8s one-pass %.3f ms | two-pass marching %.3f | two-pass generic %.3f" % (shape, scheme, t1, t2m, t2g))
