@@ -384,13 +384,50 @@ class SubgradientDescent(_SlabProblem):
         _nv.check(self.lib.tv_subgrad_step(g.ref, _nv.ptr(x), _nv.ptr(self.x0), _nv.ptr(self.G), self.step_size, self.reg,
                                            out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
 
-    def run(self, n_iter):
+    GRAPH_BLOCK = 10            # iterations captured per hipGraph (even: the x ping-pong returns to its start)
+    GRAPH_MAX_VOXELS = 1 << 23  # below this an iteration is launch-bound (a few tens of microseconds of kernels)
+
+    def run(self, n_iter, graph=None):
+        """n_iter iterations; returns the README's loss history (README.md:124).  graph: None = replay blocks of
+        GRAPH_BLOCK iterations from a hipGraph when the problem is small enough to be launch-bound and not sharded
+        (the README's own 2-D example is), True / False force it."""
         hist = torch.zeros((n_iter, 2), dtype=torch.float64, device=self.device)
-        for it in range(n_iter):
+        use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS) if graph is None else bool(graph)
+        start = 0
+        if use_graph and not self.slab.sharded and n_iter >= 2 + 2 * self.GRAPH_BLOCK:
+            self.step(hist[0])
+            self.step(hist[1])
+            start = 2 + self._run_graphed_from(hist, 2, n_iter)
+        for it in range(start, n_iter):
             self.step(hist[it])
         self.slab.allreduce_sum_(hist)
         h = hist.cpu().numpy()
         return h[:, 1] + self.reg * h[:, 0]
+
+    def _run_graphed_from(self, hist, first, n_iter):
+        """Capture GRAPH_BLOCK iterations (not executed during capture) and replay them over hist[first:]."""
+        K = self.GRAPH_BLOCK
+        nrep = (n_iter - first) // K
+        if nrep < 1:
+            return 0
+        x_ref, xalt_ref = self.x, getattr(self, "x_alt", None)
+        try:
+            buf = torch.zeros((K, 2), dtype=torch.float64, device=self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for k in range(K):
+                    self.step(buf[k])
+        except Exception:
+            self.x = x_ref                                 # nothing ran: undo the bookkeeping, stay eager
+            if xalt_ref is not None:
+                self.x_alt = xalt_ref
+            return 0
+        done = 0
+        for r in range(nrep):
+            graph.replay()
+            hist[first + done:first + done + K].copy_(buf)
+            done += K
+        return done
 
     def result(self):
         return self.x

@@ -231,3 +231,16 @@ def test_one_pass_error_on_the_readme_input_is_at_the_fp32_floor(pytv, scheme):
     tv1, G1 = _one_pass(pytv, torch.as_tensor(img).cuda(), scheme, **kw)
     assert np.abs(G1.cpu().numpy() - G_ref).max() < 3e-6
     assert abs(tv1 - float(tv_ref)) < 1e-7 * float(tv_ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_subgradient_descent_graph_replay_equals_eager(pytv, dtype):
+    """Small problems replay blocks of 10 iterations from a hipGraph: same trajectory as the eager loop."""
+    import torch
+    rng = np.random.default_rng(4)
+    x0 = torch.as_tensor((rng.random((1, 1, 64, 64)) * 100).astype(dtype)).cuda()
+    a = pytv.solvers.SubgradientDescent(x0, 25.0, 5e-3)
+    b = pytv.solvers.SubgradientDescent(x0, 25.0, 5e-3)
+    la, lb = a.run(47, graph=True), b.run(47, graph=False)
+    assert np.array_equal(la, lb)
+    assert torch.equal(a.result(), b.result())
