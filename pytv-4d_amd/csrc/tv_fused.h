@@ -197,13 +197,25 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         const bool has_pz = PREV && g.za && (gz > 0);
         const bool has_nz = NEXT && g.za && (pn != nullptr);
         const bool load_next = (pn != nullptr) && c.ok && (has_nz || (z + 1 < c.ze));
+        // upwind / central: x(z+1) feeds the forward z difference of THIS plane, so a load issued inside the frame
+        // would be one exposed latency per frame with only 1 + Nd = 5 streams in flight per wave -- request all M
+        // frames of plane z+1 here instead (these two schemes have the registers for it; hybrid has 1 + 8 streams
+        // per frame and no registers left; downwind needs x(z+1) only one plane later)
+        constexpr bool PFN = (S == UPWIND || S == CENTRAL);
+        F4 Nn[PFN ? M : 1];
+        if (PFN) {
+#pragma unroll
+            for (int t = 0; t < M; ++t) Nn[t] = load_next ? ldu(pn + (long long)t * g.s_t, voff) : zero;
+        }
         F4 cold = zero;        // x(z, t-1)
         F4 ut_prev = zero;     // wt * q'_tup(z, t-1) * mf, already valid-masked
         F4 r_prev = zero;      // accumulator of frame t-1 of THIS plane, still missing its time-down term
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const long long toff = (long long)t * g.s_t;                          // uniform
-            const F4 N = load_next ? ldu(pn + toff, voff) : zero;
+            F4 N;
+            if constexpr (PFN) N = Nn[t];
+            else N = load_next ? ldu(pn + toff, voff) : zero;
             // ------------------------------------------------ neighbourhood of x(z, t)
             XN<float, 4> n;
             n.c = C[t];
