@@ -25,6 +25,19 @@ namespace tv {
 
 using F4 = Vec<float, 4>;
 
+// Wave tile of the one-sweep CP kernel: CP_TR rows x CP_TL lanes (4 columns each); 4 waves side by side form the
+// block tile (CP_TR rows x CP_BC columns).  Default 4 x 16.  Build with -DTV_FUSED_TR=8 for 8 x 8 tiles: only 2 of 8
+// rows are then tile-edge rows, which halves the row fix-up (3.4 -> 1.7 ms on the north-star volume) and the x halo
+// rows, and the block's footprint (8 rows x 512 B) streams as fast as 4 rows x 1 KiB (tools/bwtest.hip) -- but the
+// block tile is 128 columns wide instead of 256, the sparse column-edge fix-up goes from 0.5 to 2.1 ms and the sweep
+// gains nothing (33.8 vs 33.5 ms): measured, not adopted.
+#ifndef TV_FUSED_TR
+#define TV_FUSED_TR 4
+#endif
+constexpr int CP_TR = TV_FUSED_TR, CP_TL = 64 / CP_TR, CP_WC = 4 * CP_TL, CP_BC = 4 * CP_WC;
+constexpr int CP_LSH = (CP_TL == 16) ? 4 : 3;
+static_assert(CP_TR == 4 || CP_TR == 8, "wave tile: 4 x 16 or 8 x 8");
+
 struct FusedCoord {
     int lane, row, lx, col0, y, zs, ze;
     bool ok;
@@ -49,17 +62,36 @@ __device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk, int c
     return c;
 }
 
+// coordinates of the one-sweep CP kernel: block (64, 4), wave = threadIdx.y covers columns [CP_WC w, CP_WC (w + 1))
+// of a CP_TR-row x CP_BC-column block tile
+__device__ __forceinline__ FusedCoord cp_coord(const DG& g, int zchunk, int chunk0) {
+    FusedCoord c;
+    c.lane = (int)threadIdx.x;
+    c.row = c.lane >> CP_LSH;
+    c.lx = c.lane & (CP_TL - 1);
+    const int nxv = g.nx / 4;
+    const int tiles_x = (nxv + 4 * CP_TL - 1) / (4 * CP_TL);
+    const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
+    c.col0 = (bx * 4 * CP_TL + (int)threadIdx.y * CP_TL + c.lx) * 4;
+    c.y = by * CP_TR + c.row;
+    c.ok = (c.col0 < g.nx) && (c.y < g.ny);
+    c.zs = ((int)blockIdx.y + chunk0) * zchunk;
+    c.ze = (c.zs + zchunk < g.nz) ? c.zs + zchunk : g.nz;
+    c.inpl = (long long)c.y * g.nx + c.col0;
+    return c;
+}
+
 // does the sweep leave a term of this site-vector to the fix-up kernel?  (shared by both kernels)
 // (central: the adjoint of every channel reaches both ways, so it counts as "up" and "down" here)
 template <int S, bool XW>
 __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, int col0, int zchunk) {
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND);
-    constexpr int CM = XW ? 255 : 63;          // column period of the tiles whose edges are left to the fix-up
+    constexpr int CM = XW ? CP_BC - 1 : CP_WC - 1;   // column period of the tiles whose edges are left to the fix-up
     bool f = false;
     // rows: every wave tile (4 rows); columns: only the 256-column BLOCK tile edges -- the four waves
     // of a block hand their edge columns to each other through LDS inside the sweep
-    if (UP) f = f || ((y & 3) == 0 && y >= 1) || ((col0 & CM) == 0 && col0 >= 1);
-    if (DN) f = f || ((y & 3) == 3 && y <= g.ny - 2) || ((col0 & CM) == CM - 3 && col0 + 4 <= g.nx - 1);
+    if (UP) f = f || ((y & (CP_TR - 1)) == 0 && y >= 1) || ((col0 & CM) == 0 && col0 >= 1);
+    if (DN) f = f || ((y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - 2) || ((col0 & CM) == CM - 3 && col0 + 4 <= g.nx - 1);
     if (g.za) {
         const int gz = g.z0 + zl;
         const int zs = (zl / zchunk) * zchunk;
@@ -95,6 +127,20 @@ __device__ __forceinline__ F4 shfl_down16(const F4& v) {
     return r;
 }
 
+// the same one row of the CP wave tile up / down (CP_TL lanes)
+__device__ __forceinline__ F4 cp_shfl_up(const F4& v) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_up(v.v[i], CP_TL, 64);
+    return r;
+}
+__device__ __forceinline__ F4 cp_shfl_down(const F4& v) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_down(v.v[i], CP_TL, 64);
+    return r;
+}
+
 struct FusedArgs {
     const float* x_in;
     const float* xp;      // plane z0-1 of x_in (or nullptr)
@@ -112,7 +158,7 @@ struct FusedArgs {
 template <int S, int M, bool XW>
 __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk, int chunk0) {
     __shared__ double sm[16];
-    const FusedCoord c = fused_coord(g, zchunk, chunk0);
+    const FusedCoord c = cp_coord(g, zchunk, chunk0);
     const unsigned voff = (unsigned)c.inpl * 4u;          // byte offset of this lane's vector inside a frame (frames <= 2^30 px)
     const unsigned row_bytes = (unsigned)g.nx * 4u;
     // UP: some channel's adjoint takes y^(p-e) (forward differences; central: every channel); DN: ... y^(p+e).
@@ -133,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
     // column terms that cross the 64-column wave tiles INSIDE the block: each wave publishes, per plane and
     // frame, the col-up value of its last column and the col-down value of its first column (per row);
     // the neighbouring wave adds them one plane later (after the per-plane barrier), double-buffered
-    __shared__ float edge_cu[XW ? 2 : 1][XW ? M : 1][4][4];
-    __shared__ float edge_cd[XW ? 2 : 1][XW ? M : 1][4][4];
+    __shared__ float edge_cu[XW ? 2 : 1][XW ? M : 1][4][CP_TR];
+    __shared__ float edge_cd[XW ? 2 : 1][XW ? M : 1][4][CP_TR];
     // edge_flag[w] = number of planes of this chunk whose edge columns wave w has published.  A wave starts
     // plane z only after both neighbours published plane z-1, so neighbouring waves stay within one plane of
     // each other (that is what makes two buffers enough) -- a pairwise hand-off, not a block-wide barrier.
@@ -164,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         const int eb = (zf - c.zs) & 1;
         if (XW) {
             if (UP && c.lx == 0 && wave > 0) racc.v[0] += edge_cu[eb][t][wave - 1][c.row];
-            if (DN && c.lx == 15 && wave < 3) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
+            if (DN && c.lx == CP_TL - 1 && wave < 3) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
         }
         const long long foff = (long long)zf * g.s_z + (long long)t * g.s_t;      // uniform
         const F4 x0v = ldu(a.x0 + foff, voff), pv = ldu(a.p + foff, voff);
@@ -224,28 +270,28 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             n.h_nr = n.h_pr = n.h_nz = n.h_pz = n.h_nt = n.h_pt = false;
             {   // halo rows of the wave tile: one predicated load (row 0 lanes read y-1, row 3 lanes y+1)
                 const bool want_up = PREV && (c.row == 0) && c.ok && (c.y > 0);
-                const bool want_dn = NEXT && (c.row == 3) && c.ok && (c.y + 1 < g.ny);
+                const bool want_dn = NEXT && (c.row == CP_TR - 1) && c.ok && (c.y + 1 < g.ny);
                 F4 halo = zero;
                 if (want_up || want_dn) halo = ldu(pc + toff, want_up ? voff - row_bytes : voff + row_bytes);
                 if (NEXT) {
                     n.h_nr = c.ok && (c.y + 1 < g.ny);
-                    const F4 sdn = shfl_down16(C[t]);
-                    n.nr = (c.row == 3) ? halo : sdn;
+                    const F4 sdn = cp_shfl_down(C[t]);
+                    n.nr = (c.row == CP_TR - 1) ? halo : sdn;
                 }
                 if (PREV) {
                     n.h_pr = c.ok && (c.y > 0);
-                    const F4 sup = shfl_up16(C[t]);
+                    const F4 sup = cp_shfl_up(C[t]);
                     n.pr = (c.row == 0) ? halo : sup;
                 }
             }
             {   // columns: adjacent lane inside the 16-lane row segment, one scalar at the segment edges
                 const bool le = PREV && (c.lx == 0) && c.ok && (c.col0 > 0);
-                const bool re = NEXT && (c.lx == 15) && c.ok && (c.col0 + 4 < g.nx);
+                const bool re = NEXT && (c.lx == CP_TL - 1) && c.ok && (c.col0 + 4 < g.nx);
                 float edge = 0.f;
                 if (le || re) edge = ldu1(pc + toff, le ? voff - 4u : voff + 16u);
                 if (NEXT) {
                     const float sh = __shfl_down(C[t].v[0], 1, 64);
-                    n.nc = shift_left<float, 4>(C[t], (c.lx == 15) ? edge : sh);
+                    n.nc = shift_left<float, 4>(C[t], (c.lx == CP_TL - 1) ? edge : sh);
                 }
                 if (PREV) {
                     const float sh = __shfl_up(C[t].v[3], 1, 64);
@@ -324,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
                     if (z_fwd) r = r - qzu;                           // ... except on its two-point axes)
                     if (t_fwd) r = r - qtu;
                 }
-                const F4 above = shfl_up16(qru);                      // q'_rowup of the row above
+                const F4 above = cp_shfl_up(qru);                      // q'_rowup of the row above
                 if (c.row > 0) r = r + above;
                 const float lft = __shfl_up(qcu.v[3], 1, 64);         // q'_colup one column to the left
                 r = r + shift_right<float, 4>(qcu, (c.lx == 0) ? 0.f : lft);
@@ -337,15 +383,15 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             }
             if (DN) {
                 if (!CEN) r = r + qrd + qcd + qzd + qtd;
-                const F4 below = shfl_down16(qrd);                    // q'_rowdown of the row below
-                if (c.row < 3) r = r - below;
+                const F4 below = cp_shfl_down(qrd);                    // q'_rowdown of the row below
+                if (c.row < CP_TR - 1) r = r - below;
                 const float rgt = __shfl_down(qcd.v[0], 1, 64);       // q'_coldown one column to the right
-                r = r - shift_left<float, 4>(qcd, (c.lx == 15) ? 0.f : rgt);
+                r = r - shift_left<float, 4>(qcd, (c.lx == CP_TL - 1) ? 0.f : rgt);
                 r_prev = r_prev - qtd;                                // time-down term of frame t-1
             }
             if (XW) {
                 const int eb = (z - c.zs) & 1;
-                if (UP && c.lx == 15) edge_cu[eb][t][wave][c.row] = qcu.v[3];
+                if (UP && c.lx == CP_TL - 1) edge_cu[eb][t][wave][c.row] = qcu.v[3];
                 if (DN && c.lx == 0) edge_cd[eb][t][wave][c.row] = qcd.v[0];
             }
             if (t > 0) lds_R[(t > 0) ? t - 1 : 0][tid] = r_prev;     // frame t-1 is complete up to its z+1 term
@@ -392,7 +438,7 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, co
                                              int col0) {
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
     if (!fused_needs_fixup<S, XW>(g, zl, y, col0, zchunk)) return 0.0;
-    constexpr int CM = XW ? 255 : 63;
+    constexpr int CM = XW ? CP_BC - 1 : CP_WC - 1;
     const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
     const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
     const bool z_fwd = CEN && g.z_two;
@@ -401,8 +447,8 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, co
     const F4 zero = vsplat<float, 4>(0.f);
     F4 m = zero;
     // a missing term counts only where the neighbour's channel is defined (central: interior points of the axis)
-    if (UP && (y & 3) == 0 && y >= (CEN ? 2 : 1)) m = m + vload<float, 4>(qb + (long long)c_ru * g.s_z - g.nx);
-    if (DN && (y & 3) == 3 && y <= g.ny - (CEN ? 3 : 2)) m = m - vload<float, 4>(qb + (long long)c_rd * g.s_z + g.nx);
+    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + vload<float, 4>(qb + (long long)c_ru * g.s_z - g.nx);
+    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - vload<float, 4>(qb + (long long)c_rd * g.s_z + g.nx);
     if (UP && (col0 & CM) == 0 && col0 >= (CEN ? 2 : 1)) m.v[0] += qb[(long long)c_cu * g.s_z - 1];
     if (DN && (col0 & CM) == CM - 3 && col0 + 4 <= g.nx - (CEN ? 2 : 1)) m.v[3] -= qb[(long long)c_cd * g.s_z + 4];
     if (g.za) {
@@ -436,7 +482,7 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, co
 // is row y one of the rows whose every vector misses a row term ("fix-up rows")?
 template <int S> __device__ __forceinline__ bool is_fix_row(const DG& g, int y) {
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND);
-    return (UP && (y & 3) == 0 && y >= 1) || (DN && (y & 3) == 3 && y <= g.ny - 2);
+    return (UP && (y & (CP_TR - 1)) == 0 && y >= 1) || (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - 2);
 }
 // is local plane zl a z-chunk edge plane with a missing z term?
 template <int S> __device__ __forceinline__ bool is_fix_plane(const DG& g, int zl, int zchunk) {
@@ -466,8 +512,9 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
         const int bx = (int)blockIdx.x % tiles_x, grp = (int)blockIdx.x / tiles_x;
         const int ty = (int)threadIdx.y;
         int y;
-        if (S == HYBRID || S == CENTRAL) y = grp * 8 + ((ty & 1) ? 3 : 0) + ((ty & 2) ? 4 : 0);      // rows 8k + {0, 3, 4, 7}
-        else y = grp * 16 + 4 * ty + (S == DOWNWIND ? 3 : 0);                         // rows 16k + 4j (+3)
+        // hybrid / central: first and last row of two consecutive wave tiles; up / down: one row of four tiles
+        if (S == HYBRID || S == CENTRAL) y = grp * 2 * CP_TR + ((ty & 1) ? CP_TR - 1 : 0) + ((ty & 2) ? CP_TR : 0);
+        else y = grp * 4 * CP_TR + CP_TR * ty + (S == DOWNWIND ? CP_TR - 1 : 0);
         const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
         if (col0 < g.nx && y < g.ny && is_fix_row<S>(g, y))
             acc = fixup_site<S, XW>(g, w, a, zchunk, zb + (int)blockIdx.z, (int)blockIdx.y, y, col0);
@@ -484,8 +531,8 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
             !is_fix_row<S>(g, y))
             acc = fixup_site<S, XW>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
     } else {
-        // candidates per row: vectors starting at 256 j (left edge of a block tile) and 256 j + 252 (right edge)
-        constexpr int TW = XW ? 256 : 64;
+        // candidates per row: the first and the last vector of every block tile (XW) / wave tile
+        constexpr int TW = XW ? CP_BC : CP_WC;
         const int ntile = (g.nx + TW - 1) / TW, ncand = 2 * ntile;
         const long long idx = (long long)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;
         const int zl = zb + (int)blockIdx.z;

@@ -77,6 +77,11 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
         if (int rc = check_x_halos(g, d, first ? x_prev : (const void*)x_in, last ? x_next : (const void*)x_in)) return rc;
     }
     LC lc = march_cfg(d, zc);
+    {   // block tile of the sweep: CP_TR rows x CP_BC columns (tv_fused.h)
+        const long long tx = (d.nx / 4 + 4 * CP_TL - 1) / (4 * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
+        lc.grid.x = (unsigned)(tx * ty);
+        lc.nblocks = tx * ty * lc.grid.y;
+    }
     const long long nch = lc.grid.y;
     if (chunk_count < 0) { chunk_begin = 0; chunk_count = nch; }
     if (chunk_begin < 0 || chunk_begin + chunk_count > nch) return fail(TV_E_ARG, "chunk range outside the slab");
@@ -126,9 +131,10 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     const int chunk_lo = zb / zc, chunk_hi = (zb + zn - 1) / zc;           // chunks intersecting the plane range
     FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau, chunk_lo};
     const long long tiles_x = (d.nx / 4 + 63) / 64, tiles_y = (d.ny + 3) / 4;
-    const long long ngrp = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL) ? (d.ny + 7) / 8 : (d.ny + 15) / 16;
+    const long long ngrp = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL) ? (d.ny + 2 * CP_TR - 1) / (2 * CP_TR)
+                                                                                : (d.ny + 4 * CP_TR - 1) / (4 * CP_TR);
     const bool xw = env_int("TV_FUSED_XW", 1) != 0;
-    const long long ncand = xw ? 2ll * ((d.nx + 255) / 256) : 2ll * ((d.nx + 63) / 64);
+    const long long ncand = xw ? 2ll * ((d.nx + CP_BC - 1) / CP_BC) : 2ll * ((d.nx + CP_WC - 1) / CP_WC);
     const dim3 blk(64, 4, 1);
     const dim3 g0((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)zn);
     const dim3 g1((unsigned)(tiles_x * tiles_y), (unsigned)d.m, (unsigned)(2 * (chunk_hi - chunk_lo + 1)));

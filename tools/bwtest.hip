@@ -20,13 +20,16 @@ __global__ __launch_bounds__(256) void k_write(float4_* __restrict__ b, long lon
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) b[i] = s;
 }
 // marching pattern: block (64,4) owns a 4-row x 256-col tile, marches z in a chunk, M frames, NR read + NW written streams
-template <int M, int NC, bool WR, bool NT, bool BAR>
+// LX: lanes (16-byte vectors) per tile row: 64 -> 4 rows x 1 KiB per block, 32 -> 8 rows x 512 B, 16 -> 16 rows x 256 B
+template <int M, int NC, bool WR, bool NT, bool BAR, int LX = 64>
 __global__ __launch_bounds__(256) void k_march(const float* __restrict__ x, float* __restrict__ q, int nz, int ny, int nx, int zchunk) {
     __shared__ float4_ tile[BAR ? M * 256 : 1];
-    const int lane = threadIdx.x, ty = threadIdx.y;
-    const int tiles_x = nx / 256;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int lane = tid % LX, ty = tid / LX;
+    constexpr int BH = 256 / LX;
+    const int tiles_x = nx / (LX * 4);
     const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-    const long long inpl = (long long)(by * 4 + ty) * nx + (bx * 64 + lane) * 4;
+    const long long inpl = (long long)(by * BH + ty) * nx + (bx * LX + lane) * 4;
     const long long s_t = (long long)ny * nx, s_z = s_t * M, s_dz = s_z * NC;
     const int zs = blockIdx.y * zchunk, ze = min(zs + zchunk, nz);
     float4_ acc = {0, 0, 0, 0};
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(256) void k_march(const float* __restrict__ x, floa
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const float4_ xv = *(const float4_*)(x + (long long)z * s_z + t * s_t + inpl);
-            if (BAR) tile[t * 256 + ty * 64 + lane] = xv;
+            if (BAR) tile[t * 256 + tid] = xv;
             float4_ v[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void k_march(const float* __restrict__ x, floa
                 else acc += r;
             }
         }
-        if (BAR) { __syncthreads(); acc += tile[((ty + 1) & 3) * 64 + lane]; __syncthreads(); }
+        if (BAR) { __syncthreads(); acc += tile[(tid + 64) & 255]; __syncthreads(); }
     }
     if (acc.x == 1.2345f) q[0] = acc.y;
 }
@@ -110,6 +113,12 @@ int main(int argc, char** argv) {
         printf("march r/w + LDS tile + 2 barriers     : %.2f ms  %.0f GB/s\n", ms, b_rw / ms / 1e6);
         ms = timeit([&] { hipLaunchKernelGGL((k_march<8, 8, false, false, false>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
         printf("march read only (1+8 streams)         : %.2f ms  %.0f GB/s\n", ms, b_r / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL((k_march<8, 8, true, false, false, 32>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
+        printf("march r/w, block tile 8 rows x 512 B  : %.2f ms  %.0f GB/s\n", ms, b_rw / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL((k_march<8, 8, true, false, false, 16>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
+        printf("march r/w, block tile 16 rows x 256 B : %.2f ms  %.0f GB/s\n", ms, b_rw / ms / 1e6);
+        ms = timeit([&] { hipLaunchKernelGGL((k_march<8, 8, true, false, false, 64>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
+        printf("march r/w, block tile 4 rows x 1 KiB  : %.2f ms  %.0f GB/s\n", ms, b_rw / ms / 1e6);
     }
     {
         dim3 grid((nx / 256) * (ny / 4), M, nz), blk(64, 4);
