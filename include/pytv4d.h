@@ -55,6 +55,11 @@ typedef struct tv_geom {
     double  reg_time;           /* time weight; time axis active iff m > 1 and this > 0      */
     double  factor_reg_static;  /* time channels scaled by sqrt(this) where mask_static != 0 */
     const uint8_t* mask_static; /* device, ny*nx bytes, or NULL (the reference's `False`)    */
+    const void* time_factor;    /* device, ny*nx elements of `dtype`, or NULL: per-pixel multiplier f(y,x) of the
+                                 * time channels, i.e. f^2 is a per-pixel weight on reg_time.  Generalises
+                                 * (mask_static, factor_reg_static), which is f = mask ? sqrt(factor) : 1 -- the
+                                 * "weight matrix" of the reference's to-do list (README.md:258); both may be set,
+                                 * the factors multiply */
 } tv_geom;
 
 /* ---- housekeeping ------------------------------------------------------------------------ */

@@ -144,9 +144,24 @@ def _axes_and_weights(img_shape, reg_z_over_reg, reg_time, scheme):
 
 
 def _mask_array(mask_static):
+    """bool mask (the reference's semantics), or -- BUILD EXTENSION, the reference's to-do README.md:258 -- a FLOAT
+    array: the per-pixel weight of the time regularisation; then the time channels are multiplied by sqrt(weight) and
+    factor_reg_static is ignored.  weight = where(mask, factor, 1) is the reference's boolean case."""
     if isinstance(mask_static, bool):
         return None
-    return np.asarray(mask_static, dtype=bool)
+    m = np.asarray(mask_static)
+    if np.issubdtype(m.dtype, np.floating):
+        return m
+    return m.astype(bool)
+
+
+def _time_scaled(c, mask, sqrt_factor):
+    """time channel / time part of the adjoint, scaled per pixel (tv_operators_CPU.py:148-150,428-446)"""
+    if mask is None:
+        return c
+    if np.issubdtype(mask.dtype, np.floating):
+        return c * np.broadcast_to(np.sqrt(mask), c.shape).astype(c.dtype)
+    return np.where(np.broadcast_to(mask, c.shape), c * sqrt_factor, c)
 
 
 # --------------------------------------------------------------------------------------------
@@ -167,7 +182,7 @@ def D(img, scheme, reg_z_over_reg=1.0, reg_time=0, mask_static=False, factor_reg
                 c = w * c
             if axis == _AX_T and mask is not None:
                 # time channel(s) scaled where the static mask is set (tv_operators_CPU.py:148-150)
-                c = np.where(np.broadcast_to(mask, c.shape), c * np.sqrt(factor_reg_static), c)
+                c = _time_scaled(c, mask, np.sqrt(factor_reg_static))
             chans.append(c)
     if scheme == "hybrid":
         # reference channel order: both up channels of the in-plane pair first, then both down
@@ -214,8 +229,7 @@ def _adjoint(y, scheme, z_active, t_active, w_z, w_t, mask, sqrt_factor):
         else:
             out += term
     if time_part is not None:
-        if mask is not None:
-            time_part = np.where(np.broadcast_to(mask, time_part.shape), time_part * sqrt_factor, time_part)
+        time_part = _time_scaled(time_part, mask, sqrt_factor)
         out += time_part
     if scheme == "hybrid":
         return out / np.sqrt(2.0)          # tv_operators_CPU.py:448

@@ -25,6 +25,7 @@ struct DG {
     long long s_z;         // image plane stride      m*ny*nx   (== gradient channel stride)
     long long s_dz;        // gradient plane stride   nd*m*ny*nx
     const uint8_t* mask;   // ny*nx or nullptr
+    const void* tf;        // ny*nx elements of the image dtype (per-pixel time-channel factor) or nullptr
 };
 
 template <typename T> struct WT { T wz, wt, sf; };   // sqrt(reg_z), sqrt(reg_time), sqrt(factor_static)
@@ -137,6 +138,18 @@ __device__ __forceinline__ Vec<T, V> mask_factor(const DG& g, T sf, int y, int c
 #pragma unroll
         for (int i = 0; i < V; ++i) r.v[i] = mp[i] ? sf : T(1);
     }
+    if (g.tf != nullptr) {
+        const T* fp = static_cast<const T*>(g.tf) + (long long)y * g.nx + col0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) r.v[i] *= fp[i];
+    }
+    return r;
+}
+// the same for one pixel
+template <typename T> __device__ __forceinline__ T mask_factor1(const DG& g, T sf, int y, int col) {
+    T r = T(1);
+    if (g.mask != nullptr && g.mask[(long long)y * g.nx + col]) r = sf;
+    if (g.tf != nullptr) r *= static_cast<const T*>(g.tf)[(long long)y * g.nx + col];
     return r;
 }
 

@@ -57,6 +57,7 @@ inline int make_dg(const tv_geom* g, DG& d) {
     d.s_z = d.s_t * g->m;
     d.s_dz = d.s_z * d.nd;
     d.mask = g->mask_static;
+    d.tf = g->time_factor;
     return 0;
 }
 

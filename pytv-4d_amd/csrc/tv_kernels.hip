@@ -181,7 +181,7 @@ __device__ __forceinline__ T dval(const XA<T>& X, const WT<T>& w, int axis, int 
     if (axis == 2) diff = w.wz * diff;
     if (axis == 3) {
         diff = w.wt * diff;
-        if (X.g.mask != nullptr && X.g.mask[(long long)y * X.g.nx + c]) diff *= w.sf;
+        diff *= mask_factor1<T>(X.g, w.sf, y, c);
     }
     if (S == HYBRID) diff *= Consts<T>::inv_sqrt2();
     if (S == CENTRAL) diff *= T(0.5);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_gather(XA<T> X, WT<T> w, const T* norms
                 if (axis == 3) rt += term; else r += term;
             }
         }
-        if (MODE == 1 && g.ta && g.mask != nullptr && g.mask[(long long)y * g.nx + col]) rt *= w.sf;
+        if (MODE == 1 && g.ta) rt *= mask_factor1<T>(g, w.sf, y, col);
         r += rt;
         if (S == HYBRID) r *= Consts<T>::inv_sqrt2();
         if (S == CENTRAL) r *= T(0.5);

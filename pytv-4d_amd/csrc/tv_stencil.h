@@ -261,11 +261,7 @@ template <int S, typename T, int V> struct NormalEpi {
         if (g.za) r = r + wz * (o[5] - o[4]);
         if (g.ta) {
             Vec<T, V> rt = wt * (o[7] - o[6]);                     // the slots already carry one mask factor
-            if (mask != nullptr) {
-                const uint8_t* mp = mask + (long long)c.y * g.nx + c.col0;
-#pragma unroll
-                for (int i = 0; i < V; ++i) rt.v[i] = mp[i] ? rt.v[i] * sf : rt.v[i];
-            }
+            if (mask != nullptr || g.tf != nullptr) rt = rt * mask_factor<T, V>(g, sf, c.y, c.col0);
             r = r + rt;
         }
         Vec<T, V> ov;

@@ -30,6 +30,7 @@ class TvGeom(ctypes.Structure):
         ("scheme", ctypes.c_int32), ("dtype", ctypes.c_int32),
         ("reg_z_over_reg", ctypes.c_double), ("reg_time", ctypes.c_double), ("factor_reg_static", ctypes.c_double),
         ("mask_static", ctypes.c_void_p),
+        ("time_factor", ctypes.c_void_p),
     ]
 
 
@@ -128,11 +129,21 @@ class Geometry:
         self.dtype = dtype
         self.device = torch.device(device)
         self.mask_dev = None
+        self.factor_dev = None
         if not isinstance(mask_static, bool):
             mk = torch.as_tensor(np.asarray(mask_static.detach().cpu()) if isinstance(mask_static, torch.Tensor)
                                  else np.asarray(mask_static))
-            mk = torch.broadcast_to(mk.to(torch.bool), (1, 1, ny, nx)).reshape(ny, nx)
-            self.mask_dev = mk.to(torch.uint8).contiguous().to(self.device)
+            if mk.dtype.is_floating_point:
+                # a FLOAT array is the per-pixel weight map of the time regularisation (the reference's to-do,
+                # README.md:258: "replace mask_static, factor_reg_static with a weight matrix"): the time channels are
+                # multiplied by sqrt(weight); where(mask, factor, 1) reproduces the boolean mask exactly
+                if bool((mk < 0).any()):
+                    raise ValueError("weights must be non-negative")
+                wm = torch.broadcast_to(mk.to(torch.float64), (1, 1, ny, nx)).reshape(ny, nx)
+                self.factor_dev = torch.sqrt(wm).to(dtype).contiguous().to(self.device)
+            else:
+                mk = torch.broadcast_to(mk.to(torch.bool), (1, 1, ny, nx)).reshape(ny, nx)
+                self.mask_dev = mk.to(torch.uint8).contiguous().to(self.device)
         g = TvGeom()
         g.nz, g.m, g.ny, g.nx = nz, m, ny, nx
         g.nz_global = nz if nz_global is None else int(nz_global)
@@ -143,6 +154,7 @@ class Geometry:
         g.reg_time = float(reg_time)
         g.factor_reg_static = float(factor_reg_static)
         g.mask_static = ptr(self.mask_dev)
+        g.time_factor = ptr(self.factor_dev)
         self.c = g
         nd = lib().tv_num_channels(ctypes.byref(g))
         if nd < 0:
