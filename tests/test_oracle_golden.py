@@ -174,3 +174,27 @@ def test_channel_counts():
     assert orc.num_channels("hybrid", 5, 3, 0.0, 1.0) == 6
     assert orc.num_channels("upwind", 5, 3, 1.0, 0.0) == 3
     assert orc.num_channels("central", 1, 3, 1.0, 0.5) == 3
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_weight_map_extension_reduces_to_the_reference_mask(scheme):
+    """BUILD EXTENSION (the reference's to-do, README.md:258): a float ``mask_static`` is a per-pixel weight map of the time
+    regularisation.  W = where(mask, factor, 1) must give the reference's boolean-mask outputs (golden vectors)."""
+    z = np.load(os.path.join(GOLDEN, "ops_%s.npz" % scheme))
+    done = 0
+    for name in z["case_names"]:
+        name = str(name)
+        mask = z[name + "/mask"]
+        if mask.ndim == 0:
+            continue
+        lz, mu, factor = z[name + "/params"]
+        kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=np.where(mask, factor, 1.0))
+        x, y = z[name + "/x"].astype(np.float64), z[name + "/y"].astype(np.float64)
+        tol = 1e-12 if z[name + "/x"].dtype == np.float64 else 1e-5
+        np.testing.assert_allclose(orc.D(x, scheme, **kw), z[name + "/D"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(orc.D_T(y, scheme, **kw), z[name + "/DT"], rtol=tol, atol=tol)
+        tv, G = orc.tv(x, scheme, **kw)
+        np.testing.assert_allclose(tv, z[name + "/tv"], rtol=tol)
+        np.testing.assert_allclose(G, z[name + "/G"], rtol=tol, atol=tol)
+        done += 1
+    assert done >= 2
