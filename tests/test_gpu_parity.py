@@ -777,3 +777,21 @@ def test_no_out_of_bounds_access(pytv, scheme, shape, dtype):
         body = view if name != "norms" else view[1:-1]
         assert bool(torch.isfinite(body).all()), "%s: padding leaked into the result (%s %s)" % (name, scheme, shape)
     assert np.isfinite(float(sc))
+
+
+def test_full_size_config3_on_one_gpu_two_paths_agree(pytv):
+    """BASELINE config 3, (512, 8, 1024, 1024) fp32 = 2^32 voxels with a 2^35-element dual variable, resident on ONE
+    MI355X (192 GiB).  The one-sweep kernels and the dual / primal kernel pair are independent code: the same loss from both
+    beyond 2^32 elements is the 64-bit indexing check at the largest BASELINE size (tools/big_volume_check.py)."""
+    import subprocess
+    import sys
+    import torch
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()               # hand the memory cached by the earlier tests of this process back
+    free, total = torch.cuda.mem_get_info()
+    if free < 215 * 2 ** 30:
+        pytest.skip("needs ~200 GiB of free HBM, %.0f GiB available" % (free / 2 ** 30))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "big_volume_check.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "agree" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
