@@ -3,7 +3,7 @@
 #include "tv_stencil.h"
 #include "tv_fused.h"
 
-static bool fused_m_ok(int m) { return m == 1 || m == 2 || m == 3 || m == 4 || m == 8; }
+static bool fused_m_ok(int m) { return m >= 1 && m <= 8; }
 
 template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
 #define TV_CASE_F(SC)                                              \
@@ -13,6 +13,9 @@ template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
             case 2: return f.template operator()<SC, 2>();         \
             case 3: return f.template operator()<SC, 3>();         \
             case 4: return f.template operator()<SC, 4>();         \
+            case 5: return f.template operator()<SC, 5>();         \
+            case 6: return f.template operator()<SC, 6>();         \
+            case 7: return f.template operator()<SC, 7>();         \
             case 8: return f.template operator()<SC, 8>();         \
         }                                                          \
         break;

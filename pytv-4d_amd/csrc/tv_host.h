@@ -142,7 +142,7 @@ inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
     // small planes (z/t neighbours one plane away stay L2-resident) are served better by the
     // one-site-per-thread kernels: measured on 512x512xM=1 (BASELINE config 1)
     if ((long long)d.s_z * 4 < (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024) return false;
-    return d.m == 1 || d.m == 2 || d.m == 3 || d.m == 4 || d.m == 8 || d.m == 16;
+    return (d.m >= 1 && d.m <= 8) || d.m == 16;
 }
 inline int march_zchunk(const DG& d) {
     // planes per z-chunk: long chunks amortise the chunk prologue (and, for the one-sweep CP kernel, the
@@ -175,6 +175,9 @@ template <typename F> inline int dispatch_sm(int scheme, int m, F&& f) {
             case 2: return f.template operator()<SC, 2>();         \
             case 3: return f.template operator()<SC, 3>();         \
             case 4: return f.template operator()<SC, 4>();         \
+            case 5: return f.template operator()<SC, 5>();         \
+            case 6: return f.template operator()<SC, 6>();         \
+            case 7: return f.template operator()<SC, 7>();         \
             case 8: return f.template operator()<SC, 8>();         \
             case 16: return f.template operator()<SC, 16>();       \
         }                                                          \

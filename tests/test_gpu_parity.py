@@ -163,7 +163,8 @@ def test_random_shapes_all_paths(pytv, scheme, dtype):
             np.testing.assert_allclose(G, wG, err_msg="G %s %s %s" % (scheme, shape, (lz, mu)), **_tol(dtype))
 
 
-MARCH_SHAPES = [(5, 1, 6, 128), (6, 2, 5, 132), (7, 3, 9, 256), (5, 4, 4, 128), (9, 8, 6, 192), (3, 16, 5, 128), (2, 2, 7, 260)]
+MARCH_SHAPES = [(5, 1, 6, 128), (6, 2, 5, 132), (7, 3, 9, 256), (5, 4, 4, 128), (9, 8, 6, 192), (3, 16, 5, 128), (2, 2, 7, 260),
+                (4, 5, 6, 128), (3, 6, 5, 132), (5, 7, 4, 128)]
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
@@ -208,7 +209,7 @@ def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, mo
 
 
 FUSED_SHAPES = [(1, 1, 64, 64), (5, 1, 9, 64), (6, 2, 7, 68), (7, 3, 10, 256), (9, 4, 5, 132), (5, 8, 6, 320), (20, 8, 4, 64),
-                (2, 3, 6, 64), (3, 2, 3, 72)]
+                (2, 3, 6, 64), (3, 2, 3, 72), (4, 5, 6, 64), (3, 6, 9, 132), (5, 7, 5, 72)]
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
@@ -237,8 +238,8 @@ def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, 
             np.testing.assert_allclose(a.result().cpu().numpy(), wx, rtol=1e-5, atol=1e-3, err_msg=msg)
             np.testing.assert_allclose(a.q.cpu().numpy(), b.q.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
             np.testing.assert_allclose(a.p.cpu().numpy(), b.p.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
-    g = nv.Geometry((4, 5, 8, 64), "hybrid", torch.float32, "cuda")
-    assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # M = 5 is not instantiated
+    g = nv.Geometry((4, 9, 8, 64), "hybrid", torch.float32, "cuda")
+    assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # every M <= 8 is instantiated, M = 9 is not
     g = nv.Geometry((4, 4, 8, 64), "central", torch.float64, "cuda")
     assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # fp32 only
 
