@@ -83,6 +83,17 @@ __device__ __forceinline__ FusedCoord cp_coord(const DG& g, int zchunk, int chun
 
 // does the sweep leave a term of this site-vector to the fix-up kernel?  (shared by both kernels)
 // (central: the adjoint of every channel reaches both ways, so it counts as "up" and "down" here)
+// time windows (M > 8): the sweep works on windows of CP_TWN frames; the adjoint terms that cross a window seam
+// are the fix-up's.  Is frame t a seam frame with a missing time term?  (central: the neighbour's channel must be
+// defined, i.e. the neighbour frame must be an interior one)
+constexpr int CP_TWN = 8;
+template <int S> __device__ __forceinline__ bool is_seam_frame(const DG& g, int t) {
+    constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
+    if (g.m <= CP_TWN || !g.ta) return false;
+    const int k = t % CP_TWN;
+    return (UP && k == 0 && t >= 1) || (DN && k == CP_TWN - 1 && t <= g.m - (CEN ? 3 : 2));
+}
+
 template <int S, bool XW>
 __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, int col0, int zchunk) {
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND);
@@ -101,6 +112,13 @@ __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, in
     }
     return f;
 }
+// ... including the time-window seams
+template <int S, bool XW>
+__device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, int col0, int zchunk, int t) {
+    if (is_seam_frame<S>(g, t)) return true;
+    return fused_needs_fixup<S, XW>(g, zl, y, col0, zchunk);
+}
+
 
 // uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: lets the compiler use the scalar-base form of
 // global_load / global_store (one VGPR of address for every stream of the site instead of a 64-bit VGPR pair each)
@@ -155,10 +173,15 @@ struct FusedArgs {
 };
 
 // XW: the four waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
-template <int S, int M, bool XW>
+// TWIN: time windows for volumes with more than CP_TWN frames -- grid z = window, the block works on the frames
+// [t0, t0 + M) of the volume (M = CP_TWN), reads x of the frame on either side of its window for the time differences
+// and leaves the adjoint terms that cross a window seam to the fix-up (exactly like the z-chunk edges)
+template <int S, int M, bool XW, bool TWIN = false>
 __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk, int chunk0) {
     __shared__ double sm[16];
     const FusedCoord c = cp_coord(g, zchunk, chunk0);
+    const int t0 = TWIN ? (int)blockIdx.z * CP_TWN : 0;       // first frame of this block's window
+    const int Mg = TWIN ? g.m : M;                             // frames of the volume
     const unsigned voff = (unsigned)c.inpl * 4u;          // byte offset of this lane's vector inside a frame (frames <= 2^30 px)
     const unsigned row_bytes = (unsigned)g.nx * 4u;
     // UP: some channel's adjoint takes y^(p-e) (forward differences; central: every channel); DN: ... y^(p+e).
@@ -197,8 +220,9 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         const float* pp = (PREV && g.za) ? zplane<float>(g, a.x_in, a.xp, a.xn, 1, c.zs - 1) : nullptr;
 #pragma unroll
         for (int t = 0; t < M; ++t) {
-            C[t] = c.ok ? ldu(pc + (long long)t * g.s_t, voff) : zero;
-            P[t] = (c.ok && pp != nullptr) ? ldu(pp + (long long)t * g.s_t, voff) : zero;
+            const bool fok = c.ok && (t0 + t < Mg);
+            C[t] = fok ? ldu(pc + (long long)(t0 + t) * g.s_t, voff) : zero;
+            P[t] = (fok && pp != nullptr) ? ldu(pp + (long long)(t0 + t) * g.s_t, voff) : zero;
             lds_R[t][tid] = zero;
             lds_U[t][tid] = zero;
         }
@@ -206,13 +230,13 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
 
     // finalise plane zf (its x values are in `xv`), adjoint accumulator `racc` (un-scaled)
     auto finalize = [&](int zf, int t, const F4& xv, F4 racc) {
-        if (!c.ok) return;
+        if (!c.ok || t0 + t >= Mg) return;
         const int eb = (zf - c.zs) & 1;
         if (XW) {
             if (UP && c.lx == 0 && wave > 0) racc.v[0] += edge_cu[eb][t][wave - 1][c.row];
             if (DN && c.lx == CP_TL - 1 && wave < 3) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
         }
-        const long long foff = (long long)zf * g.s_z + (long long)t * g.s_t;      // uniform
+        const long long foff = (long long)zf * g.s_z + (long long)(t0 + t) * g.s_t;      // uniform
         const F4 x0v = ldu(a.x0 + foff, voff), pv = ldu(a.p + foff, voff);
         F4 pn, xo;
         double e2 = 0.0;
@@ -225,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         }
         stu(a.p + foff, voff, pn);
         stu(a.x_out + foff, voff, xo);
-        if (!fused_needs_fixup<S, XW>(g, zf, c.y, c.col0, zchunk)) acc_fid += e2;
+        if (!fused_needs_fixup<S, XW>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += e2;
     };
 
     // wait until the neighbouring waves have published `planes` planes (all waves of a block are resident and
@@ -251,14 +275,16 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         F4 Nn[PFN ? M : 1];
         if (PFN) {
 #pragma unroll
-            for (int t = 0; t < M; ++t) Nn[t] = load_next ? ldu(pn + (long long)t * g.s_t, voff) : zero;
+            for (int t = 0; t < M; ++t) Nn[t] = (load_next && t0 + t < Mg) ? ldu(pn + (long long)(t0 + t) * g.s_t, voff) : zero;
         }
         F4 cold = zero;        // x(z, t-1)
         F4 ut_prev = zero;     // wt * q'_tup(z, t-1) * mf, already valid-masked
         F4 r_prev = zero;      // accumulator of frame t-1 of THIS plane, still missing its time-down term
 #pragma unroll
         for (int t = 0; t < M; ++t) {
-            const long long toff = (long long)t * g.s_t;                          // uniform
+            const int tg = t0 + t;                                                // frame of the volume
+            if (TWIN && tg >= Mg) break;                                          // ragged last window (block-uniform)
+            const long long toff = (long long)tg * g.s_t;                         // uniform
             F4 N;
             if constexpr (PFN) N = Nn[t];
             else N = load_next ? ldu(pn + toff, voff) : zero;
@@ -300,11 +326,13 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             }
             if (NEXT) {
                 n.h_nz = has_nz; n.nz = N;
-                if (t + 1 < M) { n.h_nt = (g.ta != 0); n.nt = C[(t + 1 < M) ? t + 1 : t]; }
+                if (t + 1 < M) { n.h_nt = (g.ta != 0) && (tg + 1 < Mg); n.nt = C[(t + 1 < M) ? t + 1 : t]; }
+                else if (TWIN && g.ta && tg + 1 < Mg) { n.h_nt = true; n.nt = c.ok ? ldu(pc + toff + g.s_t, voff) : zero; }   // across the seam
             }
             if (PREV) {
                 n.h_pz = has_pz; n.pz = P[t];
                 if (t > 0) { n.h_pt = (g.ta != 0); n.pt = cold; }
+                else if (TWIN && g.ta && tg > 0) { n.h_pt = true; n.pt = c.ok ? ldu(pc + toff - g.s_t, voff) : zero; }        // across the seam
             }
             F4 o[8];
             d_slots<S, float, 4>(g, w, n, mf, o);
@@ -346,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
                 for (int i = 0; i < 4; ++i)
                     qcu.v[i] = (c.ok && c.col0 + i < g.nx - 1 && (!CEN || c.col0 + i > 0)) ? v[k_cu].v[i] : 0.f;
                 if (g.za && c.ok && gz + 1 < g.nzg && (!CEN || z_fwd || gz > 0)) qzu = w.wz * v[k_zu];
-                if (g.ta && c.ok && t + 1 < M && (!CEN || t_fwd || t > 0)) qtu = (w.wt * v[k_tu]) * mf;
+                if (g.ta && c.ok && tg + 1 < Mg && (!CEN || t_fwd || tg > 0)) qtu = (w.wt * v[k_tu]) * mf;
             }
             if (DN) {
                 if (c.ok && c.y > 0 && (!CEN || c.y + 1 < g.ny)) qrd = v[k_rd];
@@ -354,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
                 for (int i = 0; i < 4; ++i)
                     qcd.v[i] = (c.ok && c.col0 + i > 0 && (!CEN || c.col0 + i < g.nx - 1)) ? v[k_cd].v[i] : 0.f;
                 if (g.za && c.ok && gz > 0 && (!CEN || (!z_fwd && gz + 1 < g.nzg))) qzd = w.wz * v[k_zd];
-                if (g.ta && c.ok && t > 0 && (!CEN || (!t_fwd && t + 1 < M))) qtd = (w.wt * v[k_td]) * mf;
+                if (g.ta && c.ok && tg > 0 && (!CEN || (!t_fwd && tg + 1 < Mg))) qtd = (w.wt * v[k_td]) * mf;
             }
             // ------------------------------------------------ lagged primal update of plane z-1
             if (z > c.zs) {
@@ -396,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
             }
             if (t > 0) lds_R[(t > 0) ? t - 1 : 0][tid] = r_prev;     // frame t-1 is complete up to its z+1 term
             r_prev = r;
-            if (t == M - 1) lds_R[t][tid] = r;
+            if (t == M - 1 || (TWIN && tg + 1 >= Mg)) lds_R[t][tid] = r;
             cold = C[t];
             P[t] = C[t];
             C[t] = N;
@@ -437,7 +465,7 @@ template <int S, bool XW>
 __device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, const FixupArgs& a, int zchunk, int zl, int t, int y,
                                              int col0) {
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
-    if (!fused_needs_fixup<S, XW>(g, zl, y, col0, zchunk)) return 0.0;
+    if (!fused_needs_fixup<S, XW>(g, zl, y, col0, zchunk, t)) return 0.0;
     constexpr int CM = XW ? CP_BC - 1 : CP_WC - 1;
     const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
     const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
@@ -463,6 +491,14 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, co
             const F4 d = (zl + 1 < g.nz) ? vload<float, 4>(qb + (long long)c_zd * g.s_z + g.s_dz) : vload<float, 4>(a.qn + inpl);
             m = m - w.wz * d;
         }
+    }
+    if (g.ta && g.m > CP_TWN) {      // time-window seams: the neighbouring frame belongs to another window of the sweep
+        const int c_tu = g.ch_t, c_td = (S == HYBRID) ? g.ch_t + 1 : g.ch_t;
+        const int k = t % CP_TWN;
+        F4 mt = zero;
+        if (UP && k == 0 && t >= 1) mt = mt + vload<float, 4>(qb + (long long)c_tu * g.s_z - g.s_t);
+        if (DN && k == CP_TWN - 1 && t <= g.m - (CEN ? 3 : 2)) mt = mt - vload<float, 4>(qb + (long long)c_td * g.s_z + g.s_t);
+        m = m + (w.wt * mt) * mask_factor<float, 4>(g, w.sf, y, col0);
     }
     const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : (CEN ? 0.5f : 1.f);
     const long long off = (long long)zl * g.s_z + inpl;
@@ -516,7 +552,7 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
         if (S == HYBRID || S == CENTRAL) y = grp * 2 * CP_TR + ((ty & 1) ? CP_TR - 1 : 0) + ((ty & 2) ? CP_TR : 0);
         else y = grp * 4 * CP_TR + CP_TR * ty + (S == DOWNWIND ? CP_TR - 1 : 0);
         const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
-        if (col0 < g.nx && y < g.ny && is_fix_row<S>(g, y))
+        if (col0 < g.nx && y < g.ny && is_fix_row<S>(g, y) && !is_seam_frame<S>(g, (int)blockIdx.y))
             acc = fixup_site<S, XW>(g, w, a, zchunk, zb + (int)blockIdx.z, (int)blockIdx.y, y, col0);
     } else if (CLS == 1) {
         const int k = (int)blockIdx.z, chunk = a.chunk0 + (k >> 1);
@@ -528,15 +564,24 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
         const int y = by * 4 + (int)threadIdx.y;
         const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
         if (!dup && zs < g.nz && zl >= zb && zl < zb + zn && col0 < g.nx && y < g.ny && is_fix_plane<S>(g, zl, zchunk) &&
-            !is_fix_row<S>(g, y))
+            !is_fix_row<S>(g, y) && !is_seam_frame<S>(g, (int)blockIdx.y))
             acc = fixup_site<S, XW>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
+    } else if (CLS == 3) {
+        // time-window seam frames (M > CP_TWN): EVERY site of such a frame misses a time term; blockIdx.y counts
+        // the seam frames: windows' first frames (up) and last frames (down), as 2 slots per window
+        const int wdw = (int)blockIdx.y >> 1, t = wdw * CP_TWN + (((int)blockIdx.y & 1) ? CP_TWN - 1 : 0);
+        const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
+        const int y = by * 4 + (int)threadIdx.y;
+        const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
+        if (t < g.m && col0 < g.nx && y < g.ny && is_seam_frame<S>(g, t))
+            acc = fixup_site<S, XW>(g, w, a, zchunk, zb + (int)blockIdx.z, t, y, col0);
     } else {
         // candidates per row: the first and the last vector of every block tile (XW) / wave tile
         constexpr int TW = XW ? CP_BC : CP_WC;
         const int ntile = (g.nx + TW - 1) / TW, ncand = 2 * ntile;
         const long long idx = (long long)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;
         const int zl = zb + (int)blockIdx.z;
-        if (idx < (long long)g.ny * ncand && !is_fix_plane<S>(g, zl, zchunk)) {
+        if (idx < (long long)g.ny * ncand && !is_fix_plane<S>(g, zl, zchunk) && !is_seam_frame<S>(g, (int)blockIdx.y)) {
             const int y = (int)(idx / ncand), cnd = (int)(idx % ncand);
             const int col0 = (cnd >> 1) * TW + ((cnd & 1) ? TW - 4 : 0);
             if (col0 < g.nx && !is_fix_row<S>(g, y)) acc = fixup_site<S, XW>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);

@@ -3,12 +3,14 @@
 #include "tv_stencil.h"
 #include "tv_fused.h"
 
-static bool fused_m_ok(int m) { return m >= 1 && m <= 8; }
+// every M <= 8 has its own instantiation; more frames run as time windows of CP_TWN = 8 frames (tv_fused.h)
+static bool fused_m_ok(int m) { return m >= 1; }
 
 template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
 #define TV_CASE_F(SC)                                              \
     case SC:                                                       \
         switch (m) {                                               \
+            case 0: return f.template operator()<SC, 0>();         \
             case 1: return f.template operator()<SC, 1>();         \
             case 2: return f.template operator()<SC, 2>();         \
             case 3: return f.template operator()<SC, 3>();         \
@@ -25,13 +27,13 @@ template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
 }
 
 namespace tvm {
-bool subgrad_pass2_ok(const tv_geom* g, const DG& d) { return g->scheme != TV_CENTRAL && fused_m_ok(d.m); }
+bool subgrad_pass2_ok(const tv_geom* g, const DG& d) { return g->scheme != TV_CENTRAL && d.m >= 1 && d.m <= 8; }
 int subgrad_pass2(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st,
                   const float* norms_ext, float* G) {
     const int zc = march_zchunk(d);
     const LC lc = march_cfg(d, zc);
     return dispatch_fused(g->scheme, d.m, [&]<int S, int M>() -> int {
-        if constexpr (S != CENTRAL) {
+        if constexpr (S != CENTRAL && M >= 1) {
             hipLaunchKernelGGL((k_subgrad_march<S, M>), lc.grid, lc.block, 0, st, d, make_w<float>(g), (const float*)x,
                                (const float*)xp, (const float*)xn, norms_ext, G, zc);
             HIP_TRY(hipGetLastError());
@@ -49,6 +51,7 @@ int tv_cp_fused_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
     if (g->dtype != TV_F32 || d.nx % 4 != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;
+    if (d.m > CP_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_FUSED", 0)) return 0;
     return 1;
@@ -93,8 +96,11 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
         HIP_TRY(hipMemsetAsync(fid, 0, sizeof(double), st));
         return 0;
     }
+    const int nwin = (d.m > CP_TWN) ? (d.m + CP_TWN - 1) / CP_TWN : 1;      // time windows (grid z)
     lc.grid.y = (unsigned)chunk_count;
-    lc.nblocks = (long long)lc.grid.x * chunk_count;
+    lc.grid.z = (unsigned)nwin;
+    lc.nblocks = (long long)lc.grid.x * chunk_count * nwin;
+    if (lc.nblocks > nmax) return fail(TV_E_ARG, "internal: sweep partials exceed the workspace");
     const int chunk0 = (int)chunk_begin;
     double* w0 = (double*)ws;
     double* w1 = w0 + nmax + kStage + 16;
@@ -102,8 +108,11 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
                 (float*)x_out, (float)sigma_D, (float)(1.0 / lambda), (float)tau, (float)sigma_A,
                 (float)(1.0 / (1.0 + sigma_A)), w0, w1};
     const bool xw = env_int("TV_FUSED_XW", 1) != 0;
-    int rc = dispatch_fused(g->scheme, d.m, [&]<int S, int M>() -> int {
-        if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
+    int rc = dispatch_fused(g->scheme, d.m > CP_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
+        if constexpr (M == 0) {          // M > 8: windows of 8 frames
+            if (xw) hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, true, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
+            else hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, false, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
+        } else if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
         else hipLaunchKernelGGL((k_cp_fused<S, M, false>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -142,14 +151,17 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     const dim3 g0((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)zn);
     const dim3 g1((unsigned)(tiles_x * tiles_y), (unsigned)d.m, (unsigned)(2 * (chunk_hi - chunk_lo + 1)));
     const dim3 g2((unsigned)(((long long)d.ny * ncand + 255) / 256), (unsigned)d.m, (unsigned)zn);
+    const int nwin = (d.m > CP_TWN && d.ta) ? (d.m + CP_TWN - 1) / CP_TWN : 0;     // time-window seams (M > 8)
+    const dim3 g3((unsigned)(tiles_x * tiles_y), (unsigned)(2 * (nwin > 0 ? nwin : 1)), (unsigned)zn);
     const long long n0 = (long long)g0.x * g0.y * g0.z, n1 = d.za ? (long long)g1.x * g1.y * g1.z : 0,
-                    n2 = (long long)g2.x * g2.y * g2.z;
-    if (n0 + n1 + n2 > nmax) return fail(TV_E_ARG, "internal: fix-up partials exceed the workspace");
+                    n2 = (long long)g2.x * g2.y * g2.z, n3 = nwin > 0 ? (long long)g3.x * g3.y * g3.z : 0;
+    if (n0 + n1 + n2 + n3 > nmax) return fail(TV_E_ARG, "internal: fix-up partials exceed the workspace");
     double* w0 = (double*)ws;
     auto launch = [&]<int S, bool XW>() -> int {
         hipLaunchKernelGGL((k_cp_fixup<S, 0, XW>), g0, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0);
         if (d.za) hipLaunchKernelGGL((k_cp_fixup<S, 1, XW>), g1, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0);
         hipLaunchKernelGGL((k_cp_fixup<S, 2, XW>), g2, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0 + n1);
+        if (n3 > 0) hipLaunchKernelGGL((k_cp_fixup<S, 3, XW>), g3, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0 + n1 + n2);
         HIP_TRY(hipGetLastError());
         return 0;
     };
@@ -161,7 +173,7 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
         default: rc = xw ? launch.template operator()<HYBRID, true>() : launch.template operator()<HYBRID, false>(); break;
     }
     if (rc) return rc;
-    return reduce_partials(w0, n0 + n1 + n2, nmax, fid, st);
+    return reduce_partials(w0, n0 + n1 + n2 + n3, nmax, fid, st);
 }
 
 }  // extern "C"

@@ -209,7 +209,8 @@ def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, mo
 
 
 FUSED_SHAPES = [(1, 1, 64, 64), (5, 1, 9, 64), (6, 2, 7, 68), (7, 3, 10, 256), (9, 4, 5, 132), (5, 8, 6, 320), (20, 8, 4, 64),
-                (2, 3, 6, 64), (3, 2, 3, 72), (4, 5, 6, 64), (3, 6, 9, 132), (5, 7, 5, 72)]
+                (2, 3, 6, 64), (3, 2, 3, 72), (4, 5, 6, 64), (3, 6, 9, 132), (5, 7, 5, 72),
+                (3, 16, 5, 64), (4, 12, 6, 68), (3, 9, 4, 64), (2, 24, 4, 64)]     # M > 8: time windows of 8 frames
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
@@ -239,7 +240,9 @@ def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, 
             np.testing.assert_allclose(a.q.cpu().numpy(), b.q.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
             np.testing.assert_allclose(a.p.cpu().numpy(), b.p.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
     g = nv.Geometry((4, 9, 8, 64), "hybrid", torch.float32, "cuda")
-    assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # every M <= 8 is instantiated, M = 9 is not
+    assert nv.lib().tv_cp_fused_supported(g.ref) == 1          # M > 8 runs as time windows of 8 frames
+    g = nv.Geometry((4, 4, 8, 32), "hybrid", torch.float32, "cuda")
+    assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # Nx < 64
     g = nv.Geometry((4, 4, 8, 64), "central", torch.float64, "cuda")
     assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # fp32 only
 
