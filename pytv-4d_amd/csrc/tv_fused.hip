@@ -108,7 +108,11 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
                 (float*)x_out, (float)sigma_D, (float)(1.0 / lambda), (float)tau, (float)sigma_A,
                 (float)(1.0 / (1.0 + sigma_A)), w0, w1};
     const bool xw = env_int("TV_FUSED_XW", 1) != 0;
-    int rc = dispatch_fused(g->scheme, d.m > CP_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
+    // M == 8, hybrid: the windowed instantiation (one window) needs 234 VGPRs and no scratch where the plain one sits at
+    // 256 + 8 B/lane, and is 1 ms faster per sweep on the north-star volume (33.7 vs 34.8 ms); the other schemes are
+    // 2 % faster with the plain one (measured).  TV_FUSED_FORCE_TWIN=0/1 overrides.
+    const bool force_win = (d.m == CP_TWN) && env_int("TV_FUSED_FORCE_TWIN", g->scheme == TV_HYBRID ? 1 : 0);
+    int rc = dispatch_fused(g->scheme, (d.m > CP_TWN || force_win) ? 0 : d.m, [&]<int S, int M>() -> int {
         if constexpr (M == 0) {          // M > 8: windows of 8 frames
             if (xw) hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, true, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
             else hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, false, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
