@@ -27,6 +27,9 @@
 #ifndef SG_X
 #define SG_X 0
 #endif
+#ifndef SG_BREAK_COND
+#define SG_BREAK_COND (MODE == 1 && S == HYBRID)
+#endif
 
 namespace tv {
 
@@ -169,6 +172,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
         F4 f_t_prev = zero;                  // forward time difference of frame t-1 == backward one of frame t
 #pragma unroll
         for (int t = 0; t < M; ++t) {
+            // never taken (g.m == M), but it keeps the compiler from interleaving the frames: the hybrid descent-step
+            // instantiation then needs 254 VGPRs and no scratch instead of 256 + 72 B/lane (69 -> 78 it/s on the north-star
+            // volume); the G-storing instantiations are faster without it (measured)
+            if (SG_BREAK_COND && t >= g.m) break;
             const F4 c = C[t];
             // ---- neighbourhood of x(zl, t) ------------------------------------------------------------
             // row neighbours: inside the wave by a 16-lane shuffle; first / last row of the wave from the neighbouring
