@@ -96,7 +96,7 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
                void* G, void* norms_ext, double* tv, void* ws, void* stream);
 
 /* The same TV value and sub-gradient in ONE pass over x (1/|Dx| never leaves the chip): all four schemes (central:
- * not with a two-point z or time axis), fp32, Nx % 4 == 0, M <= 8, 16-byte aligned arrays
+ * not with a two-point z or time axis), fp32, Nx % 4 == 0, any M (more than 8 frames: overlapping time windows), 16-byte aligned arrays
  * (tv_subgrad_fused_supported).  Use it when the per-voxel norms are not wanted (return_grad_norms=False,
  * pytv/tv_GPU.py:47).  Halos as for tv_subgrad.  A |Dx|^2 below the smallest normal fp32 number counts as 0. */
 int tv_subgrad_fused_supported(const tv_geom* g);

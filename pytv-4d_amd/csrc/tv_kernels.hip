@@ -709,10 +709,25 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
         if (int rc = reduce_partials((double*)ws, nb, nmax, tvout, st)) return rc;
         if (tvm::subgrad_pass2_ok(g, d))
             return tvm::subgrad_pass2(g, d, x, x_prev, x_next, st, (const float*)norms_ext, (float*)G);
-        // central: radius-2 gather, one site per thread
+        // no marching gather for this case (central: radius-2 stencil; M > 8): one site per thread
         LC lg = launch_cfg(d, 4, d.nz);
-        hipLaunchKernelGGL((k_subgrad_central_vec<float, 4>), lg.grid, lg.block, 0, st, d, make_w<float>(g), (const float*)x,
-                           (const float*)x_prev, (const float*)x_next, (const float*)norms_ext, (float*)G);
+        switch (g->scheme) {
+            case TV_UPWIND:
+                hipLaunchKernelGGL((k_subgrad_vec<UPWIND, float, 4>), lg.grid, lg.block, 0, st, d, make_w<float>(g), (const float*)x,
+                                   (const float*)x_prev, (const float*)x_next, (const float*)norms_ext, (float*)G);
+                break;
+            case TV_DOWNWIND:
+                hipLaunchKernelGGL((k_subgrad_vec<DOWNWIND, float, 4>), lg.grid, lg.block, 0, st, d, make_w<float>(g), (const float*)x,
+                                   (const float*)x_prev, (const float*)x_next, (const float*)norms_ext, (float*)G);
+                break;
+            case TV_HYBRID:
+                hipLaunchKernelGGL((k_subgrad_vec<HYBRID, float, 4>), lg.grid, lg.block, 0, st, d, make_w<float>(g), (const float*)x,
+                                   (const float*)x_prev, (const float*)x_next, (const float*)norms_ext, (float*)G);
+                break;
+            default:
+                hipLaunchKernelGGL((k_subgrad_central_vec<float, 4>), lg.grid, lg.block, 0, st, d, make_w<float>(g), (const float*)x,
+                                   (const float*)x_prev, (const float*)x_next, (const float*)norms_ext, (float*)G);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     }

@@ -70,7 +70,13 @@ struct SgStepArgs {
 // one of the previous frame and is carried, not recomputed; 1/|Dx| is one v_rsq_f32.
 // central: ONE channel per axis, d = 1/2 w (x(+e) - x(-e)) on interior points, whose product goes to BOTH neighbours
 // (G(v) = 1/2 sum_a P_a(v-e) - P_a(v+e)); two-point z / t axes (forward stencil) are left to the two-pass path.
-template <int S, int M, int NW, int MODE>
+// TWIN (M == SG_TWN == 8 only): volumes with more than 8 frames.  A block then works on a WINDOW of 8 consecutive frames
+// [t0, t0 + 8) with t0 = 6 w - 1: it computes 1/|Dx| and the products on all 8 (the x frame on either side of the window
+// is read for the time differences of the first / last one) but stores G for the inner 6 only -- the same overlap trick
+// as in y and x, now along time: 8 / 6 of the work, still one pass and no fix-up.
+constexpr int SG_TWN = 8, SG_TWU = SG_TWN - 2;
+
+template <int S, int M, int NW, int MODE, bool TWIN = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, const float* __restrict__ x,
                                                             const float* __restrict__ xp, const float* __restrict__ xn,
                                                             float* __restrict__ G, int zchunk, int nchunks, double* __restrict__ partials,
@@ -92,10 +98,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
     // own L2).  Neighbouring tiles share their ring rows / columns, so every XCD gets a CONTIGUOUS run of tiles:
     // logical id = (id % 8) * per_xcd + id / 8  (grid padded to 8 * per_xcd; the padding blocks leave at once)
     const int tiles_y = (g.ny + UR - 1) / UR;
-    const long long ntiles = (long long)tiles_x * tiles_y, total = ntiles * nchunks, per_xcd = (total + 7) / 8;
+    const int Mg = TWIN ? g.m : M;                                        // frames of the volume
+    const int nwin = TWIN ? (Mg + SG_TWU - 1) / SG_TWU : 1;
+    const long long ntiles = (long long)tiles_x * tiles_y, total = ntiles * nchunks * nwin, per_xcd = (total + 7) / 8;
     const long long lid = (long long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (lid >= total) return;
-    const int chunk = (int)(lid / ntiles), tile = (int)(lid % ntiles);
+    const int win = (int)(lid / (ntiles * nchunks));
+    const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
+    const int t0 = TWIN ? win * SG_TWU - 1 : 0;                           // volume frame of this block's frame 0
+    // is frame t of the block a frame of the volume / one whose G this block stores?
+    auto fvalid = [&](int t) { return !TWIN || (t0 + t >= 0 && t0 + t < Mg); };
+    auto fstore = [&](int t) { return !TWIN || (t0 + t >= win * SG_TWU && t0 + t < win * SG_TWU + SG_TWU && t0 + t < Mg); };
+    auto foff_t = [&](int t) { return (long long)(t0 + t) * g.s_t; };     // uniform
     const int bx = tile % tiles_x, by = tile / tiles_x;
     const int cv = bx * UC - 1 + lx, y = by * UR - 1 + ry, col0 = cv * 4;
     const bool in = (cv >= 0) && (cv < nxv) && (y >= 0) && (y < g.ny);               // site inside the frame
@@ -132,8 +146,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
         const float* pc = zplane<float>(g, x, xp, xn, 2, z_c);
 #pragma unroll
         for (int t = 0; t < M; ++t) {
-            lds_P[t][tid] = (in && pp) ? ldu(pp + (long long)t * g.s_t, voff) : zero;
-            C[t] = (in && pc) ? ldu(pc + (long long)t * g.s_t, voff) : zero;
+            lds_P[t][tid] = (in && pp && fvalid(t)) ? ldu(pp + foff_t(t), voff) : zero;
+            C[t] = (in && pc && fvalid(t)) ? ldu(pc + foff_t(t), voff) : zero;
             Gp[t] = zero;
             Gc[t] = zero;
         }
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
         const bool want_next = (pn != nullptr) && in && (g.za || zl + 1 < ze);
         F4 N[M];
 #pragma unroll
-        for (int t = 0; t < M; ++t) N[t] = want_next ? ldu(pn + (long long)t * g.s_t, voff) : zero;
+        for (int t = 0; t < M; ++t) N[t] = (want_next && fvalid(t)) ? ldu(pn + foff_t(t), voff) : zero;
 #pragma unroll
         for (int t = 0; t < M; ++t)
             if (rr == 0 || rr == 3) xe[t][wv][rr == 3 ? 1 : 0][lx] = C[t];
@@ -165,8 +179,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
         // the barrier: only the first and the last wave have these loads)
         F4 hq[2] = {zero, zero};
         if (HALO && halo_here) {
-            hq[0] = ldu(pc, hoff);
-            if (M > 1) hq[1] = ldu(pc + g.s_t, hoff);
+            if (fvalid(0)) hq[0] = ldu(pc + foff_t(0), hoff);
+            if (M > 1 && fvalid(1)) hq[1] = ldu(pc + foff_t(1), hoff);
         }
         F4 pf_t_prev = zero;                 // product of the time channel of frame t-1 (added to frame t)
         F4 f_t_prev = zero;                  // forward time difference of frame t-1 == backward one of frame t
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             F4 h = zero;
             if (HALO) {
                 h = hq[t & 1];
-                if (halo_here && t + 2 < M) hq[t & 1] = ldu(pc + (long long)(t + 2) * g.s_t, hoff);
+                if (halo_here && t + 2 < M && fvalid(t + 2)) hq[t & 1] = ldu(pc + foff_t(t + 2), hoff);
             }
             if (DN || CEN) {
                 xu = shfl_up16(c);
@@ -209,7 +223,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
                 f_c.v[0] = (ms_c0 * m_row) * (c.v[1] - xl); f_c.v[1] = (ms_in * m_row) * (c.v[2] - c.v[0]);
                 f_c.v[2] = (ms_in * m_row) * (c.v[3] - c.v[1]); f_c.v[3] = (ms_c3 * m_row) * (xr - c.v[2]);
                 f_z = wzn * (N[t] - lds_P[t][tid]);
-                if (t > 0 && t + 1 < M) f_t = (m_row * mft) * (C[(t + 1 < M) ? t + 1 : t] - C[(t > 0) ? t - 1 : 0]);
+                if (!TWIN) {
+                    if (t > 0 && t + 1 < M) f_t = (m_row * mft) * (C[(t + 1 < M) ? t + 1 : t] - C[(t > 0) ? t - 1 : 0]);
+                } else if (t0 + t > 0 && t0 + t + 1 < Mg) {      // interior frame of the volume; window ends: one more x frame
+                    const F4 xn_t = (t + 1 < M) ? C[(t + 1 < M) ? t + 1 : t] : ((in && pc) ? ldu(pc + foff_t(t + 1), voff) : zero);
+                    const F4 xp_t = (t > 0) ? C[(t > 0) ? t - 1 : 0] : ((in && pc) ? ldu(pc + foff_t(t - 1), voff) : zero);
+                    f_t = (m_row * mft) * (xn_t - xp_t);
+                }
             } else {
                 f_r = (ms_nr * m_row) * (xd - c);
                 b_r = (ms_pr * m_row) * (c - xu);
@@ -219,8 +239,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
                 b_c.v[0] = (ms_c0 * m_row) * (c.v[0] - xl); b_c.v[1] = e0; b_c.v[2] = e1; b_c.v[3] = e2;
                 f_z = wzn * (N[t] - c);
                 if (DN) b_z = wzp * (c - lds_P[t][tid]);
-                if (t + 1 < M) f_t = (m_row * mft) * (C[(t + 1 < M) ? t + 1 : t] - c);
-                b_t = f_t_prev;
+                if (!TWIN) {
+                    if (t + 1 < M) f_t = (m_row * mft) * (C[(t + 1 < M) ? t + 1 : t] - c);
+                    b_t = f_t_prev;
+                } else {
+                    if (fvalid(t) && t0 + t + 1 < Mg) {
+                        const F4 xn_t = (t + 1 < M) ? C[(t + 1 < M) ? t + 1 : t] : ((in && pc) ? ldu(pc + foff_t(t + 1), voff) : zero);
+                        f_t = (m_row * mft) * (xn_t - c);
+                    }
+                    b_t = f_t_prev;
+                    if (t == 0 && DN && t0 >= 1)                 // backward difference of the window's first frame
+                        b_t = (m_row * mft) * (c - ((in && pc) ? ldu(pc + foff_t(-1), voff) : zero));
+                }
                 f_t_prev = f_t;
             }
             F4 ss = zero;
@@ -230,11 +260,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             F4 n, rn;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                n.v[i] = inv_norm(ss.v[i], site_ok);
+                n.v[i] = inv_norm(ss.v[i], site_ok && fvalid(t));
                 rn.v[i] = ss.v[i] * n.v[i];
             }
             // four norms in fp32 (each carries its own 2^-24 already), then fp64 across frames / planes / threads
-            if (count) acc += (double)((rn.v[0] + rn.v[1]) + (rn.v[2] + rn.v[3]));
+            if (count && fstore(t)) acc += (double)((rn.v[0] + rn.v[1]) + (rn.v[2] + rn.v[3]));
             // ---- scatter the products ---------------------------------------------------------------------
             F4 gc = Gc[t], gn = zero;
             if (CEN) {          // one product per axis, to the neighbours on both sides
@@ -284,10 +314,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
             pin(gc);
             Gc[t] = gc;
             // ---- plane zl-1 is complete ------------------------------------------------------------------
-            if (store) {
+            if (store && fstore(t)) {
                 F4 o = Gp[t];
                 if (S == HYBRID || CEN) o = s * o;
-                const long long foff = (long long)(zl - 1) * g.s_z + (long long)t * g.s_t;      // uniform
+                const long long foff = (long long)(zl - 1) * g.s_z + foff_t(t);      // uniform
                 if (MODE == 0) {
                     stu(G + foff, voff, o);
                 } else {

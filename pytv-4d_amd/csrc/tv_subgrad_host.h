@@ -5,7 +5,8 @@
 #include "tv_stencil.h"
 #include "tv_subgrad.h"
 
-inline bool sg_m_ok(int m) { return m >= 1 && m <= 8; }
+// every M <= 8 has its own instantiation; more frames run as overlapping time windows of 8 frames (tv_subgrad.h)
+inline bool sg_m_ok(int m) { return m >= 1; }
 
 inline int sg_supported(const tv_geom* g) {
     DG d;
@@ -13,6 +14,7 @@ inline int sg_supported(const tv_geom* g) {
     if (g->dtype != TV_F32 || d.nx % 4 != 0 || !sg_m_ok(d.m)) return 0;
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return 0;   // two-point axes: forward stencil
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
+    if (d.m > SG_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
     if (env_int("TV_NO_FUSED_SUBGRAD", 0)) return 0;
     return 1;
 }
@@ -21,6 +23,7 @@ template <typename F> inline int dispatch_sg(int scheme, int m, F&& f) {
 #define TV_CASE_G(SC)                                              \
     case SC:                                                       \
         switch (m) {                                               \
+            case 0: return f.template operator()<SC, 0>();         \
             case 1: return f.template operator()<SC, 1>();         \
             case 2: return f.template operator()<SC, 2>();         \
             case 3: return f.template operator()<SC, 3>();         \
@@ -62,15 +65,20 @@ inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const 
     }
     if (zc > d.nz) zc = d.nz;
     const long long nch = (d.nz + zc - 1) / zc;
-    const long long nb = tx * ty * nch, per_xcd = (nb + 7) / 8;       // XCD-aware logical ids: see the kernel
+    const long long nwin = (d.m > SG_TWN) ? (d.m + SG_TWU - 1) / SG_TWU : 1;      // time windows (M > 8)
+    const long long nb = tx * ty * nch * nwin, per_xcd = (nb + 7) / 8;       // XCD-aware logical ids: see the kernel
     const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, NW, 1);
     if (nb > nmax) return fail(TV_E_ARG, "internal: partials exceed the workspace");
     double* w0 = (double*)ws;
     double* w1 = w0 + nmax + kStage + 16;
     sa.part_fid = w1;
-    int rc = dispatch_sg(g->scheme, d.m, [&]<int S, int M>() -> int {
-        hipLaunchKernelGGL((k_subgrad_one<S, M, NW, MODE>), grid, block, 0, st, d, make_w<float>(g), (const float*)x,
-                           (const float*)x_prev, (const float*)x_next, (float*)G, zc, (int)nch, w0, sa);
+    int rc = dispatch_sg(g->scheme, d.m > SG_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
+        if constexpr (M == 0)        // M > 8: overlapping windows of 8 frames
+            hipLaunchKernelGGL((k_subgrad_one<S, SG_TWN, NW, MODE, true>), grid, block, 0, st, d, make_w<float>(g), (const float*)x,
+                               (const float*)x_prev, (const float*)x_next, (float*)G, zc, (int)nch, w0, sa);
+        else
+            hipLaunchKernelGGL((k_subgrad_one<S, M, NW, MODE>), grid, block, 0, st, d, make_w<float>(g), (const float*)x,
+                               (const float*)x_prev, (const float*)x_next, (float*)G, zc, (int)nch, w0, sa);
         HIP_TRY(hipGetLastError());
         return 0;
     });

@@ -799,3 +799,19 @@ def test_full_size_config3_on_one_gpu_two_paths_agree(pytv):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "big_volume_check.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "agree" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape", [(3, 16, 6, 128), (4, 12, 5, 132), (2, 9, 7, 256)])
+def test_two_pass_subgradient_with_more_than_8_frames(pytv, scheme, shape):
+    """tv_subgrad (norms wanted) on marching-size planes with M > 8: pass 1 marches, pass 2 has no marching instantiation
+    and must take the one-site-per-thread gather OF THE SAME SCHEME (a fallback once sent every scheme to the central one)."""
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal(shape) * 10).astype(np.float32)
+    kw = dict(reg_z_over_reg=1.2, reg_time=0.9)
+    tv, G, gn = getattr(pytv.tv_GPU, "tv_" + scheme)(x.copy(), return_grad_norms=True, **kw)
+    wtv, wG, wgn = orc.tv(x.astype(np.float64), scheme, return_grad_norms=True, **kw)
+    np.testing.assert_allclose(float(tv), wtv, rtol=1e-6)
+    np.testing.assert_allclose(G, wG, **F32)
+    fin = np.isfinite(wgn)
+    np.testing.assert_allclose(gn[fin], wgn[fin], **F32)

@@ -50,6 +50,11 @@ def _one_pass(pytv, x, scheme, **kw):
     ((4, 5, 17, 64), 1.0, 0.8, False),
     ((3, 6, 9, 72), 0.5, 1.2, True),
     ((5, 7, 15, 60), 1.0, 1.0, False),
+    ((3, 9, 9, 64), 1.0, 1.0, False),          # M > 8: overlapping time windows of 8 frames (6 stored)
+    ((4, 12, 17, 68), 0.7, 1.3, True),
+    ((3, 16, 6, 64), 1.0, 0.5, False),
+    ((2, 13, 5, 60), 0.0, 1.0, False),
+    ((3, 25, 4, 64), 1.0, 1.0, False),
     ((3, 8, 9, 64), 0.0, 1.0, False),         # time axis only
     ((2, 2, 5, 68), 1.0, 1.0, False),
     ((3, 2, 6, 8), 1.0, 1.0, False),          # frame narrower than a tile
@@ -163,8 +168,8 @@ def test_one_pass_rejects_what_it_does_not_support(pytv):
     for shape, scheme, dt, kw in (((2, 1, 8, 64), "central", torch.float32, {}),                       # two-point z axis
                                   ((3, 2, 8, 64), "central", torch.float32, dict(reg_time=1.0)),       # two-point time axis
                                   ((2, 1, 8, 64), "hybrid", torch.float64, {}), ((2, 1, 8, 66), "hybrid", torch.float32, {}),
-                                  ((2, 9, 8, 64), "hybrid", torch.float32, {}), ((2, 1, 8, 7), "downwind", torch.float32, {}),
-                                  ((2, 16, 8, 64), "upwind", torch.float32, {})):
+                                  ((2, 1, 8, 7), "downwind", torch.float32, {}),
+                                  ((2, 16, 8, 66), "upwind", torch.float32, {})):
         g = nv.Geometry(shape, scheme, dt, torch.device("cuda", 0), **kw)
         assert lib.tv_subgrad_fused_supported(g.ref) == 0, (shape, scheme)
         x = torch.zeros(shape, dtype=dt, device="cuda")

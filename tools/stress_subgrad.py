@@ -12,7 +12,7 @@ rng = np.random.default_rng(2024)
 bad = done = 0
 for case in range(n_cases):
     scheme = ["upwind", "downwind", "hybrid", "central"][case % 4]
-    m = int(rng.choice([1, 2, 3, 4, 8]))
+    m = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 16, 19]))
     nz = int(rng.integers(1, 12))
     ny = int(rng.integers(1, 70))
     nx = 4 * int(rng.integers(1, 80))
