@@ -69,10 +69,11 @@ def _bwd(x, axis):
 
 
 def _cen(x, axis):
-    """x[p+e] - x[p-e] on interior points; two-point axes fall back to the forward difference
-    (tv_operators_CPU.py:331,334,339-342,347-350)."""
+    """x[p+e] - x[p-e] on interior points (tv_operators_CPU.py:331,334); a two-point z or time axis falls back to
+    the forward difference (:339-342,347-350).  A two-point ROW or COLUMN axis has no interior point: the channel is
+    zero, as the reference's slicing gives for N = 2."""
     n = x.shape[axis]
-    if n == 2:
+    if n == 2 and axis in (_AX_Z, _AX_T):
         return _fwd(x, axis)
     d = np.zeros_like(x)
     if n > 2:
@@ -106,7 +107,7 @@ def _bwd_T(y, axis):
 def _cen_T(y, axis):
     """Adjoint of _cen (tv_operators_CPU.py:623-628,633-639,646-651)."""
     n = y.shape[axis]
-    if n == 2:
+    if n == 2 and axis in (_AX_Z, _AX_T):
         return _fwd_T(y, axis)
     out = np.zeros_like(y)
     if n > 2:

@@ -815,3 +815,23 @@ def test_two_pass_subgradient_with_more_than_8_frames(pytv, scheme, shape):
     np.testing.assert_allclose(G, wG, **F32)
     fin = np.isfinite(wgn)
     np.testing.assert_allclose(gn[fin], wgn[fin], **F32)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape", [(3, 3, 2, 8), (3, 3, 8, 2), (4, 1, 2, 2), (3, 19, 2, 128), (3, 4, 3, 4)])
+def test_tiny_frames(pytv, scheme, shape):
+    """Two- and three-row / -column frames: central has no interior row (column) at N = 2, so that channel is zero -- the
+    reference's slicing semantics (pinned against the imported reference in tests/test_oracle_vs_reference.py); only a
+    two-point z or TIME axis falls back to the forward stencil."""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(shape) * 10).astype(np.float32)
+    kw = dict(reg_z_over_reg=1.0, reg_time=0.7)
+    d = getattr(pytv.tv_operators_GPU, "D_" + scheme)(x, **kw)
+    np.testing.assert_allclose(d, orc.D(x.astype(np.float64), scheme, **kw), **F32)
+    y = rng.standard_normal(d.shape).astype(np.float32)
+    np.testing.assert_allclose(getattr(pytv.tv_operators_GPU, "D_T_" + scheme)(y, **kw), orc.D_T(y.astype(np.float64), scheme, **kw), **F32)
+    wtv, wG = orc.tv(x.astype(np.float64), scheme, **kw)
+    for norms in (True, False):
+        out = getattr(pytv.tv_GPU, "tv_" + scheme)(x.copy(), return_grad_norms=norms, **kw)
+        np.testing.assert_allclose(float(out[0]), wtv, rtol=1e-6)
+        np.testing.assert_allclose(out[1], wG, **F32)

@@ -23,7 +23,8 @@ assert pytv.__file__.startswith(%(ref)r)
 rng = np.random.default_rng(11)
 worst = 0.0
 n = 0
-geoms = [(1,1,9,9),(4,1,8,8),(3,1,7,7),(5,1,6,6),(1,3,7,7),(4,2,6,6),(3,3,6,6),(5,4,7,7),(6,8,5,5)]
+geoms = [(1,1,9,9),(4,1,8,8),(3,1,7,7),(5,1,6,6),(1,3,7,7),(4,2,6,6),(3,3,6,6),(5,4,7,7),(6,8,5,5),
+         (3,1,2,2),(4,3,2,2),(1,1,3,3),(3,3,4,4)]      # tiny frames: central has no interior row / column at N = 2
 for scheme in ("upwind","downwind","central","hybrid"):
     for shape in geoms:
         for lz, mu in ((1.0,0.0),(0.0,0.0),(2.5,1.0),(1.0,2**-5),(0.0,0.7)):
