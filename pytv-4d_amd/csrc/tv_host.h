@@ -89,7 +89,12 @@ static const int kStage = 256;          // second-level partials
 // layout of the scratch buffer: [partials ... nmax][stage kStage]
 inline long long max_partials(const DG& d) {
     LC lc = launch_cfg(d, 1, d.nz + 2);
-    return lc.nblocks > kFlatBlocks ? lc.nblocks : kFlatBlocks;
+    // the one-sweep fix-up launches up to four classes whose block counts add up to ~3 x (256-column tiles) x (4-row
+    // groups) x m x nz when the z-chunks are short and the frame is narrow: bound them explicitly
+    const long long tiles = (long long)((d.nx / 4 + 63) / 64 + 1) * ((d.ny + 3) / 4 + 1);
+    long long n = 4 * tiles * (d.m + 2) * (d.nz + 2) + 4096;
+    if (lc.nblocks > n) n = lc.nblocks;
+    return n > kFlatBlocks ? n : kFlatBlocks;
 }
 
 inline int reduce_partials(double* ws, long long n, long long nmax, double* result, hipStream_t st) {

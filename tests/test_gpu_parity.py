@@ -835,3 +835,18 @@ def test_tiny_frames(pytv, scheme, shape):
         out = getattr(pytv.tv_GPU, "tv_" + scheme)(x.copy(), return_grad_norms=norms, **kw)
         np.testing.assert_allclose(float(out[0]), wtv, rtol=1e-6)
         np.testing.assert_allclose(out[1], wG, **F32)
+
+
+@pytest.mark.parametrize("shape", [(35, 9, 39, 64), (18, 20, 33, 68), (9, 3, 38, 64), (35, 1, 39, 12 * 4)])
+def test_partials_workspace_covers_narrow_frames_with_short_chunks(pytv, shape, monkeypatch):
+    """The four fix-up classes together launch ~3x more blocks than the sweep when the frame is one tile wide and the
+    z-chunks are two planes long: the scratch bound (tv_workspace_bytes) must cover that (it once did not)."""
+    import torch
+    monkeypatch.setenv("TV_ZCHUNK", "2")
+    rng = np.random.default_rng(3)
+    x0 = torch.as_tensor((50 * rng.random(shape)).astype(np.float32)).cuda()
+    a = pytv.solvers.ChambollePock(x0, 5.0, reg_time=0.7)
+    b = pytv.solvers.ChambollePock(x0, 5.0, reg_time=0.7, fused=False)
+    if not a.fused:
+        pytest.skip("one-sweep path not available for this geometry")
+    np.testing.assert_allclose(a.run(3), b.run(3), rtol=2e-6)

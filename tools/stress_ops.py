@@ -20,14 +20,22 @@ def check(name, got, want, info, **kw):
 for case in range(n_cases):
     scheme = ["upwind", "downwind", "hybrid", "central"][case % 4]
     m = int(rng.integers(1, 21))
-    nz = int(rng.integers(1, 7))
-    ny = int(rng.integers(2, 20))
-    nx = 4 * int(rng.choice([3, 16, 17, 32, 33, 64]))
+    nz = int(rng.choice([1, 2, 3, 5, 9, 18, 35]))
+    ny = int(rng.integers(2, 40))
+    nx = 4 * int(rng.choice([3, 16, 17, 32, 33, 64, 65, 130]))
+    while nz * m * ny * nx > 400000:          # keep the NumPy oracle fast
+        nz = max(1, nz // 2); ny = max(2, ny // 2)
+    os.environ["TV_ZCHUNK"] = str(int(rng.choice([0, 2, 3, 16])))
     lz = float(rng.choice([0.0, 1.0, 2.5])); mu = float(rng.choice([0.0, 0.5, 1.0]))
     if scheme == "central" and (nz == 2 or m == 2):
         nz, m = 3, max(m, 3)
     kw = dict(reg_z_over_reg=lz, reg_time=mu)
-    info = (scheme, (nz, m, ny, nx), lz, mu)
+    kind = int(rng.integers(0, 4))             # 0, 1: plain; 2: boolean mask; 3: per-pixel weight map
+    if kind == 2:
+        kw.update(mask_static=rng.random((ny, nx)) < 0.4, factor_reg_static=2.3)
+    elif kind == 3:
+        kw.update(mask_static=rng.random((ny, nx)) * 2.0)
+    info = (scheme, (nz, m, ny, nx), lz, mu, ("plain", "plain", "mask", "weights")[kind], os.environ["TV_ZCHUNK"])
     x = (rng.standard_normal((nz, m, ny, nx)) * 10).astype(np.float32)
     x64 = x.astype(np.float64)
     ops, tvg = pytv.tv_operators_GPU, pytv.tv_GPU
