@@ -10,11 +10,11 @@ from pytv import _native as nv
 from oracle import tv_oracle as orc
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(99)
-tol = dict(rtol=1e-5, atol=2e-5)
 bad = 0
+TOL = [None]
 def check(name, got, want, info, **kw):
     global bad
-    if not np.allclose(got, want, **(kw or tol)):
+    if not np.allclose(got, want, **(kw or TOL[0])):
         bad += 1
         print("MISMATCH", name, info, float(np.abs(np.asarray(got) - np.asarray(want)).max()))
 for case in range(n_cases):
@@ -36,29 +36,34 @@ for case in range(n_cases):
     elif kind == 3:
         kw.update(mask_static=rng.random((ny, nx)) * 2.0)
     info = (scheme, (nz, m, ny, nx), lz, mu, ("plain", "plain", "mask", "weights")[kind], os.environ["TV_ZCHUNK"])
-    x = (rng.standard_normal((nz, m, ny, nx)) * 10).astype(np.float32)
+    dt = np.float64 if rng.random() < 0.25 else np.float32          # fp64: the one-site-per-thread kernels, any M
+    tol = dict(rtol=1e-5, atol=2e-5) if dt == np.float32 else dict(rtol=1e-10, atol=1e-9)
+    TOL[0] = tol
+    lt = 1.0 if dt == np.float32 else 1e-5                          # scale of the loss tolerances
+    info = info + (np.dtype(dt).name,)
+    x = (rng.standard_normal((nz, m, ny, nx)) * 10).astype(dt)
     x64 = x.astype(np.float64)
     ops, tvg = pytv.tv_operators_GPU, pytv.tv_GPU
     d = getattr(ops, "D_" + scheme)(x, **kw)
     check("D", d, orc.D(x64, scheme, **kw), info)
-    y = rng.standard_normal(d.shape).astype(np.float32)
+    y = rng.standard_normal(d.shape).astype(dt)
     check("DT", getattr(ops, "D_T_" + scheme)(y, **kw), orc.D_T(y.astype(np.float64), scheme, **kw), info)
     wtv, wG = orc.tv(x64, scheme, **kw)
     for norms in (True, False):
         out = getattr(tvg, "tv_" + scheme)(x.copy(), return_grad_norms=norms, **kw)
-        check("tv(norms=%s)" % norms, float(out[0]), wtv, info, rtol=1e-6, atol=0)
+        check("tv(norms=%s)" % norms, float(out[0]), wtv, info, rtol=1e-6 * lt, atol=0)
         check("G(norms=%s)" % norms, out[1], wG, info)
     x0 = torch.as_tensor(x * 5).cuda()
     rx, rl = orc.chambolle_pock(x64 * 5, 4, 7.0, scheme=scheme, **kw)
     for fused in (False, None):
         cp = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, fused=fused, **kw)
-        check("cp loss fused=%s" % cp.fused, cp.run(4), rl, info, rtol=1e-5, atol=0)
-        check("cp x fused=%s" % cp.fused, cp.result().cpu().numpy(), rx, info, rtol=1e-4, atol=1e-3)
+        check("cp loss fused=%s" % cp.fused, cp.run(4), rl, info, rtol=1e-5 * lt, atol=0)
+        check("cp x fused=%s" % cp.fused, cp.result().cpu().numpy(), rx, info, rtol=1e-4 * lt, atol=1e-3 * lt)
     ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, **kw)
     _, al = orc.admm(x64 * 5, 2, 7.0, 0.1, 3, scheme=scheme, **kw)
-    check("admm", ad.run(2), al, info, rtol=1e-4, atol=0)
+    check("admm", ad.run(2), al, info, rtol=1e-4 * lt, atol=0)
     sg = pytv.solvers.SubgradientDescent(x0, 2.0, 0.02, scheme=scheme, **kw)
     _, sl = orc.subgradient_descent(x64 * 5, 3, 2.0, 0.02, scheme=scheme, **kw)
-    check("sg", sg.run(3), sl, info, rtol=1e-4, atol=0)
+    check("sg", sg.run(3), sl, info, rtol=1e-4 * lt, atol=0)
 print("cases %d, mismatches %d" % (n_cases, bad))
 sys.exit(1 if bad else 0)
