@@ -179,9 +179,11 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     hist_r = hist if backend == "nccl" else hist.cpu()
-    if world > 1:
+    rccl_ranks = 0
+    if dist.is_initialized():           # also with ONE rank: the device all-reduce then runs on RCCL like it does with 8
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(hist_r, op=dist.ReduceOp.SUM)
+        rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
     elapsed = float(tmax.item())
     h = hist_r.cpu().numpy()
     loss = cp.loss_from_slots(h, 25.0)
@@ -204,6 +206,9 @@ def main():
                                "two_kernel_(6+3Nd)_words": bytes_iter_fused * it_s / 1e9 / world,
                                "one_sweep_(5+2Nd)_words": 4.0 * (5 + 2 * nd) * V * it_s / 1e9 / world, "per": "GPU"},
         "loss_first_last": [float(loss[W]), float(loss[-1])],
+        "rccl_ranks": rccl_ranks,        # ranks of the RCCL communicator the run used (0: no process group / test backend)
+        "halo": {"backend": (dist.get_backend() if dist.is_initialized() else None), "planes_per_exchange": 1,
+                 "bytes_per_plane": 4 * shape[1] * shape[2] * shape[3], "exchanges_per_iteration": 2 if world > 1 else 0},
     }
     traffic = {}
     try:
@@ -219,7 +224,8 @@ def main():
         out["config"]["kernels"] = "one-sweep: tv_cp_fused + tv_cp_fixup"
         out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_fused: k_cp_fused<S,M> (dual update + lagged primal update, one pass over q)",
                            "achieved": b_k1 / t_k1 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_k1 / t_k1 / 1e9 / HBM_PEAK_GBPS,
-                           "traffic": traffic.get("fused"), "traffic_source": traffic.get("source"), "bytes_per_launch": b_k1,
+                           "traffic": traffic.get("fused"),
+                           "traffic_source": "STATIC, not measured in this run: " + str(traffic.get("source")), "bytes_per_launch": b_k1,
                            "ms_per_launch": 1e3 * t_k1,
                            "note": "algorithmic bytes (5+2Nd)*4 per voxel: q read+written once, x/x0/p read, x/p written; HIP events on the "
                                    "launch stream (includes the tiny partial-sum kernels)" + sharded}
@@ -232,7 +238,8 @@ def main():
         out["config"]["kernels"] = "two-kernel: tv_cp_dual + tv_cp_primal"
         out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_dual: k_D_march<S,M,CpDual> (fp32, planes >= 4 MiB) or k_D<S,T,V,CpDual>",
                            "achieved": b_dual / t_k1 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_dual / t_k1 / 1e9 / HBM_PEAK_GBPS,
-                           "traffic": traffic.get("dual"), "traffic_source": traffic.get("source"), "bytes_per_launch": b_dual,
+                           "traffic": traffic.get("dual"),
+                           "traffic_source": "STATIC, not measured in this run: " + str(traffic.get("source")), "bytes_per_launch": b_dual,
                            "ms_per_launch": 1e3 * t_k1,
                            "note": "algorithmic bytes (1+2Nd)*4 per voxel; HIP events on the launch stream (includes the tiny partial-sum kernels)" + sharded}
         out["roofline_primal"] = {"bound": "hbm", "kernel": "tv_cp_primal: k_DT_march<S,M,CpPrimal> or k_DT<S,T,V,SrcPlain,CpPrimal>",
@@ -240,12 +247,15 @@ def main():
                                   "frac": b_primal / t_k2 / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("primal"),
                                   "bytes_per_launch": b_primal, "ms_per_launch": 1e3 * t_k2,
                                   "note": "algorithmic bytes (Nd+5)*4 per voxel: reads q,x,x0,p; writes x,p (fidelity dual fused in)" + sharded}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if dist.is_initialized():
+        dist.barrier()          # the other ranks wait at the final barrier while rank 0 times the host baseline
+    if rank == 0 and not args.no_cpu_baseline:
         del cp, x0
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(shape, wl["reg_z"], wl["reg_time"], nd)
         try:
-            out["cpu_baseline_openmp"] = cpu_baseline_openmp(shape, wl["reg_z"], wl["reg_time"])
+            if world == 1:      # all host cores: only when no other rank's threads share them
+                out["cpu_baseline_openmp"] = cpu_baseline_openmp(shape, wl["reg_z"], wl["reg_time"])
         except Exception as exc:                      # no gcc / OpenMP on this host: the NumPy baseline stands alone
             out["cpu_baseline_openmp"] = {"error": str(exc)[:200]}
     if rank == 0:

@@ -65,6 +65,15 @@ typedef struct tv_geom {
 /* ---- housekeeping ------------------------------------------------------------------------ */
 const char* tv_last_error(void);
 int         tv_version(void);                         /* 10000*major + 100*minor + patch     */
+/* Tuning / debugging options (TV_ZCHUNK, TV_NO_FUSED, ...: DESIGN.md section 7).  The table is process-wide and explicit:
+ * every entry is initialised ONCE from the environment variable of the same name when the library first consults it,
+ * and afterwards changes only through these calls -- no entry point reads the environment per call.
+ *   tv_set_option   : 0, or TV_E_ARG for an unknown name
+ *   tv_unset_option : back to "not set" (every call site then uses its built-in default)
+ *   tv_get_option   : the value, or dflt when the option is not set                                            */
+int         tv_set_option(const char* name, int value);
+int         tv_unset_option(const char* name);
+int         tv_get_option(const char* name, int dflt);
 /* Number of gradient channels nd for this geometry (pytv/tv_operators_GPU.py:170-174,
  * 290-294,399-403,507-511), or TV_E_ARG. */
 int         tv_num_channels(const tv_geom* g);

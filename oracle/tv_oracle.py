@@ -286,10 +286,24 @@ def tv(img, scheme, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_
 # driver loops (README.md:107-124 and :141-157), generalised with keepdims so that they are
 # defined beyond 2-D; identical to the README in the 2-D case
 # --------------------------------------------------------------------------------------------
-def cp_step_size(scheme, Nz, M, reg_z_over_reg, reg_time):
-    """tau = 1 / (1 + L^2), L^2 = 4 (2 + reg_z [z] + reg_time [t]); 1/9 in 2-D (README.md:143)."""
+def time_weight_max(mask_static, factor_reg_static):
+    """Largest per-pixel weight on reg_time: the time channels are scaled by sqrt(factor_reg_static) where a boolean
+    mask is set, by sqrt(W) for a weight array W."""
+    m = _mask_array(mask_static)
+    if m is None:
+        return 1.0
+    if np.issubdtype(m.dtype, np.floating):
+        return float(m.max())
+    if not m.any():
+        return 1.0
+    return float(factor_reg_static) if m.all() else max(1.0, float(factor_reg_static))
+
+
+def cp_step_size(scheme, Nz, M, reg_z_over_reg, reg_time, time_weight_max=1.0):
+    """tau = 1 / (1 + L^2), L^2 = 4 (2 + reg_z [z] + reg_time * time_weight_max [t]) >= |D|^2; 1/9 in 2-D
+    (README.md:143).  BUILD-DEFINED beyond 2-D (the reference ships only the 2-D snippet)."""
     z, t = active_axes(scheme, Nz, M, reg_z_over_reg, reg_time)
-    return 1.0 / (1.0 + 4.0 * (2.0 + (reg_z_over_reg if z else 0.0) + (reg_time if t else 0.0)))
+    return 1.0 / (1.0 + 4.0 * (2.0 + (reg_z_over_reg if z else 0.0) + (reg_time * time_weight_max if t else 0.0)))
 
 
 def chambolle_pock(x0, n_iter, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
@@ -301,7 +315,8 @@ def chambolle_pock(x0, n_iter, regularization, scheme="hybrid", reg_z_over_reg=1
     kw = dict(reg_z_over_reg=reg_z_over_reg, reg_time=reg_time, mask_static=mask_static,
               factor_reg_static=factor_reg_static)
     if tau is None:
-        tau = cp_step_size(scheme, x0.shape[0], x0.shape[1], reg_z_over_reg, reg_time)
+        tau = cp_step_size(scheme, x0.shape[0], x0.shape[1], reg_z_over_reg, reg_time,
+                           time_weight_max(mask_static, factor_reg_static))
     x = x0.copy()
     p = np.zeros_like(x0)
     q = np.zeros_like(D(x0, scheme, **kw))
@@ -339,14 +354,17 @@ def group_soft_threshold(v, thresh):
 
 
 def admm(x0, n_outer, regularization, rho, n_cg, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-         mask_static=False, factor_reg_static=0, return_state=False):
+         mask_static=False, factor_reg_static=0, return_state=False, single_reduction=False):
     """Scaled-form ADMM for min 1/2|x-x0|^2 + reg |z|_{2,1} s.t. Dx = z.  NOT in the reference
     (README.md:26,135 only mention it): build-defined, parity unpinned; this NumPy version pins
     the HIP implementation to the same arithmetic.
       x-step : (I + rho D^T D) x = x0 + rho D^T (z - u), n_cg conjugate-gradient steps, warm start
       z-step : z = group_soft_threshold(Dx + u, reg/rho)
       u-step : u += Dx - z
-    loss[k] = 1/2|x-x0|^2 + reg |Dx|_{2,1} after the x-step."""
+    loss[k] = 1/2|x-x0|^2 + reg |Dx|_{2,1} after the x-step.
+    single_reduction: the Chronopoulos-Gear form of the same CG recurrence (w = A r, gamma = <r,r>, delta = <r,w>
+    reduced together: one all-reduce per step on a sharded volume) -- what pytv.solvers.ADMM(single_reduction=True)
+    runs; identical to the textbook form in exact arithmetic."""
     x0 = np.asarray(x0)
     kw = dict(reg_z_over_reg=reg_z_over_reg, reg_time=reg_time, mask_static=mask_static,
               factor_reg_static=factor_reg_static)
@@ -363,7 +381,26 @@ def admm(x0, n_outer, regularization, rho, n_cg, scheme="hybrid", reg_z_over_reg
         r = b - A(x)
         d = r.copy()
         rs = float(np.sum(r.astype(np.float64) ** 2))
-        for _ in range(n_cg):
+        if single_reduction:
+            w = A(r)
+            gamma, delta = rs, float(np.sum(r.astype(np.float64) * w))
+            alpha, beta = (gamma / delta if delta > 0 else 0.0), 0.0
+            d, s = np.zeros_like(r), np.zeros_like(r)
+            for c in range(n_cg):
+                d = r + d.dtype.type(beta) * d
+                s = w + s.dtype.type(beta) * s              # s = A d
+                x = x + x.dtype.type(alpha) * d
+                r = r - r.dtype.type(alpha) * s
+                if c + 1 == n_cg:
+                    break
+                w = A(r)
+                gamma_new = float(np.sum(r.astype(np.float64) ** 2))
+                delta = float(np.sum(r.astype(np.float64) * w))
+                beta = gamma_new / gamma if gamma > 0 else 0.0
+                den = delta - beta * gamma_new / alpha if alpha != 0.0 else 0.0
+                alpha = gamma_new / den if den > 0 else 0.0
+                gamma = gamma_new
+        for _ in range(0 if single_reduction else n_cg):
             Ad = A(d)
             dAd = float(np.sum(d.astype(np.float64) * Ad))
             alpha = rs / dAd if dAd > 0 else 0.0

@@ -89,7 +89,9 @@ def chambolle_pock(x0, n_iter, regularization, scheme="hybrid", reg_z_over_reg=1
     x0 = np.ascontiguousarray(x0, dtype=np.float32 if np.asarray(x0).dtype == np.float32 else np.float64)
     g, keep = _geom(x0.shape, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
     if tau is None:
-        tau = 1.0 / (1.0 + 4.0 * (2.0 + (reg_z_over_reg if g.za else 0.0) + (reg_time if g.ta else 0.0)))
+        from . import tv_oracle as _orc
+        tau = _orc.cp_step_size(scheme, x0.shape[0], x0.shape[1], reg_z_over_reg, reg_time,
+                                _orc.time_weight_max(mask_static, factor_reg_static))
     x, p = x0.copy(), np.zeros_like(x0)
     q = np.zeros((x0.shape[0], g.nd) + x0.shape[1:], dtype=x0.dtype)
     d, dt = np.empty_like(q), np.empty_like(x0)
@@ -98,4 +100,25 @@ def chambolle_pock(x0, n_iter, regularization, scheme="hybrid", reg_z_over_reg=1
     getattr(lib(), "tvc_cp" + _suf(x0))(ctypes.byref(g), vp(x), vp(x0), vp(p), vp(q), vp(d), vp(dt), ctypes.c_int(n_iter),
                                          ctypes.c_double(regularization), ctypes.c_double(sigma_D), ctypes.c_double(sigma_A),
                                          ctypes.c_double(tau), vp(loss))
+    return x, loss
+
+
+def admm(x0, n_outer, regularization, rho, n_cg, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
+         factor_reg_static=0, single_reduction=False, return_state=False):
+    """Same iteration as tv_oracle.admm, in C with OpenMP.  single_reduction: the Chronopoulos-Gear form of the CG
+    recurrence (one reduction per step), otherwise the textbook one."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float32 if np.asarray(x0).dtype == np.float32 else np.float64)
+    g, keep = _geom(x0.shape, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
+    x = x0.copy()
+    z = np.zeros((x0.shape[0], g.nd) + x0.shape[1:], dtype=x0.dtype)
+    u = np.zeros_like(z)
+    img = np.empty((4,) + x0.shape, dtype=x0.dtype)
+    dw = np.empty((2,) + z.shape, dtype=x0.dtype)
+    loss = np.zeros(n_outer)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    getattr(lib(), "tvc_admm" + _suf(x0))(ctypes.byref(g), vp(x), vp(x0), vp(z), vp(u), vp(img), vp(dw), ctypes.c_int(n_outer),
+                                           ctypes.c_int(n_cg), ctypes.c_double(regularization), ctypes.c_double(rho),
+                                           ctypes.c_int(int(bool(single_reduction))), vp(loss))
+    if return_state:
+        return x, loss, z, u
     return x, loss

@@ -3,10 +3,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <initializer_list>
+#include <mutex>
 #include <string>
 
 #include "../../include/pytv4d.h"
@@ -137,9 +140,32 @@ template <typename F> inline int dispatch(int scheme, int dtype, bool vec, F&& f
 }
 
 // ---- plane-marching fast path (tv_march.h): fp32, 16-byte lanes, M in {1,2,3,4,8,16} ---------------
+// Tuning / debugging options: ONE explicit process-wide table.  Each entry is initialised once, when
+// the library first looks at the table, from the environment variable of the same name; after that only
+// tv_set_option() changes it -- no call reads the environment again, so a running host program cannot have its
+// dispatch changed behind its back.  An option that was never set (neither way) takes the call site's default.
+struct TvOption { const char* name; std::atomic<int> has; std::atomic<int> value; };
+inline TvOption g_options[] = {
+    {"TV_NO_MARCH", 0, 0}, {"TV_MARCH_MIN_PLANE_KB", 0, 0}, {"TV_ZCHUNK", 0, 0}, {"TV_MARCH_D", 0, 0},
+    {"TV_NO_MARCH_SUBGRAD", 0, 0}, {"TV_NO_MARCH_NORMAL", 0, 0}, {"TV_SCALAR_GATHER", 0, 0}, {"TV_NO_FUSED", 0, 0},
+    {"TV_NO_FUSED_TWIN", 0, 0}, {"TV_FUSED_XW", 0, 0}, {"TV_FUSED_FORCE_TWIN", 0, 0}, {"TV_NO_FUSED_SUBGRAD", 0, 0},
+    {"TV_FUSED_ROWS", 0, 0}, {"TV_D_KERNEL", 0, 0}, {"TV_DT_KERNEL", 0, 0}, {"TV_SPARE", 0, 0},
+};
+inline std::once_flag g_options_once;
+inline TvOption* find_option(const char* name) {
+    std::call_once(g_options_once, [] {
+        for (TvOption& o : g_options) {
+            const char* v = getenv(o.name);
+            if (v && *v) { o.value = atoi(v); o.has = 1; }
+        }
+    });
+    for (TvOption& o : g_options)
+        if (strcmp(o.name, name) == 0) return &o;
+    return nullptr;
+}
 inline int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
+    const TvOption* o = find_option(name);
+    return (o && o->has.load(std::memory_order_relaxed)) ? o->value.load(std::memory_order_relaxed) : dflt;
 }
 inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
     if (g->dtype != TV_F32 || !vec || d.nx < 128) return false;

@@ -593,6 +593,21 @@ extern "C" {
 const char* tv_last_error(void) { return g_err.c_str(); }
 int tv_version(void) { return 100; }
 
+int tv_set_option(const char* name, int value) {
+    TvOption* o = (name != nullptr) ? find_option(name) : nullptr;
+    if (o == nullptr) return fail(TV_E_ARG, "unknown option");
+    o->value = value;
+    o->has = 1;
+    return 0;
+}
+int tv_unset_option(const char* name) {
+    TvOption* o = (name != nullptr) ? find_option(name) : nullptr;
+    if (o == nullptr) return fail(TV_E_ARG, "unknown option");
+    o->has = 0;
+    return 0;
+}
+int tv_get_option(const char* name, int dflt) { return (name != nullptr) ? env_int(name, dflt) : dflt; }
+
 int tv_num_channels(const tv_geom* g) {
     DG d;
     int rc = make_dg(g, d);

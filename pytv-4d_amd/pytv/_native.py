@@ -39,6 +39,9 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "tv_last_error": (ctypes.c_char_p, []),
     "tv_version": (ctypes.c_int, []),
+    "tv_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "tv_unset_option": (ctypes.c_int, [ctypes.c_char_p]),
+    "tv_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "tv_num_channels": (ctypes.c_int, [_G]),
     "tv_workspace_bytes": (ctypes.c_size_t, [_G]),
     "tv_D": (ctypes.c_int, [_G] + [_c_void_p] * 5),
@@ -97,6 +100,18 @@ def check(rc):
     raise RuntimeError("pytv native: HIP error %d: %s" % (rc, msg))
 
 
+def set_option(name, value):
+    """Set (value is an int) or unset (value is None) one of the library's tuning options (include/pytv4d.h)."""
+    if value is None:
+        check(lib().tv_unset_option(name.encode()))
+    else:
+        check(lib().tv_set_option(name.encode(), int(value)))
+
+
+def get_option(name, default):
+    return int(lib().tv_get_option(name.encode(), int(default)))
+
+
 def dtype_code(torch_dtype):
     if torch_dtype == torch.float32:
         return TV_F32
@@ -130,6 +145,9 @@ class Geometry:
         self.device = torch.device(device)
         self.mask_dev = None
         self.factor_dev = None
+        # largest per-pixel weight on reg_time: the time channels are scaled by sqrt(factor_reg_static) where the mask is
+        # set and by sqrt(weight) of a weight map, so |D|^2 <= 4 (2 + reg_z + reg_time * time_weight_max)
+        self.time_weight_max = 1.0
         if not isinstance(mask_static, bool):
             mk = torch.as_tensor(np.asarray(mask_static.detach().cpu()) if isinstance(mask_static, torch.Tensor)
                                  else np.asarray(mask_static))
@@ -141,9 +159,12 @@ class Geometry:
                     raise ValueError("weights must be non-negative")
                 wm = torch.broadcast_to(mk.to(torch.float64), (1, 1, ny, nx)).reshape(ny, nx)
                 self.factor_dev = torch.sqrt(wm).to(dtype).contiguous().to(self.device)
+                self.time_weight_max = float(wm.max())
             else:
                 mk = torch.broadcast_to(mk.to(torch.bool), (1, 1, ny, nx)).reshape(ny, nx)
                 self.mask_dev = mk.to(torch.uint8).contiguous().to(self.device)
+                if bool(mk.any()):
+                    self.time_weight_max = float(factor_reg_static) if bool(mk.all()) else max(1.0, float(factor_reg_static))
         g = TvGeom()
         g.nz, g.m, g.ny, g.nx = nz, m, ny, nx
         g.nz_global = nz if nz_global is None else int(nz_global)

@@ -15,7 +15,6 @@ neighbour is exchanged per operator apply (two for the radius-2 kernels) and, fo
 hidden behind the interior planes' kernel.  Scalars (TV, fidelity, CG dots) stay on the device as
 fp64 and are all-reduced there; nothing synchronises with the host inside the loop.
 """
-import os
 
 import torch
 
@@ -25,12 +24,14 @@ from .slab import HaloPlan, Slab
 __all__ = ["ChambollePock", "ChambollePockOperator", "ADMM", "SubgradientDescent", "cp_step_size"]
 
 
-def cp_step_size(nz_global, m, reg_z_over_reg, reg_time):
-    """tau = 1 / (1 + L^2) with L^2 = 4 (2 + reg_z [z active] + reg_time [t active]) >= |D|^2.
-    Reduces to the reference's 1/(8+1) in 2-D (README.md:143)."""
+def cp_step_size(nz_global, m, reg_z_over_reg, reg_time, time_weight_max=1.0):
+    """tau = 1 / (1 + L^2) with L^2 = 4 (2 + reg_z [z active] + reg_time * time_weight_max [t active]) >= |D|^2.
+    time_weight_max: the largest per-pixel weight on the time regularisation (``factor_reg_static`` where
+    ``mask_static`` is set, the maximum of a weight map; ``Geometry.time_weight_max``) -- the time channels are scaled
+    by its square root, so it belongs in the bound.  Reduces to the reference's 1/(8+1) in 2-D (README.md:143)."""
     z = nz_global > 1 and reg_z_over_reg > 0
     t = m > 1 and reg_time > 0
-    return 1.0 / (1.0 + 4.0 * (2.0 + (reg_z_over_reg if z else 0.0) + (reg_time if t else 0.0)))
+    return 1.0 / (1.0 + 4.0 * (2.0 + (reg_z_over_reg if z else 0.0) + (reg_time * time_weight_max if t else 0.0)))
 
 
 class _SlabProblem:
@@ -96,7 +97,8 @@ class ChambollePock(_SlabProblem):
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
-        self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time)
+        self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time,
+                                                                    self.geo.time_weight_max)
         self.x = self.x0.clone()
         self.p = torch.zeros_like(self.x0)
         self.q = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
@@ -113,13 +115,13 @@ class ChambollePock(_SlabProblem):
             # one-sweep kernel where supported -- except on small planes (z / t neighbours stay L2-resident there and
             # the one-site-per-thread kernel pair is faster: 840 vs 778 it/s on 256x1x512x512); same threshold and
             # override (TV_MARCH_MIN_PLANE_KB) as the marching kernels
-            min_plane = int(os.environ.get("TV_MARCH_MIN_PLANE_KB", "4096")) * 1024
+            min_plane = _nv.get_option("TV_MARCH_MIN_PLANE_KB", 4096) * 1024
             plane_bytes = self.geo.plane * self.x0.element_size()
             fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) and plane_bytes >= min_plane
         self.fused = bool(fused)
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
-            raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry "
-                             "(needs fp32, Nx % 4 == 0, Nx >= 64, M in {1,2,3,4,8})")
+            raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry (tv_cp_fused_supported: "
+                             "fp32, Nx % 4 == 0, Nx >= 64, Ny * Nx <= 2^30; any number of frames)")
         self.x_alt = torch.empty_like(self.x) if self.fused else None      # ping-pong partner of x
         self.overlap = bool(overlap) and sh and self.slab.nz >= 3 and not self.fused
         self.hist = None
@@ -308,7 +310,8 @@ class ChambollePockOperator(_SlabProblem):
         self.b = b
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
-        self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x_init.shape[1], reg_z_over_reg, reg_time)
+        self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x_init.shape[1], reg_z_over_reg, reg_time,
+                                                                    self.geo.time_weight_max)
         self.x = self.x0.clone()
         self.p = torch.zeros_like(b)
         self.q = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
@@ -342,10 +345,19 @@ class ChambollePockOperator(_SlabProblem):
 
 # =================================================================================================
 class SubgradientDescent(_SlabProblem):
-    """README.md:118-124 with the state on the GPU: x <- x - step ((x - x0) + reg * G(x))."""
+    """README.md:118-124 with the state on the GPU: x <- x - step ((x - x0) + reg * G(x)).
+
+    Per-step scalars: ``SLOTS`` fp64 device words, TV parts in [0:3], fidelity parts in [3:6] (one slot per launch:
+    interior planes, first two planes, last two planes when the halo exchange is overlapped)."""
+
+    SLOTS = 6
+
+    @classmethod
+    def loss_from_slots(cls, h, regularization):
+        return h[:, 3:6].sum(axis=1) + regularization * h[:, 0:3].sum(axis=1)
 
     def __init__(self, x0, regularization, step_size, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None):
+                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True):
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.reg, self.step_size = float(regularization), float(step_size)
         self.x = self.x0.clone()
@@ -368,21 +380,39 @@ class SubgradientDescent(_SlabProblem):
         self.xh_prev = self.new_plane(2) if sh and self.slab.prev is not None else None
         self.xh_next = self.new_plane(2) if sh and self.slab.next is not None else None
         self.sh = sh
+        # interior-first schedule (one-pass kernel: x is ping-ponged, so the planes being sent are never written while
+        # the exchange is in flight): planes [2, nz - 2) need no halo and hide the two-plane exchange
+        self.overlap = bool(overlap) and sh and self.one_pass and nz >= 5
+        self._scratch = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
 
-    def step(self, out):
+    def _one_pass_range(self, a, b, hp, hn, tv_slot, fid_slot):
+        g, x = self.geom(a, b), self.x
+        _nv.check(self.lib.tv_subgrad_step_fused(g.ref, _nv.ptr(x[a:b]), _nv.ptr(hp), _nv.ptr(hn), _nv.ptr(self.x0[a:b]),
+                                                 _nv.ptr(self.x_alt[a:b]), self.step_size, self.reg, tv_slot.data_ptr(),
+                                                 fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def step(self, out=None):
+        """Enqueue one iteration; out: fp64 device tensor of SLOTS words (TV parts [0:3], fidelity parts [3:6])."""
+        out = self._scratch if out is None else out
         nz, s, x = self.slab.nz, self.slab, self.x
-        s.wait(self.plan.exchange_image2(x, self.xh_prev, self.xh_next))
-        g = self.geo
+        h = self.plan.exchange_image2(x, self.xh_prev, self.xh_next)
         if self.one_pass:
-            _nv.check(self.lib.tv_subgrad_step_fused(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next),
-                                                     _nv.ptr(self.x0), _nv.ptr(self.x_alt), self.step_size, self.reg,
-                                                     out[0:1].data_ptr(), out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
+            if self.overlap:
+                self._one_pass_range(2, nz - 2, x[0:2], x[nz - 2:nz], out[0:1], out[3:4])
+                s.wait(h)
+                self._one_pass_range(0, 2, self.xh_prev, x[2:4], out[1:2], out[4:5])
+                self._one_pass_range(nz - 2, nz, x[nz - 4:nz - 2], self.xh_next, out[2:3], out[5:6])
+            else:
+                s.wait(h)
+                self._one_pass_range(0, nz, self.xh_prev, self.xh_next, out[0:1], out[3:4])
             self.x, self.x_alt = self.x_alt, self.x
             return
+        s.wait(h)
+        g = self.geo
         _nv.check(self.lib.tv_subgrad(g.ref, _nv.ptr(x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.G),
                                       _nv.ptr(self.norms_ext), out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
         _nv.check(self.lib.tv_subgrad_step(g.ref, _nv.ptr(x), _nv.ptr(self.x0), _nv.ptr(self.G), self.step_size, self.reg,
-                                           out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
+                                           out[3:4].data_ptr(), _nv.ptr(self.ws), self.stream))
 
     GRAPH_BLOCK = 10            # iterations captured per hipGraph (even: the x ping-pong returns to its start)
     GRAPH_MAX_VOXELS = 1 << 23  # below this an iteration is launch-bound (a few tens of microseconds of kernels)
@@ -391,7 +421,7 @@ class SubgradientDescent(_SlabProblem):
         """n_iter iterations; returns the README's loss history (README.md:124).  graph: None = replay blocks of
         GRAPH_BLOCK iterations from a hipGraph when the problem is small enough to be launch-bound and not sharded
         (the README's own 2-D example is), True / False force it."""
-        hist = torch.zeros((n_iter, 2), dtype=torch.float64, device=self.device)
+        hist = torch.zeros((n_iter, self.SLOTS), dtype=torch.float64, device=self.device)
         use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS) if graph is None else bool(graph)
         start = 0
         if use_graph and not self.slab.sharded and n_iter >= 2 + 2 * self.GRAPH_BLOCK:
@@ -401,8 +431,7 @@ class SubgradientDescent(_SlabProblem):
         for it in range(start, n_iter):
             self.step(hist[it])
         self.slab.allreduce_sum_(hist)
-        h = hist.cpu().numpy()
-        return h[:, 1] + self.reg * h[:, 0]
+        return self.loss_from_slots(hist.cpu().numpy(), self.reg)
 
     def _run_graphed_from(self, hist, first, n_iter):
         """Capture GRAPH_BLOCK iterations (not executed during capture) and replay them over hist[first:]."""
@@ -412,7 +441,7 @@ class SubgradientDescent(_SlabProblem):
             return 0
         x_ref, xalt_ref = self.x, getattr(self, "x_alt", None)
         try:
-            buf = torch.zeros((K, 2), dtype=torch.float64, device=self.device)
+            buf = torch.zeros((K, self.SLOTS), dtype=torch.float64, device=self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 for k in range(K):

@@ -51,3 +51,22 @@ def _native_library():
     if not mod.up_to_date():
         mod.build(verbose=False)
     yield
+
+
+@pytest.fixture
+def tvopt(monkeypatch):
+    """Set one of the library's tuning options for the duration of a test: ``tvopt("TV_ZCHUNK", 3)``.  The library
+    reads the environment only once (when it is loaded), so the option goes through tv_set_option(); the environment
+    variable is set as well for the ranks a test spawns."""
+    from pytv import _native
+    unset = -2 ** 31
+    before = {}
+
+    def set_(name, value):
+        if name not in before:
+            before[name] = _native.get_option(name, unset)
+        monkeypatch.setenv(name, str(value))
+        _native.set_option(name, int(value))
+    yield set_
+    for name, old in before.items():
+        _native.set_option(name, None if old == unset else old)

@@ -73,9 +73,9 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
                                                         (4, (8, 4, 5, 128), False, "0"), (2, (12, 2, 9, 68), True, "2"),
                                                         (2, (14, 2, 5, 16), True, "0"),
                                                         (2, (8, 12, 5, 64), True, "1")])      # M > 8: time windows
-def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, zchunk, monkeypatch):
+def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, zchunk, tvopt):
     from oracle import tv_oracle as orc
-    monkeypatch.setenv("TV_ZCHUNK", zchunk)     # inherited by the spawned ranks; "1"/"2": >= 3 chunks per rank -> overlap
+    tvopt("TV_ZCHUNK", zchunk)     # inherited by the spawned ranks; "1"/"2": >= 3 chunks per rank -> overlap
     kw = dict(reg_z_over_reg=1.3, reg_time=0.7)
     mgr = mp.Manager()
     ret = mgr.dict()

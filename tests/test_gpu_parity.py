@@ -169,7 +169,7 @@ MARCH_SHAPES = [(5, 1, 6, 128), (6, 2, 5, 132), (7, 3, 9, 256), (5, 4, 4, 128), 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("zchunk", ["3", "16"])
-def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, monkeypatch):
+def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, tvopt):
     """fp32, Nx >= 128, M in {1,2,3,4,8,16}: the plane-marching kernels (tv_march.h).  Checked against the
     oracle and against the one-site-per-thread kernels (TV_NO_MARCH=1) on the same input."""
     import torch
@@ -180,18 +180,18 @@ def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, mo
             x = rng.standard_normal(shape).astype(np.float32)
             mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
             kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=3.0 if use_mask else 0)
-            monkeypatch.setenv("TV_ZCHUNK", zchunk)
-            monkeypatch.setenv("TV_NO_MARCH", "0")
+            tvopt("TV_ZCHUNK", zchunk)
+            tvopt("TV_NO_MARCH", "0")
             gD = getattr(ops, "D_" + scheme)(x, **kw)
             wD = orc.D(x.astype(np.float64), scheme, **kw)
             np.testing.assert_allclose(gD, wD, err_msg="D %s %s" % (scheme, shape), **F32)
             y = rng.standard_normal(wD.shape).astype(np.float32)
             gDT = getattr(ops, "D_T_" + scheme)(y, **kw)
             np.testing.assert_allclose(gDT, orc.D_T(y.astype(np.float64), scheme, **kw), err_msg="DT %s %s" % (scheme, shape), **F32)
-            monkeypatch.setenv("TV_NO_MARCH", "1")
+            tvopt("TV_NO_MARCH", "1")
             assert np.array_equal(getattr(ops, "D_" + scheme)(x, **kw), gD), (scheme, shape)
             np.testing.assert_allclose(getattr(ops, "D_T_" + scheme)(y, **kw), gDT, rtol=1e-6, atol=1e-6)
-            monkeypatch.setenv("TV_NO_MARCH", "0")
+            tvopt("TV_NO_MARCH", "0")
             # fused solvers on the marching path (CpDual / CpPrimal / AdmmZU / AxpyDT epilogues)
             x0 = (50.0 * rng.random(shape)).astype(np.float32)
             cp = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 5.0, scheme=scheme, **kw)
@@ -215,13 +215,13 @@ FUSED_SHAPES = [(1, 1, 64, 64), (5, 1, 9, 64), (6, 2, 7, 68), (7, 3, 10, 256), (
 
 @pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("zchunk,xw", [("2", "1"), ("16", "1"), ("0", "0"), ("3", "0")])
-def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, monkeypatch):
+def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, tvopt):
     """tv_cp_fused + tv_cp_fixup (q read/written once) against tv_cp_dual + tv_cp_primal and the oracle:
     ragged rows (Ny % 4 != 0), partial wave tiles (Nx % 64 != 0), chunk edges inside the volume."""
     import torch
     from pytv import _native as nv
-    monkeypatch.setenv("TV_ZCHUNK", zchunk)          # "0" = the library's own choice
-    monkeypatch.setenv("TV_FUSED_XW", xw)            # in-block column-edge exchange variant
+    tvopt("TV_ZCHUNK", zchunk)          # "0" = the library's own choice
+    tvopt("TV_FUSED_XW", xw)            # in-block column-edge exchange variant
     rng = np.random.default_rng(41)
     for shape in FUSED_SHAPES:
         for lz, mu, use_mask in ((1.0, 1.0, False), (0.0, 0.6, True), (2.5, 0.0, False)):
@@ -543,12 +543,12 @@ def test_cp_with_fidelity_operator(pytv):
 @pytest.mark.parametrize("cuts", [(0, 3, 7), (0, 2, 4, 7), (0, 1, 2, 3, 4, 5, 6, 7)])
 @pytest.mark.parametrize("shape,dtype,zchunk", [((7, 3, 8, 12), np.float64, "16"), ((7, 3, 6, 132), np.float32, "16"),
                                                 ((7, 4, 5, 256), np.float32, "2")])
-def test_slab_calls_equal_unsharded(pytv, scheme, cuts, shape, dtype, zchunk, monkeypatch):
+def test_slab_calls_equal_unsharded(pytv, scheme, cuts, shape, dtype, zchunk, tvopt):
     # the fp32 shapes with Nx >= 128 take the plane-marching kernels (tv_march.h); TV_ZCHUNK=2 puts
     # chunk boundaries inside the slabs
     import torch
     from pytv import _native as nv
-    monkeypatch.setenv("TV_ZCHUNK", zchunk)
+    tvopt("TV_ZCHUNK", zchunk)
     lib = nv.lib()
     rng = np.random.default_rng(12)
     kw = dict(reg_z_over_reg=1.7, reg_time=0.6)
@@ -838,11 +838,11 @@ def test_tiny_frames(pytv, scheme, shape):
 
 
 @pytest.mark.parametrize("shape", [(35, 9, 39, 64), (18, 20, 33, 68), (9, 3, 38, 64), (35, 1, 39, 12 * 4)])
-def test_partials_workspace_covers_narrow_frames_with_short_chunks(pytv, shape, monkeypatch):
+def test_partials_workspace_covers_narrow_frames_with_short_chunks(pytv, shape, tvopt):
     """The four fix-up classes together launch ~3x more blocks than the sweep when the frame is one tile wide and the
     z-chunks are two planes long: the scratch bound (tv_workspace_bytes) must cover that (it once did not)."""
     import torch
-    monkeypatch.setenv("TV_ZCHUNK", "2")
+    tvopt("TV_ZCHUNK", "2")
     rng = np.random.default_rng(3)
     x0 = torch.as_tensor((50 * rng.random(shape)).astype(np.float32)).cuda()
     a = pytv.solvers.ChambollePock(x0, 5.0, reg_time=0.7)

@@ -60,9 +60,9 @@ def _one_pass(pytv, x, scheme, **kw):
     ((3, 2, 6, 8), 1.0, 1.0, False),          # frame narrower than a tile
     ((2, 1, 3, 4), 1.0, 0.0, False),
 ])
-def test_one_pass_matches_oracle_and_two_pass(pytv, scheme, zchunk, shape, lz, mu, use_mask, monkeypatch):
+def test_one_pass_matches_oracle_and_two_pass(pytv, scheme, zchunk, shape, lz, mu, use_mask, tvopt):
     import torch
-    monkeypatch.setenv("TV_ZCHUNK", zchunk)
+    tvopt("TV_ZCHUNK", zchunk)
     rng = np.random.default_rng(20 + shape[0] + shape[3])
     img = (rng.standard_normal(shape) * 10).astype(np.float32)
     img[:, :, 2:4, 2:20] = 3.0                  # a flat patch: |Dx| == 0 there (the 0 -> +inf rule)
@@ -113,10 +113,10 @@ def test_one_pass_on_reference_golden(pytv, scheme):
 @pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
 @pytest.mark.parametrize("cuts", [(0, 3, 7), (0, 2, 4, 7), (0, 1, 2, 3, 4, 5, 6, 7)])
 @pytest.mark.parametrize("zchunk", ["16", "2"])
-def test_one_pass_slab_calls_equal_unsharded(pytv, scheme, cuts, zchunk, monkeypatch):
+def test_one_pass_slab_calls_equal_unsharded(pytv, scheme, cuts, zchunk, tvopt):
     import torch
     from pytv import _native as nv
-    monkeypatch.setenv("TV_ZCHUNK", zchunk)
+    tvopt("TV_ZCHUNK", zchunk)
     lib = nv.lib()
     shape = (7, 3, 17, 132)
     rng = np.random.default_rng(5)

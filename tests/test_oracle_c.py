@@ -41,3 +41,31 @@ def test_c_oracle_chambolle_pock_equals_numpy_oracle(scheme):
         gx, gloss = occ.chambolle_pock(x0, 15, 5.0, scheme=scheme, **kw)
         np.testing.assert_allclose(gloss, wloss, rtol=1e-11)
         np.testing.assert_allclose(gx, wx, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("single", [False, True])
+def test_c_oracle_admm_equals_numpy_oracle(scheme, single):
+    rng = np.random.default_rng(6)
+    for shape, lz, mu, use_mask in GEOMS[:4]:
+        mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
+        kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=3.0 if use_mask else 0)
+        x0 = 50 * rng.random(shape)
+        wx, wloss, wz, wu = orc.admm(x0, 4, 5.0, 0.3, 3, scheme=scheme, return_state=True, single_reduction=single, **kw)
+        gx, gloss, gz, gu = occ.admm(x0, 4, 5.0, 0.3, 3, scheme=scheme, return_state=True, single_reduction=single, **kw)
+        np.testing.assert_allclose(gloss, wloss, rtol=1e-11)
+        np.testing.assert_allclose(gx, wx, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(gz, wz, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(gu, wu, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_single_reduction_cg_is_the_same_iteration(scheme):
+    """The Chronopoulos-Gear recurrence and the textbook CG agree to rounding (same Krylov iterates)."""
+    rng = np.random.default_rng(8)
+    x0 = 50 * rng.random((4, 3, 7, 6))
+    kw = dict(reg_z_over_reg=1.5, reg_time=0.7)
+    ax, aloss = orc.admm(x0, 5, 5.0, 0.3, 4, scheme=scheme, **kw)
+    bx, bloss = orc.admm(x0, 5, 5.0, 0.3, 4, scheme=scheme, single_reduction=True, **kw)
+    np.testing.assert_allclose(bloss, aloss, rtol=1e-9)
+    np.testing.assert_allclose(bx, ax, rtol=1e-8, atol=1e-8)

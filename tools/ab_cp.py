@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""In-process interleaved A/B of Chambolle-Pock variants on the north-star shape (env knobs are read by
-the C-ABI at every call).  usage: python tools/ab_cp.py NAME=ENV1=V1,ENV2=V2 NAME2=... [--rounds 4] [--shape ...]"""
+"""In-process interleaved A/B of Chambolle-Pock variants on the north-star shape (the knobs go through
+tv_set_option).  usage: python tools/ab_cp.py NAME=ENV1=V1,ENV2=V2 NAME2=... [--rounds 4] [--shape ...]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,8 @@ res = {n: [] for n, _ in variants}
 for r in range(rounds):
     for name, env in variants:
         for k, v in env.items():
-            os.environ[k] = v
+            if k.startswith("TV_"):
+                pytv._native.set_option(k, int(v))
         fused = None if env.get("FUSED", "1") == "1" else False
         cp = pytv.solvers.ChambollePock(x0, 25.0, reg_time=1.0, fused=fused)
         for _ in range(2):
@@ -33,7 +34,8 @@ for r in range(rounds):
         k1 = np.mean([e[0].elapsed_time(e[1]) for e in cp.timing]); k2 = np.mean([e[1].elapsed_time(e[2]) for e in cp.timing])
         res[name].append((dt * 1e3, k1, k2))
         for k in env:
-            os.environ.pop(k, None)
+            if k.startswith("TV_"):
+                pytv._native.set_option(k, None)
         del cp
         torch.cuda.empty_cache()
 for name, _ in variants:

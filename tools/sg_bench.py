@@ -14,7 +14,7 @@ print("shape %s; words = fp32 words per voxel the iteration must move (x, x0 rea
 for scheme in schemes:
     for one_pass in (True, False):
         sg = pytv.solvers.SubgradientDescent(x0, 25.0, 0.01, scheme=scheme, reg_time=1.0, one_pass=one_pass)
-        hist = torch.zeros((16, 2), dtype=torch.float64, device=x0.device)
+        hist = torch.zeros((16, sg.SLOTS), dtype=torch.float64, device=x0.device)
         for i in range(3):
             sg.step(hist[i])
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -13,9 +13,9 @@ for shape in [(1,1,512,512), (1,1,2048,2048), (256,1,512,512), (128,8,512,512), 
     for scheme in ("hybrid", "upwind"):
         kw = dict(reg_time=1.0 if shape[1] > 1 else 0.0)
         t1 = bench(lambda: pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=False, one_pass=True, **kw))
-        os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+        pytv._native.set_option("TV_MARCH_MIN_PLANE_KB", 0)
         t2m = bench(lambda: pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=True, one_pass=False, **kw))
-        os.environ["TV_MARCH_MIN_PLANE_KB"] = "1000000"
+        pytv._native.set_option("TV_MARCH_MIN_PLANE_KB", 1000000)
         t2g = bench(lambda: pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=True, one_pass=False, **kw))
-        os.environ.pop("TV_MARCH_MIN_PLANE_KB")
+        pytv._native.set_option("TV_MARCH_MIN_PLANE_KB", None)
         print("%-20s %-8s one-pass %.3f ms | two-pass marching %.3f | two-pass generic %.3f" % (shape, scheme, t1, t2m, t2g))

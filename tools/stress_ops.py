@@ -26,6 +26,7 @@ for case in range(n_cases):
     while nz * m * ny * nx > 400000:          # keep the NumPy oracle fast
         nz = max(1, nz // 2); ny = max(2, ny // 2)
     os.environ["TV_ZCHUNK"] = str(int(rng.choice([0, 2, 3, 16])))
+    nv.set_option("TV_ZCHUNK", int(os.environ["TV_ZCHUNK"]))
     lz = float(rng.choice([0.0, 1.0, 2.5])); mu = float(rng.choice([0.0, 0.5, 1.0]))
     if scheme == "central" and (nz == 2 or m == 2):
         nz, m = 3, max(m, 3)

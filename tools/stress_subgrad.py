@@ -21,6 +21,7 @@ for case in range(n_cases):
     kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=(rng.random((ny, nx)) < 0.4) if use_mask else False,
               factor_reg_static=2.3 if use_mask else 0)
     os.environ["TV_ZCHUNK"] = str(int(rng.choice([0, 1, 2, 3, 5, 16])))
+    nv.set_option("TV_ZCHUNK", int(os.environ["TV_ZCHUNK"]))
     x = torch.as_tensor((rng.standard_normal((nz, m, ny, nx)) * 10).astype(np.float32)).cuda()
     geo = nv.Geometry(tuple(x.shape), scheme, x.dtype, x.device, **kw)
     if not nv.lib().tv_subgrad_fused_supported(geo.ref):
