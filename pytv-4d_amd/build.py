@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip", "tv_fused.hip", "tv_subgrad.hip", "tv_sgstep.hip"]
-HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h", "tv_fused.h", "tv_subgrad.h", "tv_subgrad_host.h"]
+UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip", "tv_fused.hip", "tv_subgrad.hip", "tv_sgstep.hip", "tv_dstream.hip"]
+HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h", "tv_fused.h", "tv_subgrad.h", "tv_subgrad_host.h", "tv_dstream.h"]
 DEPS = [os.path.join(CSRC, f) for f in UNITS + HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "pytv4d.h")]
 OUT = os.path.join(HERE, "pytv", "libpytv4d_hip.so")
 OBJDIR = os.path.join(HERE, "build")

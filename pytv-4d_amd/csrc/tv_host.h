@@ -250,6 +250,9 @@ int D_normal_op(const tv_geom* g, const DG& d, const void* x, const void* xp, co
                 float* out, float rho, double* partials);
 int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
               float* z, float* u, float thresh, double* partials);
+// streaming forward kernel (tv_dstream.h): d = D x without LDS tile or barrier, every load one plane ahead of its use
+bool D_stream_ok(const tv_geom* g, const DG& d, bool vec);
+int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, float* dout);
 int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb, float* out);
 int DT_axpy(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
             float* out, const float* base, float alpha);

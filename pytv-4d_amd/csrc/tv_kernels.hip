@@ -628,9 +628,16 @@ int tv_D(const tv_geom* g, const void* x, const void* x_prev, const void* x_next
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
     const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, dout});
     hipStream_t st = (hipStream_t)stream;
-    // tv_D is write dominated (1 word read, Nd written): the one-site-per-thread kernel is faster than the
-    // marching one here (measured 4.85 vs 5.66 ms on 64x8x1024x1024 hybrid); TV_MARCH_D=1 forces marching
-    if (env_int("TV_MARCH_D", 0) && march_ok(g, d, vec)) {
+    // TV_D_KERNEL: 0 = one site per thread (k_D), 1 = plane-marching with an LDS tile (k_D_march), 2 = streaming
+    // (k_D_stream: no tile, no barrier, x read once).  Default: streaming for planes of at least TV_MARCH_MIN_PLANE_KB
+    // (64x8x1024x1024, ms hybrid / upwind / downwind / central: k_D 4.90 / 2.39 / 2.37 / 3.04, k_D_march 5.76 / 2.71 /
+    // 2.47 / 2.99, k_D_stream 4.31 / 2.16 / 2.17 / 2.31); on small planes the z / t neighbours of the one-site kernel
+    // stay in L2 and it wins (256x1x512x512: 0.39 / 0.19 ms against 0.40 / 0.23) -- profiles/r2_d_kernels.txt
+    const bool big_plane = (long long)d.s_z * 4 >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;
+    const int kern = env_int("TV_D_KERNEL", env_int("TV_MARCH_D", 0) ? 1 : (big_plane ? 2 : 0));
+    if (kern == 2 && tvm::D_stream_ok(g, d, vec) && !env_int("TV_NO_MARCH", 0))
+        return tvm::D_stream(g, d, x, x_prev, x_next, st, (float*)dout);
+    if (kern == 1 && march_ok(g, d, vec)) {
         long long nb;
         return tvm::D_store(g, d, x, x_prev, x_next, st, &nb, (float*)dout);
     }
