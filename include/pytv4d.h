@@ -60,6 +60,18 @@ typedef struct tv_geom {
                                  * (mask_static, factor_reg_static), which is f = mask ? sqrt(factor) : 1 -- the
                                  * "weight matrix" of the reference's to-do list (README.md:258); both may be set,
                                  * the factors multiply */
+    const void* time_weight_vol;/* device, nz*m*ny*nx elements of `dtype`, or NULL: per-VOXEL multiplier f(z,t,y,x) of the
+                                 * time channels (f^2 = weight on reg_time at that voxel): the reference's to-do "weight matrix
+                                 * of size Nz x M x N x N" (README.md:258), local planes of the slab.  Multiplies with the two
+                                 * per-pixel forms above.  D scales the time channel of a voxel by f at THAT voxel; D^T is the
+                                 * exact adjoint (every sample is scaled by its own voxel's f before the difference), which for
+                                 * a weight that does not vary along t is the reference's "scale the time part at the output
+                                 * voxel" (pytv/tv_operators_CPU.py:442-446); the sub-gradient keeps its unit-weight adjoint
+                                 * (the weight enters through D only, pytv/tv_GPU.py:104-122).  The plane-marching, one-sweep and
+                                 * one-pass fast paths do not take a weight volume (tv_cp_fused_supported /
+                                 * tv_subgrad_fused_supported answer 0): the one-site-per-thread kernels do the work */
+    const void* time_weight_prev;/* plane z0-1 / z0+nz of the same volume (m*ny*nx elements each) or NULL: only the          */
+    const void* time_weight_next;/* ghost-plane norms of tv_subgrad on a slab read them                                       */
 } tv_geom;
 
 /* ---- housekeeping ------------------------------------------------------------------------ */
@@ -99,7 +111,9 @@ int tv_l21(const tv_geom* g, const void* d, int32_t nd, void* norms, double* res
 /* *tv (device fp64) = TV of the local planes; G = the reference's sub-gradient
  * (pytv/tv_GPU.py:47-375).  norms_ext: REQUIRED scratch/output of (nz + 2) planes; on return
  * plane k+1 holds 1 / |D x| of local plane k, 0 where |D x| == 0 -- the reciprocal of the
- * reference's grad_norms (which has those zeros replaced by +inf, pytv/tv_GPU.py:88).
+ * reference's grad_norms (which has those zeros replaced by +inf, pytv/tv_GPU.py:88).  "== 0" means here, and in every
+ * other sub-gradient entry point: |D x|^2 below the smallest NORMAL number of the dtype (fp32: |D x| < 1.1e-19), where a
+ * square carries no information any more; the reference zeroes only at exactly 0.
  * x_prev / x_next: TWO planes each (z0-2, z0-1) / (z0+nz, z0+nz+1) when sharded, else NULL. */
 int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* x_next,
                void* G, void* norms_ext, double* tv, void* ws, void* stream);
@@ -111,6 +125,10 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
 int tv_subgrad_fused_supported(const tv_geom* g);
 int tv_subgrad_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, double* tv,
                      void* ws, void* stream);
+/* The same with the per-voxel norms as a by-product: norms (nz,m,ny,nx) = |D x| with zeros replaced by +inf -- the
+ * reference's grad_norms (return_grad_norms=True, pytv/tv_GPU.py:47,88,135-139).  Three words per voxel. */
+int tv_subgrad_fused_norms(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, void* norms,
+                           double* tv, void* ws, void* stream);
 /* One iteration of the README's sub-gradient loop (README.md:118-124) in the same single pass, G never stored:
  *   x_out = x - step * ((x - x0) + lambda * G(x));  *tv = TV(x);  *fid = 1/2 |x_out - x0|^2   (local planes).
  * x and x_out must be different buffers (ping-pong).  Same geometries as tv_subgrad_fused. */

@@ -156,6 +156,14 @@ def _mask_array(mask_static):
     return m.astype(bool)
 
 
+def _varies_in_time(mask):
+    """is ``mask`` a per-VOXEL weight array (BUILD EXTENSION, README.md:258 "weight matrix of size Nz x M x N x N"),
+    i.e. a float array with an extent along z or t?  Then the adjoint scales every time sample by its OWN voxel's
+    factor before the difference (the exact adjoint of D); for per-pixel weights that is what the reference does by
+    scaling the summed time part at the output voxel (tv_operators_CPU.py:442-446)."""
+    return mask is not None and np.issubdtype(mask.dtype, np.floating) and mask.ndim == 4 and (mask.shape[0] > 1 or mask.shape[1] > 1)
+
+
 def _time_scaled(c, mask, sqrt_factor):
     """time channel / time part of the adjoint, scaled per pixel (tv_operators_CPU.py:148-150,428-446)"""
     if mask is None:
@@ -219,8 +227,12 @@ def _adjoint(y, scheme, z_active, t_active, w_z, w_t, mask, sqrt_factor):
         if t_active:
             order.append((_AX_T, 0, c))
     time_part = None
+    per_voxel = _varies_in_time(mask)
     for axis, which, ch in order:
-        term = adj[which](y[:, ch], axis)
+        ych = y[:, ch]
+        if axis == _AX_T and per_voxel:
+            ych = _time_scaled(ych, mask, sqrt_factor)          # sample by sample, before the adjoint stencil
+        term = adj[which](ych, axis)
         if axis == _AX_Z:
             out += w_z * term
         elif axis == _AX_T:
@@ -230,7 +242,8 @@ def _adjoint(y, scheme, z_active, t_active, w_z, w_t, mask, sqrt_factor):
         else:
             out += term
     if time_part is not None:
-        time_part = _time_scaled(time_part, mask, sqrt_factor)
+        if not per_voxel:
+            time_part = _time_scaled(time_part, mask, sqrt_factor)
         out += time_part
     if scheme == "hybrid":
         return out / np.sqrt(2.0)          # tv_operators_CPU.py:448

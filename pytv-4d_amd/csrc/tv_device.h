@@ -26,6 +26,9 @@ struct DG {
     long long s_dz;        // gradient plane stride   nd*m*ny*nx
     const uint8_t* mask;   // ny*nx or nullptr
     const void* tf;        // ny*nx elements of the image dtype (per-pixel time-channel factor) or nullptr
+    const void* wv;        // nz*m*ny*nx elements of the image dtype (per-VOXEL time-channel factor, local planes) or nullptr
+    const void* wvp;       // plane z0-1 / z0+nz of the same (ghost planes of the two-pass sub-gradient) or nullptr
+    const void* wvn;
 };
 
 template <typename T> struct WT { T wz, wt, sf; };   // sqrt(reg_z), sqrt(reg_time), sqrt(factor_static)
@@ -144,6 +147,24 @@ __device__ __forceinline__ Vec<T, V> mask_factor(const DG& g, T sf, int y, int c
         for (int i = 0; i < V; ++i) r.v[i] *= fp[i];
     }
     return r;
+}
+// per-VOXEL factor of the time channels (tv_geom::time_weight_vol) at local plane zl (ghost planes: -1, nz), frame t;
+// 1 where there is no weight volume, the frame does not exist or the ghost plane was not supplied
+template <typename T> __device__ __forceinline__ const T* vol_plane(const DG& g, int zl, int t) {
+    if (g.wv == nullptr || t < 0 || t >= g.m) return nullptr;
+    const T* pl = (zl >= 0 && zl < g.nz) ? static_cast<const T*>(g.wv) + (long long)zl * g.s_z
+                                          : static_cast<const T*>(zl < 0 ? g.wvp : g.wvn);
+    return pl != nullptr ? pl + (long long)t * g.s_t : nullptr;
+}
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> vol_factor(const DG& g, int zl, int t, int y, int col0) {
+    const T* pl = vol_plane<T>(g, zl, t);
+    if (pl == nullptr) return vsplat<T, V>(T(1));
+    return vload<T, V>(pl + (long long)y * g.nx + col0);
+}
+template <typename T> __device__ __forceinline__ T vol_factor1(const DG& g, int zl, int t, int y, int col) {
+    const T* pl = vol_plane<T>(g, zl, t);
+    return pl != nullptr ? pl[(long long)y * g.nx + col] : T(1);
 }
 // the same for one pixel
 template <typename T> __device__ __forceinline__ T mask_factor1(const DG& g, T sf, int y, int col) {

@@ -51,6 +51,7 @@ int tv_cp_fused_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
     if (g->dtype != TV_F32 || d.nx % 4 != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;
+    if (d.wv != nullptr) return 0;                                  // weight volume: kernel pair on the one-site path
     if (d.m > CP_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_FUSED", 0)) return 0;

@@ -61,6 +61,9 @@ inline int make_dg(const tv_geom* g, DG& d) {
     d.s_dz = d.s_z * d.nd;
     d.mask = g->mask_static;
     d.tf = g->time_factor;
+    d.wv = g->time_weight_vol;
+    d.wvp = g->time_weight_vol ? g->time_weight_prev : nullptr;
+    d.wvn = g->time_weight_vol ? g->time_weight_next : nullptr;
     return 0;
 }
 
@@ -169,6 +172,7 @@ inline int env_int(const char* name, int dflt) {
 }
 inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
     if (g->dtype != TV_F32 || !vec || d.nx < 128) return false;
+    if (d.wv != nullptr) return false;                    // weight volume: one-site-per-thread kernels
     if (env_int("TV_NO_MARCH", 0)) return false;
     // small planes (z/t neighbours one plane away stay L2-resident) are served better by the
     // one-site-per-thread kernels: measured on 512x512xM=1 (BASELINE config 1)

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void k_D(DG g, WT<T> w, const T* x, const T* x
         }
         XN<T, V> n;
         load_xn<T, V, NEXT, PREV>(g, pc, pp, pn, c, n);
-        const Vec<T, V> mf = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
+        Vec<T, V> mf = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
+        if (g.ta && g.wv != nullptr) mf = mf * vol_factor<T, V>(g, c.zl, c.t, c.y, c.col0);   // the channel lives at this voxel
         Vec<T, V> o[8];
         d_slots<S, T, V>(g, w, n, mf, o);
         acc = epi(g, c, o);
@@ -106,9 +107,14 @@ __global__ __launch_bounds__(256) void k_DT(DG g, WT<T> w, Src src, Epi epi) {
         auto tax = [&](auto mode, int ch) {
             constexpr int M = decltype(mode)::value;
             const long long o = offd + (long long)ch * g.s_z;
-            const Vec<T, V> lo = (c.t >= 1 && M != 1) ? src.ld(o - g.s_t) : zero;
-            const Vec<T, V> ce = (M != 2) ? src.ld(o) : zero;
-            const Vec<T, V> hi = (c.t + 1 < g.m && M != 0) ? src.ld(o + g.s_t) : zero;
+            Vec<T, V> lo = (c.t >= 1 && M != 1) ? src.ld(o - g.s_t) : zero;
+            Vec<T, V> ce = (M != 2) ? src.ld(o) : zero;
+            Vec<T, V> hi = (c.t + 1 < g.m && M != 0) ? src.ld(o + g.s_t) : zero;
+            if (g.wv != nullptr) {      // weight volume: exact adjoint, every sample carries its own voxel's factor
+                lo = lo * vol_factor<T, V>(g, c.zl, c.t - 1, c.y, c.col0);
+                ce = ce * vol_factor<T, V>(g, c.zl, c.t, c.y, c.col0);
+                hi = hi * vol_factor<T, V>(g, c.zl, c.t + 1, c.y, c.col0);
+            }
             rt = rt + w.wt * adj_axis<M, T, V>(c.t, g.m, lo, ce, hi);
         };
 
@@ -182,6 +188,7 @@ __device__ __forceinline__ T dval(const XA<T>& X, const WT<T>& w, int axis, int 
     if (axis == 3) {
         diff = w.wt * diff;
         diff *= mask_factor1<T>(X.g, w.sf, y, c);
+        diff *= vol_factor1<T>(X.g, zl, t, y, c);
     }
     if (S == HYBRID) diff *= Consts<T>::inv_sqrt2();
     if (S == CENTRAL) diff *= T(0.5);
@@ -205,7 +212,8 @@ __global__ __launch_bounds__(256) void k_gather(XA<T> X, WT<T> w, const T* norms
                 const T n = norms_ext[(long long)(qz + 1) * g.s_z + (long long)qt * g.s_t + (long long)qy * g.nx + qc];
                 return d * n;           // n = 1/|Dx| from pass 1 (0 where |Dx| == 0)
             }
-            return d;
+            // D^T D: the adjoint scales the time sample of voxel q by q's own weight-volume factor
+            return (axis == 3) ? d * vol_factor1<T>(g, qz, qt, qy, qc) : d;
         };
         T r = T(0), rt = T(0);
         const int naxes = 4;
@@ -268,8 +276,15 @@ __global__ __launch_bounds__(256) void k_subgrad_vec(DG g, WT<T> w, const T* x, 
     load_xn<T, V, true, true>(g, pc, pp, pn, c, xs);
     const T* nc = norms_ext + (long long)(c.zl + 1) * g.s_z;
     load_xn<T, V, true, true>(g, nc, pp ? nc - g.s_z : nullptr, pn ? nc + g.s_z : nullptr, c, ns);
-    const Vec<T, V> mf = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
-    const Vec<T, V> r = subgrad_site<S, T, V>(g, w, xs, ns, mf);
+    const Vec<T, V> mf2 = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
+    Vec<T, V> r;
+    if (g.ta && g.wv != nullptr) {
+        const Vec<T, V> mf = mf2 * vol_factor<T, V>(g, c.zl, c.t, c.y, c.col0);
+        const Vec<T, V> mfp = mf2 * vol_factor<T, V>(g, c.zl, c.t - 1, c.y, c.col0), mfn = mf2 * vol_factor<T, V>(g, c.zl, c.t + 1, c.y, c.col0);
+        r = subgrad_site<S, T, V>(g, w, xs, ns, mf, &mfp, &mfn);
+    } else {
+        r = subgrad_site<S, T, V>(g, w, xs, ns, mf2);
+    }
     vstore<T, V>(G + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, r);
 }
 
@@ -296,7 +311,20 @@ __global__ __launch_bounds__(256) void k_normal_vec(DG g, WT<T> w, const T* x, c
         if (g.za) r = r + (w.wz * w.wz) * ((xs.h_pz ? xs.c - xs.pz : zero) - (xs.h_nz ? xs.nz - xs.c : zero));
         if (g.ta) {
             const Vec<T, V> mf = mask_factor<T, V>(g, w.sf, c.y, c.col0);
-            r = r + ((w.wt * w.wt) * ((xs.h_pt ? xs.c - xs.pt : zero) - (xs.h_nt ? xs.nt - xs.c : zero))) * (mf * mf);
+            if (g.wv == nullptr) {
+                r = r + ((w.wt * w.wt) * ((xs.h_pt ? xs.c - xs.pt : zero) - (xs.h_nt ? xs.nt - xs.c : zero))) * (mf * mf);
+            } else {
+                // weight volume f(z,t,y,x): up channels weigh the backward term with f(t-1)^2 and the forward one with f(t)^2,
+                // down channels with f(t)^2 and f(t+1)^2; hybrid is the mean of the two
+                const Vec<T, V> f0 = vol_factor<T, V>(g, c.zl, c.t, c.y, c.col0), fp = vol_factor<T, V>(g, c.zl, c.t - 1, c.y, c.col0),
+                                fn = vol_factor<T, V>(g, c.zl, c.t + 1, c.y, c.col0);
+                const Vec<T, V> b = xs.h_pt ? xs.c - xs.pt : zero, f = xs.h_nt ? xs.nt - xs.c : zero;
+                Vec<T, V> tt;
+                if (S == UPWIND) tt = b * (fp * fp) - f * (f0 * f0);
+                else if (S == DOWNWIND) tt = b * (f0 * f0) - f * (fn * fn);
+                else tt = T(0.5) * ((b * (fp * fp) - f * (f0 * f0)) + (b * (f0 * f0) - f * (fn * fn)));
+                r = r + ((w.wt * w.wt) * tt) * (mf * mf);
+            }
         }
         const long long off = (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
         Vec<T, V> o;
@@ -375,10 +403,25 @@ __global__ __launch_bounds__(256) void k_normal_central_vec(DG g, WT<T> w, const
         }
         if (g.ta) {
             Vec<T, V> rt;
-            if (g.t_two) rt = (w.wt * w.wt) * axis1(c.t, g.m, (c.t >= 1) ? vload<T, V>(pc - g.s_t) : zero,
-                                                             (c.t + 1 < g.m) ? vload<T, V>(pc + g.s_t) : zero);
-            else rt = (w.wt * w.wt) * axis2(c.t, g.m, (c.t >= 2) ? vload<T, V>(pc - 2 * g.s_t) : zero,
-                                            (c.t + 2 < g.m) ? vload<T, V>(pc + 2 * g.s_t) : zero);
+            if (g.wv == nullptr) {
+                if (g.t_two) rt = (w.wt * w.wt) * axis1(c.t, g.m, (c.t >= 1) ? vload<T, V>(pc - g.s_t) : zero,
+                                                                 (c.t + 1 < g.m) ? vload<T, V>(pc + g.s_t) : zero);
+                else rt = (w.wt * w.wt) * axis2(c.t, g.m, (c.t >= 2) ? vload<T, V>(pc - 2 * g.s_t) : zero,
+                                                (c.t + 2 < g.m) ? vload<T, V>(pc + 2 * g.s_t) : zero);
+            } else {
+                // weight volume: the term that comes from the channel at voxel q carries f(q)^2
+                const Vec<T, V> f0 = vol_factor<T, V>(g, c.zl, c.t, c.y, c.col0), fp = vol_factor<T, V>(g, c.zl, c.t - 1, c.y, c.col0),
+                                fn = vol_factor<T, V>(g, c.zl, c.t + 1, c.y, c.col0);
+                Vec<T, V> a = zero;
+                if (g.t_two) {                       // forward stencil: channel at p-e and at p
+                    if (c.t >= 1) a = a + (xc - vload<T, V>(pc - g.s_t)) * (fp * fp);
+                    if (c.t <= g.m - 2) a = a - (vload<T, V>(pc + g.s_t) - xc) * (f0 * f0);
+                } else {                             // central: channel at p-e and at p+e (interior frames only)
+                    if (c.t - 1 > 0 && c.t - 1 < g.m - 1) a = a + (xc - vload<T, V>(pc - 2 * g.s_t)) * (fp * fp);
+                    if (c.t + 1 > 0 && c.t + 1 < g.m - 1) a = a - (vload<T, V>(pc + 2 * g.s_t) - xc) * (fn * fn);
+                }
+                rt = (w.wt * w.wt) * a;
+            }
             const Vec<T, V> mf = mask_factor<T, V>(g, w.sf, c.y, c.col0);
             r = r + rt * (mf * mf);
         }
@@ -407,7 +450,14 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
     const T* pc = zplane<T>(g, x, xp, xn, 2, c.zl) + inpl;
     const T* nc = norms_ext + (long long)(c.zl + 1) * g.s_z + inpl;
     const Vec<T, V> xc = vload<T, V>(pc);
-    const Vec<T, V> mf = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
+    const Vec<T, V> mf2 = g.ta ? mask_factor<T, V>(g, w.sf, c.y, c.col0) : vsplat<T, V>(T(1));
+    // time-channel factor of the voxel one frame back / this one / one frame ahead (they differ only with a weight volume)
+    Vec<T, V> mf = mf2, mfa = mf2, mfb = mf2;
+    if (g.ta && g.wv != nullptr) {
+        mf = mf2 * vol_factor<T, V>(g, c.zl, c.t, c.y, c.col0);
+        mfa = mf2 * vol_factor<T, V>(g, c.zl, c.t - 1, c.y, c.col0);
+        mfb = mf2 * vol_factor<T, V>(g, c.zl, c.t + 1, c.y, c.col0);
+    }
     const T h = T(0.5);
     Vec<T, V> r = zero;
     // term of one axis from the vectors two steps away (x) and one step away (norms); wa < 0: unweighted
@@ -416,7 +466,7 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
         if (pos - 1 > 0 && pos - 1 < n - 1) {
             Vec<T, V> d = xc - xm2;
             if (weighted) d = wa * d;
-            if (timeax) d = d * mf;
+            if (timeax) d = d * mfa;
             d = h * d;
 #pragma unroll
             for (int i = 0; i < V; ++i) r.v[i] += d.v[i] * nm1.v[i];
@@ -424,7 +474,7 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
         if (pos + 1 > 0 && pos + 1 < n - 1) {
             Vec<T, V> d = xp2 - xc;
             if (weighted) d = wa * d;
-            if (timeax) d = d * mf;
+            if (timeax) d = d * mfb;
             d = h * d;
 #pragma unroll
             for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] * np1.v[i];
@@ -434,7 +484,7 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
                    bool timeax) {
         if (pos >= 1) {             // g(p-e), d(p-e) = 1/2 w (x(p) - x(p-e))
             Vec<T, V> d = wa * (xc - xm1);
-            if (timeax) d = d * mf;
+            if (timeax) d = d * mfa;
             d = h * d;
 #pragma unroll
             for (int i = 0; i < V; ++i) r.v[i] += d.v[i] * nm1.v[i];
@@ -626,7 +676,7 @@ int tv_D(const tv_geom* g, const void* x, const void* x_prev, const void* x_next
     if (int rc = make_dg(g, d)) return rc;
     if (x == nullptr || dout == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, dout});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, dout, d.wv, d.wvp, d.wvn});
     hipStream_t st = (hipStream_t)stream;
     // TV_D_KERNEL: 0 = one site per thread (k_D), 1 = plane-marching with an LDS tile (k_D_march), 2 = streaming
     // (k_D_stream: no tile, no barrier, x read once).  Default: streaming for planes of at least TV_MARCH_MIN_PLANE_KB
@@ -661,7 +711,7 @@ int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_pr
     if (int rc = make_dg(g, d)) return rc;
     if (a == nullptr || out == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_y_halos(g, d, ab_prev, ab_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({a, b, ab_prev, ab_next, base, out});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({a, b, ab_prev, ab_next, base, out, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const bool plain_store = (base == nullptr && alpha == 1.0);
     if (b == nullptr && march_ok(g, d, vec)) {
@@ -720,7 +770,9 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
     if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr)))
         return fail(TV_E_HALO, "tv_subgrad on a slab needs two halo planes on each interior side");
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, norms_ext});
+    if (d.za && d.ta && d.wv != nullptr && ((e_lo && d.wvp == nullptr) || (e_hi && d.wvn == nullptr)))
+        return fail(TV_E_HALO, "tv_subgrad on a slab with a weight volume needs time_weight_prev / time_weight_next");
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, norms_ext, d.wv, d.wvp, d.wvn});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec && aligned16({G})) && !env_int("TV_NO_MARCH_SUBGRAD", 0)) {
@@ -807,7 +859,7 @@ int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void
         return fail(TV_E_HALO, "tv_normal_op on a slab needs two halo planes on each interior side");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out, d.wv});
     if (g->scheme != TV_CENTRAL && d.m <= 8 && march_ok(g, d, vec) && !env_int("TV_NO_MARCH_NORMAL", 0)) {
         long long nb;
         if (int rc = tvm::D_normal_op(g, d, x, x_prev, x_next, st, &nb, (float*)out, (float)rho, (double*)ws)) return rc;
@@ -842,7 +894,7 @@ int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* 
     if (x == nullptr || q == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, q});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, q, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
@@ -868,7 +920,7 @@ int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void
     if (q == nullptr || x == nullptr || x0 == nullptr || p == nullptr || fid == nullptr || ws == nullptr)
         return fail(TV_E_ARG, "NULL array");
     if (int rc = check_y_halos(g, d, q_prev, q_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({q, q_prev, q_next, x, x0, p});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({q, q_prev, q_next, x, x0, p, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
@@ -893,7 +945,7 @@ int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* 
     if (int rc = make_dg(g, d)) return rc;
     if (x == nullptr || z == nullptr || u == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, z, u});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, z, u, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {

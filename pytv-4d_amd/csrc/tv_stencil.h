@@ -158,9 +158,11 @@ template <int S, typename T, int V> struct StoreD {
 // 1/|Dx| per voxel into an array with one extra plane in front; 0 where |Dx| == 0 (the reference sets
 // |Dx| := +inf there so that the site contributes nothing, pytv/tv_GPU.py:88 -- same effect), and also where
 // |Dx| is so small that its reciprocal would overflow.  Storing the reciprocal makes pass 2 division-free.
-template <typename T> __device__ __forceinline__ T tiny_norm();
-template <> __device__ __forceinline__ float tiny_norm<float>() { return 1e-30f; }
-template <> __device__ __forceinline__ double tiny_norm<double>() { return 1e-300; }
+// ONE rule for "the gradient is zero" in every sub-gradient kernel (two-pass NormEpi, one-pass inv_norm, marching
+// D_norms): |Dx|^2 below the smallest normal number of the type
+template <typename T> __device__ __forceinline__ T tiny_sumsq();
+template <> __device__ __forceinline__ float tiny_sumsq<float>() { return 0x1p-126f; }
+template <> __device__ __forceinline__ double tiny_sumsq<double>() { return 0x1p-1022; }
 template <int S, typename T, int V> struct NormEpi {
     static constexpr bool REDUCES = true;
     T* norms_ext;
@@ -173,7 +175,7 @@ template <int S, typename T, int V> struct NormEpi {
         for (int i = 0; i < V; ++i) {
             const T r = tsqrt(s.v[i]);
             acc += (double)r;
-            n.v[i] = (r > tiny_norm<T>()) ? T(1) / r : T(0);
+            n.v[i] = (s.v[i] >= tiny_sumsq<T>()) ? T(1) / r : T(0);
         }
         vstore<T, V>(norms_ext + (long long)(c.zl + 1) * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, n);
         return (c.zl >= 0 && c.zl < g.nz) ? acc : 0.0;
@@ -290,9 +292,12 @@ __device__ __forceinline__ Vec<T, V> div_where(const Vec<T, V>& d, const Vec<T, 
 }
 
 // sub-gradient of one site-vector from the radius-1 neighbourhoods of x (xs) and of 1/|Dx| (ns)
+// mf_prev / mf_next (weight volume only): the time-channel factor of the voxel one frame back / ahead -- D_up(p - e_t)
+// carries the factor of frame t-1 and D_down(p + e_t) that of frame t+1; nullptr: the factor does not depend on t
 template <int S, typename T, int V>
 __device__ __forceinline__ Vec<T, V> subgrad_site(const DG& g, const WT<T>& w, const XN<T, V>& xs, const XN<T, V>& ns,
-                                                  const Vec<T, V>& mf) {
+                                                  const Vec<T, V>& mf, const Vec<T, V>* mf_prev = nullptr,
+                                                  const Vec<T, V>* mf_next = nullptr) {
     static_assert(S != CENTRAL, "radius-2 scheme");
     constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
     const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : T(1);
@@ -320,7 +325,15 @@ __device__ __forceinline__ Vec<T, V> subgrad_site(const DG& g, const WT<T>& w, c
         r.v[i] += acc;
     }
     if (g.za) axis(xs.nz, xs.pz, xs.h_nz, xs.h_pz, ns.nz, ns.pz, w.wz, true, false);
-    if (g.ta) axis(xs.nt, xs.pt, xs.h_nt, xs.h_pt, ns.nt, ns.pt, w.wt, true, true);
+    if (g.ta && mf_prev == nullptr) axis(xs.nt, xs.pt, xs.h_nt, xs.h_pt, ns.nt, ns.pt, w.wt, true, true);
+    if (g.ta && mf_prev != nullptr) {
+        Vec<T, V> f = xs.h_nt ? xs.nt - xs.c : zero, b = xs.h_pt ? xs.c - xs.pt : zero;
+        f = w.wt * f; b = w.wt * b;
+        Vec<T, V> f_c = f * mf, b_c = b * mf, b_p = b * (*mf_prev), f_n = f * (*mf_next);
+        if (S == HYBRID) { f_c = s * f_c; b_c = s * b_c; b_p = s * b_p; f_n = s * f_n; }
+        if (UP) r = r + (div_where<T, V>(b_p, ns.pt, xs.h_pt) - div_where<T, V>(f_c, ns.c, xs.h_nt));
+        if (DN) r = r + (div_where<T, V>(b_c, ns.c, xs.h_pt) - div_where<T, V>(f_n, ns.nt, xs.h_nt));
+    }
     if (S == HYBRID) r = s * r;
     return r;
 }

@@ -51,17 +51,20 @@ __device__ __forceinline__ float from_right_lane(float v) {
 // as a zero gradient: v_rsq_f32 flushes denormal inputs, and fp32 squares carry no information there anyway
 // (the reference's own float32 path loses |Dx| in the same range).
 __device__ __forceinline__ float inv_norm(float ss, bool site_ok) {
-    return (ss >= 0x1p-126f && site_ok) ? __builtin_amdgcn_rsqf(ss) : 0.f;
+    return (ss >= tiny_sumsq<float>() && site_ok) ? __builtin_amdgcn_rsqf(ss) : 0.f;
 }
 
 // MODE 1: instead of G the kernel writes the sub-gradient DESCENT step of the README loop (README.md:122-123)
 //     x_out = x - step * ((x - x0) + lambda * G(x)),     fid partial = 1/2 |x_out - x0|^2
 // (x is ping-ponged: neighbouring tiles still read the old image), which saves writing and re-reading G.
+// MODE 2: G as in MODE 0 plus the per-voxel norms |Dx| (zeros replaced by +inf: the reference's grad_norms,
+//     pytv/tv_GPU.py:88,135-139), 3 words per voxel instead of the >= 5 of the two-pass form.
 struct SgStepArgs {
     const float* x0;
     float* x_out;
     float step, lambda;
     double* part_fid;
+    float* norms;
 };
 
 // The kernel is issue-bound (hybrid: ~200 vector instructions per site-vector and frame), so the per-site
@@ -264,7 +267,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
                 rn.v[i] = ss.v[i] * n.v[i];
             }
             // four norms in fp32 (each carries its own 2^-24 already), then fp64 across frames / planes / threads
-            if (count && fstore(t)) acc += (double)((rn.v[0] + rn.v[1]) + (rn.v[2] + rn.v[3]));
+            if (count && fstore(t)) {
+                acc += (double)((rn.v[0] + rn.v[1]) + (rn.v[2] + rn.v[3]));
+                if (MODE == 2) {
+                    F4 nv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) nv.v[i] = (n.v[i] > 0.f) ? rn.v[i] : __builtin_inff();
+                    stu(sa.norms + (long long)zl * g.s_z + foff_t(t), voff, nv);
+                }
+            }
             // ---- scatter the products ---------------------------------------------------------------------
             F4 gc = Gc[t], gn = zero;
             if (CEN) {          // one product per axis, to the neighbours on both sides
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_subgrad_one(DG g, WT<float> w, c
                 F4 o = Gp[t];
                 if (S == HYBRID || CEN) o = s * o;
                 const long long foff = (long long)(zl - 1) * g.s_z + foff_t(t);      // uniform
-                if (MODE == 0) {
+                if (MODE != 1) {
                     stu(G + foff, voff, o);
                 } else {
                     const F4 x0v = ldu(sa.x0 + foff, voff), p = lds_P[t][tid];      // p = x(zl-1)

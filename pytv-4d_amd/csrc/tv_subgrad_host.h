@@ -12,6 +12,7 @@ inline int sg_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
     if (g->dtype != TV_F32 || d.nx % 4 != 0 || !sg_m_ok(d.m)) return 0;
+    if (d.wv != nullptr) return 0;                                  // weight volume: two-pass kernels
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return 0;   // two-point axes: forward stencil
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (d.m > SG_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;

@@ -31,6 +31,9 @@ class TvGeom(ctypes.Structure):
         ("reg_z_over_reg", ctypes.c_double), ("reg_time", ctypes.c_double), ("factor_reg_static", ctypes.c_double),
         ("mask_static", ctypes.c_void_p),
         ("time_factor", ctypes.c_void_p),
+        ("time_weight_vol", ctypes.c_void_p),
+        ("time_weight_prev", ctypes.c_void_p),
+        ("time_weight_next", ctypes.c_void_p),
     ]
 
 
@@ -50,6 +53,7 @@ _SIGNATURES = {
     "tv_subgrad": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [_c_double_p, _c_void_p, _c_void_p]),
     "tv_subgrad_fused_supported": (ctypes.c_int, [_G]),
     "tv_subgrad_fused": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [_c_double_p, _c_void_p, _c_void_p]),
+    "tv_subgrad_fused_norms": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [_c_double_p, _c_void_p, _c_void_p]),
     "tv_subgrad_step_fused": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p,
                                                                       _c_void_p, _c_void_p]),
     "tv_cp_dual": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [ctypes.c_double, ctypes.c_double, _c_double_p, _c_void_p, _c_void_p]),
@@ -133,7 +137,14 @@ class Geometry:
     """Python-side owner of a ``tv_geom``: keeps the device mask alive and caches the workspace."""
 
     def __init__(self, shape, scheme, dtype, device, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
-                 factor_reg_static=0.0, nz_global=None, z0=0):
+                 factor_reg_static=0.0, nz_global=None, z0=0, weight_halo=None, weight_dev=None):
+        """mask_static: ``False``, a boolean mask broadcastable from (1, 1, Ny, Nx) (the reference's form, with
+        ``factor_reg_static``), or a FLOAT array of weights on the time regularisation -- per pixel (broadcastable from
+        (1, 1, Ny, Nx)) or per voxel (broadcastable to (Nz, M, Ny, Nx): the reference's to-do "weight matrix of size
+        Nz x M x N x N", README.md:258).  The time channels are multiplied by sqrt(weight).
+        weight_halo: (plane z0-1, plane z0+nz) of a per-voxel weight on a z-slab, each (M, Ny, Nx) or None (only the
+        sub-gradient on a slab needs them).  weight_dev: internal -- (vol, prev, next) device tensors that already hold
+        sqrt(weight) for exactly these planes (sub-slab geometries of the solvers)."""
         if scheme not in SCHEMES:
             raise ValueError("unknown TV scheme %r" % (scheme,))
         if len(shape) != 4:
@@ -145,6 +156,7 @@ class Geometry:
         self.device = torch.device(device)
         self.mask_dev = None
         self.factor_dev = None
+        self.weight_vol = None          # (sqrt-weight volume, plane z0-1 or None, plane z0+nz or None), device tensors
         # largest per-pixel weight on reg_time: the time channels are scaled by sqrt(factor_reg_static) where the mask is
         # set and by sqrt(weight) of a weight map, so |D|^2 <= 4 (2 + reg_z + reg_time * time_weight_max)
         self.time_weight_max = 1.0
@@ -152,13 +164,24 @@ class Geometry:
             mk = torch.as_tensor(np.asarray(mask_static.detach().cpu()) if isinstance(mask_static, torch.Tensor)
                                  else np.asarray(mask_static))
             if mk.dtype.is_floating_point:
-                # a FLOAT array is the per-pixel weight map of the time regularisation (the reference's to-do,
-                # README.md:258: "replace mask_static, factor_reg_static with a weight matrix"): the time channels are
-                # multiplied by sqrt(weight); where(mask, factor, 1) reproduces the boolean mask exactly
+                # a FLOAT array is the weight of the time regularisation (the reference's to-do, README.md:258: "replace
+                # mask_static, factor_reg_static with a weight matrix"): the time channels are multiplied by
+                # sqrt(weight); where(mask, factor, 1) reproduces the boolean mask exactly
                 if bool((mk < 0).any()):
                     raise ValueError("weights must be non-negative")
-                wm = torch.broadcast_to(mk.to(torch.float64), (1, 1, ny, nx)).reshape(ny, nx)
-                self.factor_dev = torch.sqrt(wm).to(dtype).contiguous().to(self.device)
+                per_pixel = mk.dim() <= 2 or all(int(v) == 1 for v in mk.shape[:-2])
+                if per_pixel:
+                    wm = torch.broadcast_to(mk.to(torch.float64), (1, 1, ny, nx)).reshape(ny, nx)
+                    self.factor_dev = torch.sqrt(wm).to(dtype).contiguous().to(self.device)
+                else:       # per voxel: (Nz, M, Ny, Nx)
+                    wm = torch.broadcast_to(mk.to(torch.float64), (nz, m, ny, nx))
+                    halo = [None, None]
+                    for k in (0, 1):
+                        if weight_halo is not None and weight_halo[k] is not None:
+                            hk = torch.as_tensor(np.asarray(weight_halo[k].detach().cpu()) if isinstance(weight_halo[k], torch.Tensor)
+                                                 else np.asarray(weight_halo[k])).to(torch.float64)
+                            halo[k] = torch.sqrt(torch.broadcast_to(hk, (m, ny, nx))).to(dtype).contiguous().to(self.device)
+                    self.weight_vol = (torch.sqrt(wm).to(dtype).contiguous().to(self.device), halo[0], halo[1])
                 self.time_weight_max = float(wm.max())
             else:
                 mk = torch.broadcast_to(mk.to(torch.bool), (1, 1, ny, nx)).reshape(ny, nx)
@@ -176,6 +199,14 @@ class Geometry:
         g.factor_reg_static = float(factor_reg_static)
         g.mask_static = ptr(self.mask_dev)
         g.time_factor = ptr(self.factor_dev)
+        if weight_dev is not None:
+            self.weight_vol = weight_dev
+        if self.weight_vol is not None:
+            if tuple(self.weight_vol[0].shape) != (nz, m, ny, nx):
+                raise ValueError("weight volume has shape %s, the image %s" % (tuple(self.weight_vol[0].shape), (nz, m, ny, nx)))
+            g.time_weight_vol = ptr(self.weight_vol[0])
+            g.time_weight_prev = ptr(self.weight_vol[1])
+            g.time_weight_next = ptr(self.weight_vol[2])
         self.c = g
         nd = lib().tv_num_channels(ctypes.byref(g))
         if nd < 0:

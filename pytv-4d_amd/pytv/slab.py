@@ -123,6 +123,17 @@ class Slab:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def allreduce_max_(self, t):
+        """In-place maximum over ranks of a (small, fp64) tensor."""
+        if self.sharded:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.detach().to("cpu")
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
     def local(self, full):
         """This rank's planes of a full array whose axis 0 is z."""
         return full[self.z0:self.z0 + self.nz]

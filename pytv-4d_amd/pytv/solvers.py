@@ -52,16 +52,46 @@ class _SlabProblem:
         self.kw = dict(reg_z_over_reg=reg_z_over_reg, reg_time=reg_time, mask_static=mask_static,
                        factor_reg_static=factor_reg_static)
         self._geoms = {}
-        self.geo = self.geom(0, self.slab.nz)
         self.lib = _nv.lib()
+        nz, m, ny, nx = self.x0.shape
+        geo = _nv.Geometry((nz, m, ny, nx), scheme, self.dtype, self.device, nz_global=self.slab.nz_global, z0=self.slab.z0,
+                           **self.kw)
+        self._wvol = None
+        if geo.weight_vol is not None:
+            # per-voxel weights on the time regularisation (mask_static = float array of this rank's slab shape): the
+            # neighbours' boundary planes of the weight are fetched ONCE (the sub-gradient's ghost-plane norms read them)
+            wv = geo.weight_vol[0]
+            gp = self.new_plane() if self.slab.prev is not None else None
+            gn = self.new_plane() if self.slab.next is not None else None
+            self.slab.wait(self.slab.exchange(send_prev=wv[0:1] if self.slab.prev is not None else None,
+                                              send_next=wv[nz - 1:nz] if self.slab.next is not None else None,
+                                              recv_prev=gp, recv_next=gn))
+            self._wvol = (wv, gp, gn)
+            twm = torch.tensor([geo.time_weight_max], dtype=torch.float64, device=self.device)
+            if self.slab.sharded:
+                self.slab.allreduce_max_(twm)
+            self._twmax = float(twm.item())
+            geo = None
+        self.geo = geo if geo is not None else self.geom(0, nz)
+        self._geoms[(0, nz)] = self.geo
 
     def geom(self, a, b):
         """Geometry of local planes [a, b) seen as a slab of the global volume."""
         key = (a, b)
         if key not in self._geoms:
             nz, m, ny, nx = self.x0.shape
-            self._geoms[key] = _nv.Geometry((b - a, m, ny, nx), self.scheme, self.dtype, self.device,
-                                            nz_global=self.slab.nz_global, z0=self.slab.z0 + a, **self.kw)
+            if self._wvol is None:
+                self._geoms[key] = _nv.Geometry((b - a, m, ny, nx), self.scheme, self.dtype, self.device,
+                                                nz_global=self.slab.nz_global, z0=self.slab.z0 + a, **self.kw)
+            else:
+                wv, gp, gn = self._wvol
+                kw = dict(self.kw, mask_static=False, factor_reg_static=0)
+                dev = (wv[a:b], wv[a - 1] if a > 0 else (gp[0] if gp is not None else None),
+                       wv[b] if b < nz else (gn[0] if gn is not None else None))
+                g = _nv.Geometry((b - a, m, ny, nx), self.scheme, self.dtype, self.device, nz_global=self.slab.nz_global,
+                                 z0=self.slab.z0 + a, weight_dev=dev, **kw)
+                g.time_weight_max = self._twmax
+                self._geoms[key] = g
         return self._geoms[key]
 
     @property

@@ -2,11 +2,11 @@
 
 ``tv_<scheme>(img, ...)`` returns the total variation of ``img`` and the reference's sub-gradient
 (pytv/tv_GPU.py:47,142,217,290).  The reference materialises D(img) (Nd x the image), then runs
-3..14 sliced ``G[...] += +-D/norm`` updates; here one fused HIP pass writes |D img| per voxel and the
-TV partial sums, a second one gathers G straight from ``img`` and the norms -- the gradient array is
-never stored (C-ABI ``tv_subgrad``, include/pytv4d.h).  When the norms are not asked for
-(``return_grad_norms=False``) and the geometry allows, TV and G come from a single pass over ``img``
-(``tv_subgrad_fused``): the norms never leave the chip either.
+3..14 sliced ``G[...] += +-D/norm`` updates; here TV, G and -- when asked for -- the per-voxel norms come
+from a SINGLE pass over ``img`` (C-ABI ``tv_subgrad_fused`` / ``tv_subgrad_fused_norms``, include/pytv4d.h: fp32,
+Nx % 4 == 0); fp64 input, ragged rows, a per-voxel weight volume and central with a two-point axis take the
+two-pass form (``tv_subgrad``: 1/|D img| per voxel + TV partial sums, then a gather of G from ``img`` and those
+norms).  The gradient array is never stored either way.
 
 Conventions kept: ``mask`` zeroes the caller's array in place; the TV
 value is always a 0-d numpy array; G (and grad_norms) are numpy unless ``return_pytorch_tensor``;
@@ -34,26 +34,30 @@ def one_pass_ok(geo, itemsize=4):
 def tv_subgradient_device(x, scheme, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0,
                           want_norms=True, one_pass=None):
     """Device-resident core: x is a contiguous fp32/fp64 device tensor (Nz, M, Ny, Nx).
-    Returns (tv 0-d fp64 device tensor, G, inverse-norm view 1/|Dx| with 0 where |Dx| == 0) without any
-    host synchronisation.  With ``want_norms=False`` the third item is None and, where the geometry allows,
-    TV and G come from ONE pass over x (``one_pass``: None = automatic, True / False = force)."""
+    Returns (tv 0-d fp64 device tensor, G, grad_norms) without any host synchronisation; grad_norms is |Dx| per voxel
+    with zeros replaced by +inf (the reference's convention, tv_GPU.py:88), or None with ``want_norms=False``.
+    Where the geometry allows, everything comes from ONE pass over x (``one_pass``: None = automatic, True / False =
+    force); otherwise from the two-pass kernels (1/|Dx| to memory, then a gather)."""
     geo = _nv.Geometry(tuple(x.shape), scheme, x.dtype, x.device, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
     nz, m, ny, nx = geo.shape
     G = torch.empty_like(x)
     if one_pass is None:
-        one_pass = (not want_norms) and one_pass_ok(geo, x.element_size())
+        one_pass = one_pass_ok(geo, x.element_size())
+    tv = geo.scalar()
     if one_pass:
         if want_norms:
-            raise ValueError("the one-pass kernel does not produce the per-voxel norms")
-        tv = geo.scalar()
+            norms = torch.empty_like(x)
+            _nv.check(_nv.lib().tv_subgrad_fused_norms(geo.ref, _nv.ptr(x), None, None, _nv.ptr(G), _nv.ptr(norms), _nv.ptr(tv),
+                                                       _nv.ptr(geo.workspace()), _nv.current_stream(x.device)))
+            return tv, G, norms
         _nv.check(_nv.lib().tv_subgrad_fused(geo.ref, _nv.ptr(x), None, None, _nv.ptr(G), _nv.ptr(tv),
                                              _nv.ptr(geo.workspace()), _nv.current_stream(x.device)))
         return tv, G, None
     norms_ext = torch.empty((nz + 2, m, ny, nx), dtype=x.dtype, device=x.device)
-    tv = geo.scalar()
     _nv.check(_nv.lib().tv_subgrad(geo.ref, _nv.ptr(x), None, None, _nv.ptr(G), _nv.ptr(norms_ext), _nv.ptr(tv),
                                    _nv.ptr(geo.workspace()), _nv.current_stream(x.device)))
-    return tv, G, norms_ext[1:nz + 1]
+    # the kernels keep 1 / |Dx| (0 where |Dx| counts as zero): the reference's grad_norms is its reciprocal
+    return tv, G, (torch.reciprocal(norms_ext[1:nz + 1]) if want_norms else None)
 
 
 def _tv(scheme, img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_static, return_pytorch_tensor,
@@ -63,12 +67,11 @@ def _tv(scheme, img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_sta
     x, _ = _to_device(img)
     if x.dim() != 4:
         raise ValueError("img must be 4-D (Nz, M, N, N), got shape %s" % (tuple(x.shape),))
-    tv, G, inv_n = tv_subgradient_device(x, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static,
-                                         want_norms=bool(return_grad_norms))
+    tv, G, gn = tv_subgradient_device(x, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static,
+                                      want_norms=bool(return_grad_norms))
     tv = tv.detach().cpu().numpy()          # 0-d numpy, always (tv_GPU.py:85 via compute_L21_norm)
     if not return_grad_norms:
         return (tv, G) if return_pytorch_tensor else (tv, G.detach().cpu().numpy())
-    gn = torch.reciprocal(inv_n)            # the reference's grad_norms: |Dx| with zeros replaced by +inf (tv_GPU.py:88)
     if return_pytorch_tensor:
         return tv, G, gn
     return tv, G.detach().cpu().numpy(), gn.detach().cpu().numpy()

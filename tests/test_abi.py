@@ -41,8 +41,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from pytv import _native as nv
     # 6 x int64 + 2 x int32 + 3 x double + pointer, no padding surprises
-    assert ctypes.sizeof(nv.TvGeom) == 6 * 8 + 2 * 4 + 3 * 8 + 8 + 8
-    assert nv.TvGeom.scheme.offset == 48 and nv.TvGeom.reg_z_over_reg.offset == 56 and nv.TvGeom.mask_static.offset == 80 and nv.TvGeom.time_factor.offset == 88
+    assert ctypes.sizeof(nv.TvGeom) == 6 * 8 + 2 * 4 + 3 * 8 + 8 + 8 + 3 * 8
+    assert nv.TvGeom.scheme.offset == 48 and nv.TvGeom.reg_z_over_reg.offset == 56 and nv.TvGeom.mask_static.offset == 80 and nv.TvGeom.time_factor.offset == 88 and nv.TvGeom.time_weight_vol.offset == 96 and nv.TvGeom.time_weight_next.offset == 112
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)

@@ -561,7 +561,7 @@ def test_slab_calls_equal_unsharded(pytv, scheme, cuts, shape, dtype, zchunk, tv
     nv.check(lib.tv_D(full.ref, nv.ptr(x), None, None, nv.ptr(D_full), st))
     DT_full = torch.empty_like(x)
     nv.check(lib.tv_DT(full.ref, nv.ptr(y), None, None, nv.ptr(DT_full), st))
-    tv_full, G_full, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, **kw)
+    tv_full, G_full, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, one_pass=False, **kw)
     A_full = torch.empty_like(x)
     dot_full = full.scalar()
     nv.check(lib.tv_normal_op(full.ref, nv.ptr(x), None, None, 0.3, nv.ptr(A_full), nv.ptr(dot_full), nv.ptr(full.workspace()), st))

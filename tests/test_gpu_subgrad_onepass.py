@@ -76,7 +76,7 @@ def test_one_pass_matches_oracle_and_two_pass(pytv, scheme, zchunk, shape, lz, m
     tv_ref, G_ref = orc.tv(img.astype(np.float64), scheme, **kw)
     np.testing.assert_allclose(G1.cpu().numpy(), G_ref, **F32)
     assert abs(tv1 - float(tv_ref)) <= 1e-6 * abs(float(tv_ref))
-    tv2, G2, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, **kw)
+    tv2, G2, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, one_pass=False, **kw)
     np.testing.assert_allclose(G1.cpu().numpy(), G2.cpu().numpy(), rtol=2e-6, atol=2e-5)
     assert abs(tv1 - float(tv2)) <= 1e-6 * abs(tv1)
 
@@ -252,3 +252,57 @@ def test_subgradient_descent_graph_replay_equals_eager(pytv, dtype):
     la, lb = a.run(47, graph=True), b.run(47, graph=False)
     assert np.array_equal(la, lb)
     assert torch.equal(a.result(), b.result())
+
+
+@pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
+@pytest.mark.parametrize("shape,lz,mu", [((5, 3, 20, 64), 1.0, 0.5), ((3, 8, 9, 132), 1.3, 1.0), ((4, 12, 7, 64), 1.0, 0.7),
+                                         ((1, 1, 33, 68), 1.0, 0.0)])
+def test_one_pass_with_norms_matches_the_reference_convention(pytv, scheme, shape, lz, mu):
+    """tv_subgrad_fused_norms: G, TV and grad_norms (|Dx| with zeros replaced by +inf, pytv/tv_GPU.py:88,135-139) from
+    ONE pass; the drop-in tv_<scheme>(..., return_grad_norms=True) takes it."""
+    import torch
+    rng = np.random.default_rng(11 + shape[0])
+    img = (rng.standard_normal(shape) * 10).astype(np.float32)
+    img[:, :, 2:5, 2:30] = 3.0                  # a flat patch: |Dx| == 0 there -> +inf
+    kw = dict(reg_z_over_reg=lz, reg_time=mu)
+    if scheme == "central" and (shape[0] == 2 or shape[1] == 2):
+        pytest.skip("central with a two-point axis")
+    tv_ref, G_ref, n_ref = orc.tv(img.astype(np.float64), scheme, return_grad_norms=True, **kw)
+    tv1, G1, n1 = pytv.tv_GPU.tv_subgradient_device(torch.as_tensor(img).cuda(), scheme, want_norms=True, one_pass=True, **kw)
+    n1 = n1.cpu().numpy()
+    assert np.array_equal(np.isinf(n1), np.isinf(n_ref)) and np.isinf(n1).sum() > 0
+    fin = np.isfinite(n_ref)
+    np.testing.assert_allclose(n1[fin], n_ref[fin], rtol=2e-6)
+    np.testing.assert_allclose(G1.cpu().numpy(), G_ref, **F32)
+    assert abs(float(tv1) - float(tv_ref)) <= 1e-6 * float(tv_ref)
+    out = getattr(pytv.tv_GPU, "tv_" + scheme)(img.copy(), return_grad_norms=True, **kw)
+    assert np.array_equal(out[2], n1) and np.array_equal(out[1], G1.cpu().numpy())
+
+
+@pytest.mark.parametrize("scheme", ONE_PASS_SCHEMES)
+def test_zero_gradient_rule_is_the_same_on_every_path(pytv, scheme):
+    """A gradient whose SQUARE is below the smallest normal fp32 number (|Dx| < 1.1e-19) counts as zero on the one-pass
+    and on the two-pass kernels alike (the reference zeroes at exactly 0; fp32 squares carry nothing below that), so
+    return_grad_norms=True / False give the same G and TV.  Steps of 1e-21 on a flat image: every |Dx| is denormal-squared."""
+    import torch
+    shape = (3, 2, 8, 64)
+    img = np.full(shape, 2.0, np.float32)
+    img += (np.arange(64, dtype=np.float32) * 1e-30)[None, None, None, :]     # swallowed by fp32: exactly flat
+    x = torch.as_tensor(img).cuda()
+    tiny = torch.zeros(shape, device="cuda")
+    tiny[:, :, 3, 10:20] = 1e-21              # |Dx| ~ 1e-21: its square underflows
+    tiny[:, :, 5, 30] = 1e-3                  # a regular gradient for contrast
+    kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
+    res = []
+    for one_pass in (True, False):
+        if one_pass and scheme == "central" and min(shape[:2]) == 2:
+            continue
+        tv, G, n = pytv.tv_GPU.tv_subgradient_device(tiny, scheme, want_norms=True, one_pass=one_pass, **kw)
+        res.append((float(tv), G.cpu().numpy(), n.cpu().numpy()))
+    for tv, G, n in res:
+        assert np.isinf(n[:, :, 3, 12]).all()                 # counted as zero gradient
+        assert np.isfinite(n[:, :, 5, 30]).all()
+        assert np.abs(G[:, :, 3, 12:18]).max() == 0.0         # and contributes nothing
+    if len(res) == 2:
+        np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(np.isinf(res[0][2]), np.isinf(res[1][2]))

@@ -1,0 +1,242 @@
+"""Per-VOXEL weights on the time regularisation: ``mask_static=<float array of shape (Nz, M, Ny, Nx)>`` (C-ABI fields
+``time_weight_vol`` / ``time_weight_prev`` / ``time_weight_next`` = sqrt(W)).  This is the reference's first to-do
+(README.md:258: "Replace mask_static, factor_reg_static with a weight matrix of size Nz x M x N x N that is passed
+directly onto all functions").  No reference behaviour exists for a weight that varies along z or t; what pins it:
+  * a weight volume that is constant along z and t must reproduce the per-pixel weight map and, through it, the
+    reference's boolean-mask golden vectors;
+  * D^T is the exact adjoint of D (checked in fp64 on the GPU) -- that defines where the factor of every sample sits;
+  * general volumes follow the same formula in the oracle (tests/test_oracle_weights.py pins it on the CPU).
+Every entry point that takes a geometry is exercised: D, D^T, TV + sub-gradient (with norms; a weight volume runs the
+two-pass kernels), Chambolle-Pock, ADMM (normal operator, z/u update, D^T axpy), sub-gradient descent, slab calls with
+ghost planes of the weight, and two ranks sharing the GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PKG, ROOT, SCHEMES
+from oracle import tv_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pytv():
+    import pytv
+    return pytv
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_constant_volume_reproduces_the_reference_mask_golden(pytv, scheme):
+    z = np.load(os.path.join(GOLDEN, "ops_%s.npz" % scheme))
+    done = 0
+    for name in z["case_names"]:
+        name = str(name)
+        mask = z[name + "/mask"]
+        if mask.ndim == 0:
+            continue
+        lz, mu, factor = z[name + "/params"]
+        x, y = z[name + "/x"], z[name + "/y"]
+        W = np.broadcast_to(np.where(mask, factor, 1.0), x.shape).copy()         # a full (Nz, M, Ny, Nx) volume
+        kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=W)
+        tol = dict(rtol=1e-5, atol=1e-5) if x.dtype == np.float32 else dict(rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(getattr(pytv.tv_operators_GPU, "D_" + scheme)(x, **kw), z[name + "/D"], **tol)
+        np.testing.assert_allclose(getattr(pytv.tv_operators_GPU, "D_T_" + scheme)(y, **kw), z[name + "/DT"], **tol)
+        tv, G, gn = getattr(pytv.tv_GPU, "tv_" + scheme)(x.copy(), return_grad_norms=True, **kw)
+        np.testing.assert_allclose(float(tv), z[name + "/tv"], rtol=tol["rtol"])
+        np.testing.assert_allclose(G, z[name + "/G"], **tol)
+        done += 1
+    assert done >= 2
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype,shape", [(np.float64, (4, 3, 9, 14)), (np.float32, (5, 4, 18, 132)), (np.float32, (6, 8, 12, 64)),
+                                         (np.float32, (3, 2, 7, 9)), (np.float64, (1, 5, 6, 8))])
+def test_general_weight_volume_matches_oracle(pytv, scheme, dtype, shape):
+    import torch
+    from pytv import _native as nv
+    rng = np.random.default_rng(47)
+    x = (rng.standard_normal(shape) * 10).astype(dtype)
+    W = rng.random(shape) * 3.0
+    W[1:, 1, 2:4, 3:7] = 0.0                        # no time regularisation at all on a patch of one frame
+    kw = dict(reg_z_over_reg=1.3, reg_time=0.8, mask_static=W)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == np.float32 else dict(rtol=1e-11, atol=1e-11)
+    x64 = x.astype(np.float64)
+    g = nv.Geometry(shape, scheme, torch.float64 if dtype == np.float64 else torch.float32, "cuda", **kw)
+    assert g.weight_vol is not None and g.factor_dev is None and g.mask_dev is None
+    assert not nv.lib().tv_cp_fused_supported(g.ref) and not nv.lib().tv_subgrad_fused_supported(g.ref)
+    d = getattr(pytv.tv_operators_GPU, "D_" + scheme)(x, **kw)
+    np.testing.assert_allclose(d, orc.D(x64, scheme, **kw), **tol)
+    y = rng.standard_normal(d.shape).astype(dtype)
+    dt = getattr(pytv.tv_operators_GPU, "D_T_" + scheme)(y, **kw)
+    np.testing.assert_allclose(dt, orc.D_T(y.astype(np.float64), scheme, **kw), **tol)
+    # exact adjointness, accumulated in fp64
+    lhs = float(np.sum(d.astype(np.float64) * y.astype(np.float64)))
+    rhs = float(np.sum(x64 * dt.astype(np.float64)))
+    assert abs(lhs - rhs) <= (1e-4 if dtype == np.float32 else 1e-10) * max(abs(lhs), 1.0)
+    # TV + sub-gradient (+ norms)
+    tv_ref, G_ref, n_ref = orc.tv(x64, scheme, return_grad_norms=True, **kw)
+    for norms in (True, False):
+        out = getattr(pytv.tv_GPU, "tv_" + scheme)(x.copy(), return_grad_norms=norms, **kw)
+        np.testing.assert_allclose(float(out[0]), tv_ref, rtol=1e-6 if dtype == np.float32 else 1e-12)
+        np.testing.assert_allclose(out[1], G_ref, **tol)
+        if norms:
+            fin = np.isfinite(n_ref)
+            np.testing.assert_allclose(out[2][fin], n_ref[fin], rtol=1e-5 if dtype == np.float32 else 1e-11)
+    if scheme == "central" and (shape[0] == 2 or shape[1] == 2):
+        return
+    # Chambolle-Pock (kernel pair), ADMM, sub-gradient descent
+    x0 = torch.as_tensor(x * 5).cuda()
+    ref_x, ref_loss = orc.chambolle_pock(x64 * 5, 8, 7.0, scheme=scheme, **kw)
+    cp = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, **kw)
+    assert not cp.fused
+    loss = cp.run(8)
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-5 if dtype == np.float32 else 1e-10)
+    np.testing.assert_allclose(cp.result().cpu().numpy(), ref_x, rtol=1e-4, atol=1e-3 if dtype == np.float32 else 1e-8)
+    ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, **kw)
+    la = ad.run(3)
+    ax, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, **kw)
+    np.testing.assert_allclose(la, lref, rtol=1e-4 if dtype == np.float32 else 1e-9)
+    np.testing.assert_allclose(ad.result().cpu().numpy(), ax, rtol=1e-4, atol=5e-3 if dtype == np.float32 else 1e-8)
+    sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, **kw)
+    ls = sg.run(5)
+    sx, sref = orc.subgradient_descent(x64 * 5, 5, 7.0, 2e-3, scheme=scheme, **kw)
+    np.testing.assert_allclose(ls, sref, rtol=1e-5 if dtype == np.float32 else 1e-10)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_slab_calls_with_a_weight_volume_equal_unsharded(pytv, scheme, dtype):
+    """Every C-ABI operator on a z-slab (weights of the slab + ghost planes of the weight) == the unsharded call."""
+    import torch
+    from pytv import _native as nv
+    lib = nv.lib()
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    shape = (7, 3, 6, 20)
+    rng = np.random.default_rng(5)
+    x = torch.as_tensor((rng.standard_normal(shape) * 10).astype(dtype)).cuda()
+    W = rng.random(shape) * 2.5
+    kw = dict(reg_z_over_reg=1.2, reg_time=0.9)
+    gF = nv.Geometry(shape, scheme, tdt, "cuda", mask_static=W, **kw)
+    st = nv.current_stream(x.device)
+    dF = torch.empty(gF.grad_shape, dtype=tdt, device="cuda")
+    nv.check(lib.tv_D(gF.ref, nv.ptr(x), None, None, nv.ptr(dF), st))
+    GF, nF, tvF = torch.empty_like(x), torch.empty((shape[0] + 2,) + shape[1:], dtype=tdt, device="cuda"), gF.scalar()
+    nv.check(lib.tv_subgrad(gF.ref, nv.ptr(x), None, None, nv.ptr(GF), nv.ptr(nF), nv.ptr(tvF), nv.ptr(gF.workspace()), st))
+    oF, dotF = torch.empty_like(x), gF.scalar()
+    nv.check(lib.tv_normal_op(gF.ref, nv.ptr(x), None, None, 0.3, nv.ptr(oF), nv.ptr(dotF), nv.ptr(gF.workspace()), st))
+    tFull = torch.empty_like(x)
+    nv.check(lib.tv_DT(gF.ref, nv.ptr(dF), None, None, nv.ptr(tFull), st))
+    per = 2 if scheme == "hybrid" else 1
+    ch_b, ch_f = 2 * per, 2 * per + (1 if scheme == "hybrid" else 0)
+    tv_sum = 0.0
+    for a, b in ((0, 3), (3, 5), (5, 7)):
+        halo = (W[a - 1] if a > 0 else None, W[b] if b < shape[0] else None)
+        gS = nv.Geometry((b - a,) + shape[1:], scheme, tdt, "cuda", mask_static=W[a:b], weight_halo=halo, nz_global=shape[0], z0=a, **kw)
+        xp1 = x[a - 1:a] if a > 0 else None
+        xn1 = x[b:b + 1] if b < shape[0] else None
+        xp2 = x[a - 2:a] if a >= 2 else (torch.cat([torch.zeros_like(x[0:1]), x[0:1]]) if a == 1 else None)
+        xn2 = x[b:b + 2] if b + 2 <= shape[0] else (torch.cat([x[b:b + 1], torch.zeros_like(x[0:1])]) if b + 1 == shape[0] else None)
+        dS = torch.empty(gS.grad_shape, dtype=tdt, device="cuda")
+        nv.check(lib.tv_D(gS.ref, nv.ptr(x[a:b]), nv.ptr(xp1), nv.ptr(xn1), nv.ptr(dS), st))
+        assert torch.equal(dS, dF[a:b])
+        GS, nS, tvS = torch.empty_like(x[a:b]), torch.empty((b - a + 2,) + shape[1:], dtype=tdt, device="cuda"), gS.scalar()
+        nv.check(lib.tv_subgrad(gS.ref, nv.ptr(x[a:b]), nv.ptr(xp2), nv.ptr(xn2), nv.ptr(GS), nv.ptr(nS), nv.ptr(tvS), nv.ptr(gS.workspace()), st))
+        assert torch.equal(GS, GF[a:b])
+        tv_sum += tvS.item()
+        oS, dotS = torch.empty_like(x[a:b]), gS.scalar()
+        nv.check(lib.tv_normal_op(gS.ref, nv.ptr(x[a:b]), nv.ptr(xp2), nv.ptr(xn2), 0.3, nv.ptr(oS), nv.ptr(dotS), nv.ptr(gS.workspace()), st))
+        assert torch.equal(oS, oF[a:b])
+        tS = torch.empty_like(x[a:b])
+        yp = dF[a - 1, ch_b].contiguous() if a > 0 else None
+        yn = dF[b, ch_f].contiguous() if b < shape[0] else None
+        nv.check(lib.tv_DT(gS.ref, nv.ptr(dF[a:b].contiguous()), nv.ptr(yp), nv.ptr(yn), nv.ptr(tS), st))
+        assert torch.equal(tS, tFull[a:b])
+    assert abs(tv_sum - tvF.item()) <= 1e-6 * tvF.item()
+    # a slab without the ghost planes of the weight is an error for the sub-gradient (its ghost-plane norms need them)
+    gBad = nv.Geometry((2,) + shape[1:], scheme, tdt, "cuda", mask_static=W[3:5], nz_global=shape[0], z0=3, **kw)
+    rc = lib.tv_subgrad(gBad.ref, nv.ptr(x[3:5]), nv.ptr(x[1:3]), nv.ptr(x[5:7]), nv.ptr(GF[3:5]), nv.ptr(nF), nv.ptr(tvF), nv.ptr(gBad.workspace()), st)
+    assert rc == -2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, shape, scheme, kw, ret):
+    import torch
+    import torch.distributed as dist
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pytv
+        from pytv.slab import Slab
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(77)
+        x0_full = (60.0 * rng.random(shape)).astype(np.float32)
+        W = rng.random(shape) * 2.0
+        slab = Slab(shape[0])
+        x0 = torch.as_tensor(slab.local(x0_full).copy()).cuda()
+        kwl = dict(kw, mask_static=slab.local(W).copy())
+        out = {"z": (slab.z0, slab.nz)}
+        cp = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, slab=slab, **kwl)
+        out["cp_loss"], out["cp_x"], out["tau"] = cp.run(6), cp.result().cpu().numpy(), cp.tau
+        sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, slab=slab, **kwl)
+        out["sg_loss"], out["sg_x"] = sg.run(4), sg.result().cpu().numpy()
+        ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, **kwl)
+        out["ad_loss"], out["ad_x"] = ad.run(2), ad.result().cpu().numpy()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_sharded_solvers_with_a_weight_volume_equal_the_unsharded_oracle(scheme):
+    import torch.multiprocessing as mp
+    shape, world = (9, 3, 8, 16), 3
+    kw = dict(reg_z_over_reg=1.3, reg_time=0.7)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), shape, scheme, kw, ret), nprocs=world, join=True)
+    rng = np.random.default_rng(77)
+    x0 = (60.0 * rng.random(shape)).astype(np.float32).astype(np.float64)
+    W = rng.random(shape) * 2.0
+    kwf = dict(kw, mask_static=W)
+    wx, wloss = orc.chambolle_pock(x0, 6, 7.0, scheme=scheme, **kwf)
+    sx, sloss = orc.subgradient_descent(x0, 4, 7.0, 2e-3, scheme=scheme, **kwf)
+    ax, aloss = orc.admm(x0, 2, 7.0, 0.1, 3, scheme=scheme, **kwf)
+    for r in range(world):
+        z0, nz = ret[r]["z"]
+        assert abs(ret[r]["tau"] - orc.cp_step_size(scheme, shape[0], shape[1], 1.3, 0.7, float(W.max()))) < 1e-15
+        np.testing.assert_allclose(ret[r]["cp_loss"], wloss, rtol=1e-5)
+        np.testing.assert_allclose(ret[r]["cp_x"], wx[z0:z0 + nz], rtol=1e-5, atol=2e-3)
+        np.testing.assert_allclose(ret[r]["sg_loss"], sloss, rtol=1e-5)
+        np.testing.assert_allclose(ret[r]["sg_x"], sx[z0:z0 + nz], rtol=1e-5, atol=2e-3)
+        np.testing.assert_allclose(ret[r]["ad_loss"], aloss, rtol=5e-5)
+        np.testing.assert_allclose(ret[r]["ad_x"], ax[z0:z0 + nz], rtol=1e-4, atol=5e-3)
+
+
+def test_cp_with_a_strong_static_weight_converges(pytv):
+    """the step-size bound must include the largest time weight (|D|^2 <= 4 (2 + reg_z + reg_time max W)).
+    With factor_reg_static = 25 the old tau = 1 / (1 + 4 (2 + 1 + 1)) violates tau (sigma_A + sigma_D |D|^2) <= 1."""
+    import torch
+    rng = np.random.default_rng(3)
+    shape = (4, 6, 24, 64)
+    x0 = torch.as_tensor((100 * rng.random(shape)).astype(np.float32)).cuda()
+    mask = np.zeros(shape[2:], bool)
+    mask[4:20, 8:56] = True
+    for kw in (dict(mask_static=mask, factor_reg_static=25.0), dict(mask_static=np.where(mask, 25.0, 1.0)),
+               dict(mask_static=np.broadcast_to(np.where(mask, 25.0, 1.0), shape).copy())):
+        cp = pytv.solvers.ChambollePock(x0, 25.0, scheme="hybrid", reg_time=1.0, **kw)
+        assert abs(cp.tau - 1.0 / (1.0 + 4.0 * (2.0 + 1.0 + 25.0))) < 1e-12
+        loss = cp.run(60)
+        assert np.all(np.diff(loss[5:]) <= 1e-7 * loss[5]), "loss must decrease monotonically"

@@ -28,7 +28,7 @@ for case in range(n_cases):
         continue
     tv1, G1, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=False, one_pass=True, **kw)
     tv1b, G1b, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, want_norms=False, one_pass=True, **kw)
-    tv2, G2, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, **kw)
+    tv2, G2, _ = pytv.tv_GPU.tv_subgradient_device(x, scheme, one_pass=False, **kw)
     ok = torch.equal(G1, G1b) and float(tv1) == float(tv1b) and torch.allclose(G1, G2, rtol=1e-5, atol=2e-5) \
         and abs(float(tv1) - float(tv2)) <= 1e-6 * max(1.0, abs(float(tv2)))
     done += 1
