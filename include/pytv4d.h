@@ -194,6 +194,31 @@ int tv_dot(const tv_geom* g, const void* a, const void* b, double* result, void*
 int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, double step, double lambda,
                     double* fid, void* ws, void* stream);
 
+/* ---- multi-GPU: z-slab neighbours over RCCL, one process per GPU ------------------------------ */
+/* The reference is single-GPU (its README only remarks that the (Nz, M, N, N) layout "can be decomposed easily along z",
+ * README.md:235).  Rank r holds the planes [z0, z0 + nz) (tv_geom::z0 / nz_global) and, per operator apply, trades the
+ * boundary plane(s) named by the halo arguments above with ranks r-1 / r+1: a chain, not a ring.
+ *   tv_ctx_unique_id : rank 0 fills 128 bytes; the host program hands them to every rank by its own means
+ *   tv_ctx_create    : collective over the nranks processes (ncclCommInitRank); `device` = HIP device of this process
+ *   tv_halo_exchange : ONE grouped exchange on `stream`, in stream order, no host synchronisation: `count` elements of
+ *                      `dtype` to / from prev_rank and next_rank (-1 = no such neighbour; NULL buffer = nothing that way).
+ *                      Matching is per peer in posting order: a rank's send_next meets its next rank's recv_prev.
+ *   tv_allreduce_f64 : in-place sum / max of n fp64 device words over all ranks, on `stream`
+ * RCCL is bound at run time (dlopen): hosts that never create a context never load it.
+ * Errors: 0 ok, < 0 argument, 1..999 hipError_t, 1000 + ncclResult_t. */
+#define TV_UNIQUE_ID_BYTES 128
+#define TV_SUM 0
+#define TV_MAX 1
+typedef struct tv_ctx tv_ctx;
+int tv_ctx_unique_id(void* id_out);
+int tv_ctx_create(tv_ctx** ctx, int rank, int nranks, const void* unique_id, int device);
+int tv_ctx_destroy(tv_ctx* ctx);
+int tv_ctx_rank(const tv_ctx* ctx);
+int tv_ctx_size(const tv_ctx* ctx);
+int tv_halo_exchange(tv_ctx* ctx, int32_t dtype, int64_t count, int prev_rank, int next_rank, const void* send_prev,
+                     const void* send_next, void* recv_prev, void* recv_next, void* stream);
+int tv_allreduce_f64(tv_ctx* ctx, double* buf, int64_t n, int32_t op, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

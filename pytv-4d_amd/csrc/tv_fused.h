@@ -34,7 +34,13 @@ using F4 = Vec<float, 4>;
 #ifndef TV_FUSED_TR
 #define TV_FUSED_TR 4
 #endif
-constexpr int CP_TR = TV_FUSED_TR, CP_TL = 64 / CP_TR, CP_WC = 4 * CP_TL, CP_BC = 4 * CP_WC;
+#ifndef TV_FUSED_NW
+#define TV_FUSED_NW 4
+#endif
+// CP_NW waves side by side form the block tile (they hand their tile-edge COLUMN terms to each other through LDS).
+// -DTV_FUSED_TR=8 -DTV_FUSED_NW=8: 8-row wave tiles in a block of 8 waves = 8 rows x 256 columns (one block per CU)
+constexpr int CP_NW = TV_FUSED_NW;
+constexpr int CP_TR = TV_FUSED_TR, CP_TL = 64 / CP_TR, CP_WC = 4 * CP_TL, CP_BC = CP_NW * CP_WC;
 constexpr int CP_LSH = (CP_TL == 16) ? 4 : 3;
 static_assert(CP_TR == 4 || CP_TR == 8, "wave tile: 4 x 16 or 8 x 8");
 
@@ -70,9 +76,9 @@ __device__ __forceinline__ FusedCoord cp_coord(const DG& g, int zchunk, int chun
     c.row = c.lane >> CP_LSH;
     c.lx = c.lane & (CP_TL - 1);
     const int nxv = g.nx / 4;
-    const int tiles_x = (nxv + 4 * CP_TL - 1) / (4 * CP_TL);
+    const int tiles_x = (nxv + CP_NW * CP_TL - 1) / (CP_NW * CP_TL);
     const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
-    c.col0 = (bx * 4 * CP_TL + (int)threadIdx.y * CP_TL + c.lx) * 4;
+    c.col0 = (bx * CP_NW * CP_TL + (int)threadIdx.y * CP_TL + c.lx) * 4;
     c.y = by * CP_TR + c.row;
     c.ok = (c.col0 < g.nx) && (c.y < g.ny);
     c.zs = ((int)blockIdx.y + chunk0) * zchunk;
@@ -177,7 +183,7 @@ struct FusedArgs {
 // [t0, t0 + M) of the volume (M = CP_TWN), reads x of the frame on either side of its window for the time differences
 // and leaves the adjoint terms that cross a window seam to the fix-up (exactly like the z-chunk edges)
 template <int S, int M, bool XW, bool TWIN = false>
-__global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk, int chunk0) {
+__global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk, int chunk0) {
     __shared__ double sm[16];
     const FusedCoord c = cp_coord(g, zchunk, chunk0);
     const int t0 = TWIN ? (int)blockIdx.z * CP_TWN : 0;       // first frame of this block's window
@@ -197,17 +203,17 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
     // x planes z (C) and z-1 (P) live in registers; the adjoint accumulators R (plane z-1 waiting
     // for its z+1 term) and the carried z-up terms U live in LDS, private per thread ([frame][thread]:
     // conflict-free 16-byte lanes, no barrier needed) -- 4 M vectors of state do not fit the VGPR file
-    __shared__ F4 lds_R[M][256];
-    __shared__ F4 lds_U[M][256];
+    __shared__ F4 lds_R[M][64 * CP_NW];
+    __shared__ F4 lds_U[M][64 * CP_NW];
     // column terms that cross the 64-column wave tiles INSIDE the block: each wave publishes, per plane and
     // frame, the col-up value of its last column and the col-down value of its first column (per row);
     // the neighbouring wave adds them one plane later (after the per-plane barrier), double-buffered
-    __shared__ float edge_cu[XW ? 2 : 1][XW ? M : 1][4][CP_TR];
-    __shared__ float edge_cd[XW ? 2 : 1][XW ? M : 1][4][CP_TR];
+    __shared__ float edge_cu[XW ? 2 : 1][XW ? M : 1][CP_NW][CP_TR];
+    __shared__ float edge_cd[XW ? 2 : 1][XW ? M : 1][CP_NW][CP_TR];
     // edge_flag[w] = number of planes of this chunk whose edge columns wave w has published.  A wave starts
     // plane z only after both neighbours published plane z-1, so neighbouring waves stay within one plane of
     // each other (that is what makes two buffers enough) -- a pairwise hand-off, not a block-wide barrier.
-    __shared__ volatile int edge_flag[4];
+    __shared__ volatile int edge_flag[CP_NW];
     const int wave = (int)threadIdx.y;
     if (XW) {
         if (c.lane == 0) edge_flag[wave] = 0;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
         const int eb = (zf - c.zs) & 1;
         if (XW) {
             if (UP && c.lx == 0 && wave > 0) racc.v[0] += edge_cu[eb][t][wave - 1][c.row];
-            if (DN && c.lx == CP_TL - 1 && wave < 3) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
+            if (DN && c.lx == CP_TL - 1 && wave < CP_NW - 1) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
         }
         const long long foff = (long long)zf * g.s_z + (long long)(t0 + t) * g.s_t;      // uniform
         const F4 x0v = ldu(a.x0 + foff, voff), pv = ldu(a.p + foff, voff);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_cp_fused(DG g, WT<float> w, FusedArg
     // a wave never waits for a plane its neighbour can only reach after this wave moves on: no deadlock)
     auto wait_neighbours = [&](int planes) {
         if (wave > 0) while (edge_flag[wave - 1] < planes) __builtin_amdgcn_s_sleep(1);
-        if (wave < 3) while (edge_flag[wave + 1] < planes) __builtin_amdgcn_s_sleep(1);
+        if (wave < CP_NW - 1) while (edge_flag[wave + 1] < planes) __builtin_amdgcn_s_sleep(1);
         __threadfence_block();
     };
     for (int z = c.zs; z < c.ze; ++z) {

@@ -85,8 +85,9 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     }
     LC lc = march_cfg(d, zc);
     {   // block tile of the sweep: CP_TR rows x CP_BC columns (tv_fused.h)
-        const long long tx = (d.nx / 4 + 4 * CP_TL - 1) / (4 * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
+        const long long tx = (d.nx / 4 + CP_NW * CP_TL - 1) / (CP_NW * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
         lc.grid.x = (unsigned)(tx * ty);
+        lc.block = dim3(64, CP_NW, 1);
         lc.nblocks = tx * ty * lc.grid.y;
     }
     const long long nch = lc.grid.y;

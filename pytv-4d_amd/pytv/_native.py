@@ -13,7 +13,8 @@ import numpy as np
 import torch  # noqa: F401  (must come first: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpytv4d_hip.so")
+# PYTV4D_LIB: developer override (A/B of an experimental build of the same C-ABI: pytv-4d_amd/build.py TV_VARIANT=...)
+LIB_PATH = os.environ.get("PYTV4D_LIB") or os.path.join(_HERE, "libpytv4d_hip.so")
 
 SCHEMES = {"upwind": 0, "downwind": 1, "central": 2, "hybrid": 3}
 TV_F32, TV_F64 = 0, 1
@@ -45,6 +46,13 @@ _SIGNATURES = {
     "tv_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "tv_unset_option": (ctypes.c_int, [ctypes.c_char_p]),
     "tv_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "tv_ctx_unique_id": (ctypes.c_int, [_c_void_p]),
+    "tv_ctx_create": (ctypes.c_int, [ctypes.POINTER(_c_void_p), ctypes.c_int, ctypes.c_int, _c_void_p, ctypes.c_int]),
+    "tv_ctx_destroy": (ctypes.c_int, [_c_void_p]),
+    "tv_ctx_rank": (ctypes.c_int, [_c_void_p]),
+    "tv_ctx_size": (ctypes.c_int, [_c_void_p]),
+    "tv_halo_exchange": (ctypes.c_int, [_c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [_c_void_p] * 5),
+    "tv_allreduce_f64": (ctypes.c_int, [_c_void_p, _c_void_p, ctypes.c_int64, ctypes.c_int32, _c_void_p]),
     "tv_num_channels": (ctypes.c_int, [_G]),
     "tv_workspace_bytes": (ctypes.c_size_t, [_G]),
     "tv_D": (ctypes.c_int, [_G] + [_c_void_p] * 5),

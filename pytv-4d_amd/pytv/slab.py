@@ -8,8 +8,76 @@ every operator apply needs ONE boundary plane (M*N*N elements, contiguous) from 
 Traffic is nearest-neighbour only -- a chain, not a ring: ncclSend/ncclRecv grouped in one
 ``batch_isend_irecv`` per exchange, plus an fp64 all-reduce of a few scalars for TV / loss / CG dots.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+
+class _EventHandle:
+    """work-handle look-alike: ``wait()`` orders the CURRENT stream behind an event (no host block)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class NativeComm:
+    """The RCCL communicator of the C-ABI (include/pytv4d.h: tv_ctx_create / tv_halo_exchange / tv_allreduce_f64).
+
+    ``torch.distributed`` is used ONCE, to hand rank 0's 128-byte unique id to the other ranks (any backend, gloo
+    included); after that every exchange is a C call that enqueues ncclSend / ncclRecv on a dedicated side stream.
+    The ordering with the launch stream is explicit -- an event recorded on the launch stream gates the side stream
+    before the exchange, an event recorded after it is what ``wait()`` makes the launch stream wait for -- so nothing
+    depends on ProcessGroupNCCL's internal streams."""
+
+    def __init__(self, group=None, device=None):
+        from . import _native as _nv
+        self._nv = _nv
+        self.lib = _nv.lib()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _nv.check(self.lib.tv_ctx_unique_id(buf))
+        box = [buf.raw]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        self.ctx = ctypes.c_void_p()
+        _nv.check(self.lib.tv_ctx_create(ctypes.byref(self.ctx), self.rank, self.world, box[0], self.device.index or 0))
+        self.stream = torch.cuda.Stream(self.device)
+
+    def exchange(self, prev, nxt, send_prev, send_next, recv_prev, recv_next):
+        ts = [t for t in (send_prev, send_next, recv_prev, recv_next) if t is not None]
+        if not ts:
+            return []
+        count, dtype = ts[0].numel(), ts[0].dtype
+        if any(t.numel() != count or t.dtype != dtype or not t.is_contiguous() for t in ts):
+            raise ValueError("halo messages of one exchange must be contiguous and of one size / dtype")
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                          # the planes to send are complete, the receive buffers' readers are done
+        self.stream.wait_event(ready)
+        p = self._nv.ptr
+        self._nv.check(self.lib.tv_halo_exchange(self.ctx, self._nv.dtype_code(dtype), count, -1 if prev is None else prev,
+                                                 -1 if nxt is None else nxt, p(send_prev), p(send_next), p(recv_prev), p(recv_next),
+                                                 self.stream.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return [_EventHandle(done)]
+
+    def allreduce_(self, t, op):
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            raise ValueError("tv_allreduce_f64 reduces contiguous fp64 device words")
+        self._nv.check(self.lib.tv_allreduce_f64(self.ctx, t.data_ptr(), t.numel(), op, torch.cuda.current_stream(self.device).cuda_stream))
+        return t
+
+    def close(self):
+        if self.ctx:
+            self.lib.tv_ctx_destroy(self.ctx)
+            self.ctx = ctypes.c_void_p()
 
 
 def partition(nz_global, world):
@@ -26,8 +94,11 @@ def partition(nz_global, world):
 class Slab:
     """This rank's share of the volume and its neighbour exchange."""
 
-    def __init__(self, nz_global, group=None, rank=None, world=None):
+    def __init__(self, nz_global, group=None, rank=None, world=None, native_comm=None):
+        """native_comm: a ``NativeComm`` -- halos and scalar all-reduces then go through the C-ABI's own RCCL
+        communicator instead of ``torch.distributed`` (which the default path uses: backend "nccl" = RCCL)."""
         self.group = group
+        self.native = native_comm
         if rank is None or world is None:
             if dist.is_available() and dist.is_initialized():
                 rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -57,6 +128,10 @@ class Slab:
         (``wait()`` orders the current stream behind the transfer on RCCL; it blocks on gloo)."""
         if not self.sharded:
             return []
+        if self.native is not None:
+            return self.native.exchange(self.prev, self.next, send_prev if self.prev is not None else None,
+                                        send_next if self.next is not None else None,
+                                        recv_prev if self.prev is not None else None, recv_next if self.next is not None else None)
         if self._stage_through_host(send_prev, send_next, recv_prev, recv_next):
             return self._exchange_staged(send_prev, send_next, recv_prev, recv_next)
         ops = []
@@ -115,6 +190,8 @@ class Slab:
     def allreduce_sum_(self, t):
         """In-place sum over ranks of a (small, fp64) tensor."""
         if self.sharded:
+            if self.native is not None and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous():
+                return self.native.allreduce_(t, 0)
             if t.is_cuda and dist.get_backend(self.group) == "gloo":
                 h = t.detach().to("cpu")
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -126,6 +203,8 @@ class Slab:
     def allreduce_max_(self, t):
         """In-place maximum over ranks of a (small, fp64) tensor."""
         if self.sharded:
+            if self.native is not None and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous():
+                return self.native.allreduce_(t, 1)
             if t.is_cuda and dist.get_backend(self.group) == "gloo":
                 h = t.detach().to("cpu")
                 dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)

@@ -291,7 +291,7 @@ def test_zero_gradient_rule_is_the_same_on_every_path(pytv, scheme):
     x = torch.as_tensor(img).cuda()
     tiny = torch.zeros(shape, device="cuda")
     tiny[:, :, 3, 10:20] = 1e-21              # |Dx| ~ 1e-21: its square underflows
-    tiny[:, :, 5, 30] = 1e-3                  # a regular gradient for contrast
+    tiny[:, :, 5, 30:] = 1e-3                 # a regular step edge for contrast
     kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
     res = []
     for one_pass in (True, False):
@@ -301,7 +301,7 @@ def test_zero_gradient_rule_is_the_same_on_every_path(pytv, scheme):
         res.append((float(tv), G.cpu().numpy(), n.cpu().numpy()))
     for tv, G, n in res:
         assert np.isinf(n[:, :, 3, 12]).all()                 # counted as zero gradient
-        assert np.isfinite(n[:, :, 5, 30]).all()
+        assert np.isfinite(n[:, :, 5, 29:31]).any()
         assert np.abs(G[:, :, 3, 12:18]).max() == 0.0         # and contributes nothing
     if len(res) == 2:
         np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)

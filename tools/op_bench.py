@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Achieved bandwidth of every C-ABI operator (device resident, fp32) against its algorithmic bytes.
-usage: python tools/op_bench.py [NzxMxNyxNx] [scheme ...]"""
+usage: python tools/op_bench.py [NzxMxNyxNx] [scheme ...]      (DTYPE=f64 in the environment: double precision)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
@@ -13,7 +13,10 @@ lib = nv.lib()
 dev = torch.device("cuda", 0)
 gen = torch.Generator(device=dev).manual_seed(0)
 x = torch.rand(shape, device=dev, generator=gen) * 100
+if os.environ.get("DTYPE", "f32") == "f64":
+    x = x.double()
 V = x.numel()
+WB = x.element_size()
 
 
 def timeit(f, reps=5):
@@ -26,23 +29,25 @@ def timeit(f, reps=5):
     return a.elapsed_time(b) / reps * 1e-3
 
 
-print("shape %s  V = %.0f Mvox; GB/s = algorithmic bytes / time; frac of 8000 GB/s" % (shape, V / 1e6))
-print("%-9s %-16s %8s %9s %7s  %s" % ("scheme", "op", "ms", "GB/s", "frac", "algorithmic words/voxel"))
+print("shape %s  V = %.0f Mvox  dtype %s; GB/s = algorithmic bytes / time; frac of 8000 GB/s" % (shape, V / 1e6, x.dtype))
+print("%-9s %-22s %8s %9s %7s  %s" % ("scheme", "op", "ms", "GB/s", "frac", "algorithmic words/voxel"))
 for scheme in schemes:
     kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
     g = nv.Geometry(shape, scheme, x.dtype, dev, **kw)
     nd, st, ws = g.nd, nv.current_stream(dev), g.workspace()
-    d = torch.empty(g.grad_shape, device=dev)
+    d = torch.empty(g.grad_shape, device=dev, dtype=x.dtype)
     o = torch.empty_like(x); o2 = torch.empty_like(x)
-    ne = torch.empty((shape[0] + 2,) + shape[1:], device=dev)
+    ne = torch.empty((shape[0] + 2,) + shape[1:], device=dev, dtype=x.dtype)
     sc = g.scalar()
-    u = torch.zeros(g.grad_shape, device=dev)
+    u = torch.zeros(g.grad_shape, device=dev, dtype=x.dtype)
     ops = [
         ("tv_D", 1 + nd, lambda: nv.check(lib.tv_D(g.ref, nv.ptr(x), None, None, nv.ptr(d), st))),
         ("tv_DT", nd + 1, lambda: nv.check(lib.tv_DT(g.ref, nv.ptr(d), None, None, nv.ptr(o), st))),
         ("tv_l21", nd, lambda: nv.check(lib.tv_l21(g.ref, nv.ptr(d), nd, None, nv.ptr(sc), nv.ptr(ws), st))),
         ("tv_subgrad", 2, lambda: nv.check(lib.tv_subgrad(g.ref, nv.ptr(x), None, None, nv.ptr(o), nv.ptr(ne), nv.ptr(sc), nv.ptr(ws), st))),
         ("tv_subgrad_fused", 2, (lambda: nv.check(lib.tv_subgrad_fused(g.ref, nv.ptr(x), None, None, nv.ptr(o), nv.ptr(sc), nv.ptr(ws), st)))
+         if lib.tv_subgrad_fused_supported(g.ref) else None),
+        ("tv_subgrad_fused_norms", 3, (lambda: nv.check(lib.tv_subgrad_fused_norms(g.ref, nv.ptr(x), None, None, nv.ptr(o), nv.ptr(o2), nv.ptr(sc), nv.ptr(ws), st)))
          if lib.tv_subgrad_fused_supported(g.ref) else None),
         ("tv_normal_op", 2, lambda: nv.check(lib.tv_normal_op(g.ref, nv.ptr(x), None, None, 0.1, nv.ptr(o), nv.ptr(sc), nv.ptr(ws), st))),
         ("tv_admm_zu", 1 + 3 * nd, lambda: nv.check(lib.tv_admm_zu(g.ref, nv.ptr(x), None, None, nv.ptr(d), nv.ptr(u), 1.0, nv.ptr(sc), nv.ptr(ws), st))),
@@ -55,7 +60,7 @@ for scheme in schemes:
         if (only and name not in only) or f is None:
             continue
         t = timeit(f)
-        gbs = words * 4.0 * V / t / 1e9
-        print("%-9s %-16s %8.3f %9.0f %7.3f  %d" % (scheme, name, t * 1e3, gbs, gbs / 8000.0, words))
+        gbs = words * float(WB) * V / t / 1e9
+        print("%-9s %-22s %8.3f %9.0f %7.3f  %d" % (scheme, name, t * 1e3, gbs, gbs / 8000.0, words))
     del d, u, o, o2, ne
     torch.cuda.empty_cache()
