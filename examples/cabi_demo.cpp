@@ -100,6 +100,48 @@ int main() {
     }
     for (int it = 0; it < 5; ++it)
         if (fabs(loss[0][it] - loss[1][it]) > 1e-5 * fabs(loss[0][it])) { fprintf(stderr, "the two CP paths disagree at iteration %d\n", it); return 1; }
+    // ---- sharding from C++: the multi-GPU surface (tv_ctx_*, RCCL underneath) ----------------------------------------------
+    // A host with one process per GPU gives every rank a z-slab (tv_geom::z0 / nz_global) and trades boundary planes with
+    // tv_halo_exchange.  This box has one GPU, so the one rank here plays BOTH neighbours of a two-slab split: slab A =
+    // planes [0, 3), slab B = planes [3, 6); with itself as prev and next peer the messages meet in posting order
+    // (first send -> first receive), i.e. what goes out as "send_prev" comes back as "recv_prev".
+    {
+        unsigned char id[TV_UNIQUE_ID_BYTES];
+        tv_ctx* ctx = nullptr;
+        TV_OK(tv_ctx_unique_id(id));
+        TV_OK(tv_ctx_create(&ctx, 0, 1, id, 0));
+        const int64_t plane = g.m * g.ny * g.nx, h = 3;
+        float *halo_for_B = nullptr, *halo_for_A = nullptr, *dA = nullptr, *dB = nullptr;
+        HIP_OK(hipMalloc(&halo_for_B, plane * sizeof(float)));
+        HIP_OK(hipMalloc(&halo_for_A, plane * sizeof(float)));
+        HIP_OK(hipMalloc(&dA, h * nd * plane * sizeof(float)));
+        HIP_OK(hipMalloc(&dB, (g.nz - h) * nd * plane * sizeof(float)));
+        // A's last plane -> B's "previous" halo, B's first plane -> A's "next" halo, one grouped exchange on the stream
+        TV_OK(tv_halo_exchange(ctx, TV_F32, plane, 0, 0, x + (h - 1) * plane, x + h * plane, halo_for_B, halo_for_A, st));
+        tv_geom ga = g, gb = g;
+        ga.nz = h; ga.z0 = 0;
+        gb.nz = g.nz - h; gb.z0 = h;
+        TV_OK(tv_D(&ga, x, nullptr, halo_for_A, dA, st));                 // enqueued behind the exchange: no host sync
+        TV_OK(tv_D(&gb, x + h * plane, halo_for_B, nullptr, dB, st));
+        double* red = nullptr;
+        HIP_OK(hipMalloc(&red, sizeof(double)));
+        const double one = 1.0;
+        HIP_OK(hipMemcpyAsync(red, &one, sizeof(double), hipMemcpyHostToDevice, st));
+        TV_OK(tv_allreduce_f64(ctx, red, 1, TV_SUM, st));
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<float> ha(h * nd * plane), hb((g.nz - h) * nd * plane);
+        HIP_OK(hipMemcpy(ha.data(), dA, ha.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hb.data(), dB, hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < ha.size(); ++i) bad += (ha[i] != hd[i]);
+        for (size_t i = 0; i < hb.size(); ++i) bad += (hb[i] != hd[ha.size() + i]);
+        double redh = 0.0;
+        HIP_OK(hipMemcpy(&redh, red, sizeof(double), hipMemcpyDeviceToHost));
+        printf("two z-slabs with exchanged halos vs the whole volume: %zu differing elements; all-reduce over %d rank(s) = %.1f\n",
+               bad, tv_ctx_size(ctx), redh);
+        TV_OK(tv_ctx_destroy(ctx));
+        if (bad != 0 || redh != 1.0) { fprintf(stderr, "sharded D differs from the unsharded one\n"); return 1; }
+    }
     // ---- error reporting across the ABI: no exception, a status and a message -----------------------------------------
     g.scheme = 9;
     const int rc = tv_D(&g, x, nullptr, nullptr, d, st);

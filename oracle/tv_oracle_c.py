@@ -19,6 +19,9 @@ class Geom(ctypes.Structure):
 
 
 def build(force=False):
+    override = os.environ.get("TV_ORACLE_C_LIB")        # a sanitizer build made by tools/sanitize.py
+    if override:
+        return override
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(SRC), os.path.getmtime(INC)):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)

@@ -25,20 +25,21 @@ namespace tv {
 
 using F4 = Vec<float, 4>;
 
-// Wave tile of the one-sweep CP kernel: CP_TR rows x CP_TL lanes (4 columns each); 4 waves side by side form the
-// block tile (CP_TR rows x CP_BC columns).  Default 4 x 16.  Build with -DTV_FUSED_TR=8 for 8 x 8 tiles: only 2 of 8
-// rows are then tile-edge rows, which halves the row fix-up (3.4 -> 1.7 ms on the north-star volume) and the x halo
-// rows, and the block's footprint (8 rows x 512 B) streams as fast as 4 rows x 1 KiB (tools/bwtest.hip) -- but the
-// block tile is 128 columns wide instead of 256, the sparse column-edge fix-up goes from 0.5 to 2.1 ms and the sweep
-// gains nothing (33.8 vs 33.5 ms): measured, not adopted.
+// Wave tile of the one-sweep CP kernel: CP_TR rows x CP_TL lanes (4 columns each); CP_NW waves side by side form the
+// block tile (CP_TR rows x CP_BC columns) and hand their tile-edge COLUMN terms to each other through LDS.
+// Default (round 2): 8 x 8 lanes per wave, 8 waves per block = 8 rows x 256 columns, one 512-thread block per CU at
+// M = 8 (the per-thread R / U slots take 128 KiB).  Only 2 of 8 rows are tile-edge rows, which halves the row fix-up
+// and the x halo rows, and the block tile keeps the 256-column period of the sparse column-edge fix-up.
+// Measured on the north-star volume (profiles/r2_ab_sweep_tr8nw8.txt): iteration 37.7 -> 35.7 ms (sweep 33.4 -> 32.8,
+// fix-up 4.3 -> 2.9 ms); upwind / downwind / central -1..2 %; 128x16x1024x1024 40.2 -> 38.3 ms.  Round 1's 4 x 16 lanes,
+// 4 waves: -DTV_FUSED_TR=4 -DTV_FUSED_NW=4.  (8-row tiles in a 4-wave block, 128 columns: row fix-up halves but the
+// column-edge fix-up goes 0.5 -> 2.1 ms -- no net gain, round 1.)
 #ifndef TV_FUSED_TR
-#define TV_FUSED_TR 4
+#define TV_FUSED_TR 8
 #endif
 #ifndef TV_FUSED_NW
-#define TV_FUSED_NW 4
+#define TV_FUSED_NW 8
 #endif
-// CP_NW waves side by side form the block tile (they hand their tile-edge COLUMN terms to each other through LDS).
-// -DTV_FUSED_TR=8 -DTV_FUSED_NW=8: 8-row wave tiles in a block of 8 waves = 8 rows x 256 columns (one block per CU)
 constexpr int CP_NW = TV_FUSED_NW;
 constexpr int CP_TR = TV_FUSED_TR, CP_TL = 64 / CP_TR, CP_WC = 4 * CP_TL, CP_BC = CP_NW * CP_WC;
 constexpr int CP_LSH = (CP_TL == 16) ? 4 : 3;

@@ -184,7 +184,8 @@ inline int march_zchunk(const DG& d) {
     // chunk-edge fix-up planes); short ones keep >= ~4096 blocks in flight.  TV_ZCHUNK overrides.
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
-        const long long tiles = (long long)((d.nx / 4 + 63) / 64) * ((d.ny + 3) / 4);
+        long long tiles = (long long)((d.nx / 4 + 63) / 64) * ((d.ny + 3) / 4);
+        if (tiles < 1) tiles = 1;                        // frames narrower than one 4-column vector (tools/abi_validation.py)
         const long long want_chunks = (4096 + tiles - 1) / tiles;
         zc = (int)(d.nz / (want_chunks > 0 ? want_chunks : 1));
         if (zc > 32) zc = 32;

@@ -45,3 +45,50 @@ def test_self_exchange_on_the_rccl_stream_is_ordered_with_the_launch_stream():
                        text=True, timeout=300)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     assert "RCCL_SELFTEST_OK" in p.stdout
+
+
+_CTX_SCRIPT = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+import torch
+from pytv import _native as nv
+lib = nv.lib()
+torch.cuda.set_device(0)
+buf = ctypes.create_string_buffer(128)
+nv.check(lib.tv_ctx_unique_id(buf))
+ctx = ctypes.c_void_p()
+nv.check(lib.tv_ctx_create(ctypes.byref(ctx), 0, 1, buf.raw, 0))
+assert lib.tv_ctx_rank(ctx) == 0 and lib.tv_ctx_size(ctx) == 1
+st = torch.cuda.current_stream().cuda_stream
+for dtype, code in ((torch.float32, 0), (torch.float64, 1)):
+    a = torch.rand(1 << 20, device="cuda", dtype=dtype)          # what a rank sends towards its previous neighbour
+    b = torch.rand(1 << 20, device="cuda", dtype=dtype)          # ... towards its next neighbour
+    ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+    # the one rank is its own prev and next peer: messages meet in posting order (send_prev -> recv_prev, send_next -> recv_next)
+    nv.check(lib.tv_halo_exchange(ctx, code, a.numel(), 0, 0, a.data_ptr(), b.data_ptr(), ra.data_ptr(), rb.data_ptr(), st))
+    c = ra * 2 + rb                                               # consumer on the same stream, no host sync in between
+    torch.cuda.synchronize()
+    assert torch.equal(ra, a) and torch.equal(rb, b) and torch.equal(c, a * 2 + b)
+    # a rank at the end of the chain: only one neighbour
+    rb.zero_()
+    nv.check(lib.tv_halo_exchange(ctx, code, a.numel(), -1, 0, None, b.data_ptr(), None, rb.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(rb, b)
+t = torch.tensor([1.5, -2.0, 7.0], dtype=torch.float64, device="cuda")
+nv.check(lib.tv_allreduce_f64(ctx, t.data_ptr(), 3, 0, st))
+nv.check(lib.tv_allreduce_f64(ctx, t.data_ptr(), 3, 1, st))
+torch.cuda.synchronize()
+assert t.tolist() == [1.5, -2.0, 7.0]
+assert lib.tv_halo_exchange(ctx, 0, 4, 5, -1, None, None, None, None, st) < 0        # neighbour outside the communicator
+nv.check(lib.tv_ctx_destroy(ctx))
+print("TV_CTX_OK")
+"""
+
+
+def test_cabi_rccl_context_with_one_rank():
+    """include/pytv4d.h multi-GPU surface (tv_ctx_create / tv_halo_exchange / tv_allreduce_f64 / tv_ctx_destroy) on a real
+    RCCL communicator of one rank, the rank being its own z-neighbour."""
+    pkg = os.path.join(ROOT, "pytv-4d_amd")
+    p = subprocess.run([sys.executable, "-c", _CTX_SCRIPT % pkg], env=_env(29633), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "TV_CTX_OK" in p.stdout
