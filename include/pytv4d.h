@@ -178,6 +178,25 @@ int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_pr
  * over local planes.  x_prev / x_next: TWO planes each as in tv_subgrad. */
 int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho,
                  void* out, double* dot, void* ws, void* stream);
+/* The same operator with two dot products and an optional right-hand side, for conjugate gradients:
+ *   b == NULL : out = A x,      dots[0] = <x, A x>,   dots[1] = <x, x>
+ *   b != NULL : out = b - A x,  dots[0] = <out, out>, dots[1] = <x, x>;  out2 (or NULL) receives a second copy of out
+ * A = I + rho D^T D; dots: two device fp64 words (local planes). */
+int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, const void* b, void* out,
+                  void* out2, double* dots, void* ws, void* stream);
+/* One step of the SINGLE-REDUCTION conjugate gradient (Chronopoulos-Gear form; one all-reduce of two scalars per step on
+ * a sharded volume instead of two all-reduces).  sc: four device fp64 words
+ *     sc[0] = gamma = <r, r>,  sc[1] = delta = <r, w> with w = A r   (already summed over the ranks)
+ *     sc[2] = gamma of the previous step,  sc[3] = alpha of the previous step; sc[3] == 0 marks the FIRST step of a solve
+ *   beta = first ? 0 : gamma / gamma_old;   alpha = gamma / (first ? delta : delta - beta gamma / alpha_old)
+ *   d = r + beta d;  s = w + beta s (= A d);  x += alpha d;  r -= alpha s;   then sc[2] = gamma, sc[3] = alpha
+ * x0 != NULL: *fid = 1/2 |x_new - x0|^2 (the ADMM loss after the last step, for one extra read). */
+int tv_cg_update(const tv_geom* g, void* x, void* r, void* d, void* s, const void* w, double* sc, const void* x0, double* fid,
+                 void* ws, void* stream);
+/* The z / u update of tv_admm_zu storing t = z - u_new in place of z: the next right-hand side x0 + rho D^T (z - u) is
+ * then tv_DT_axpy(t, NULL, ..) over ONE gradient array; z = t + u whenever it is wanted. */
+int tv_admm_tu(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* t, void* u,
+               double thresh, double* tv, void* ws, void* stream);
 /* Conjugate-gradient vector updates with device-resident scalars (no host round trip):
  *   tv_cg_step1: alpha = rs/dAd;  x += alpha d;  r -= alpha Ad;  *rs_new = <r, r>
  *   tv_cg_step2: beta = rs_new/rs; d = r + beta d                                            */

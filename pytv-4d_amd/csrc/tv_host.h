@@ -254,7 +254,11 @@ bool subgrad_pass2_ok(const tv_geom* g, const DG& d);
 int D_normal_op(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
                 float* out, float rho, double* partials);
 int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
-              float* z, float* u, float thresh, double* partials);
+              float* z, float* u, float thresh, double* partials, int tform);
+// streaming normal operator (tv_nstream.h): radius-1 schemes, fp32; two dot products
+bool N_stream_ok(const tv_geom* g, const DG& d, bool vec);
+int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, float* out, float* out2,
+             float rho, hipStream_t st, long long* nb, double* part0, double* part1);
 // streaming forward kernel (tv_dstream.h): d = D x without LDS tile or barrier, every load one plane ahead of its use
 bool D_stream_ok(const tv_geom* g, const DG& d, bool vec);
 int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, float* dout);

@@ -604,6 +604,72 @@ __global__ __launch_bounds__(256) void k_cg2(long long nv, T* d, const T* r, con
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x)
         vstore<T, V>(d + i * V, vload<T, V>(r + i * V) + beta * vload<T, V>(d + i * V));
 }
+// single-reduction CG (Chronopoulos-Gear): sc = {gamma = <r,r>, delta = <r,w>, gamma_old, alpha_old}; alpha_old == 0 marks
+// the first step of a solve.  d = r + beta d; s = w + beta s; x += alpha d; r -= alpha s; optional partial 1/2 |x - x0|^2
+__device__ __forceinline__ void cgcg_scalars(const double* sc, double& alpha, double& beta, bool& first) {
+    const double gamma = sc[0], delta = sc[1], gamma_old = sc[2], alpha_old = sc[3];
+    first = (alpha_old == 0.0);
+    beta = (!first && gamma_old > 0.0) ? gamma / gamma_old : 0.0;
+    const double den = first ? delta : delta - beta * gamma / alpha_old;
+    alpha = (den > 0.0) ? gamma / den : 0.0;
+}
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_cgcg(long long nv, T* x, T* r, T* d, T* s, const T* w, const double* sc, const T* x0,
+                                               double* partials) {
+    __shared__ double sm[16];
+    double al, be;
+    bool first;
+    cgcg_scalars(sc, al, be, first);
+    const T alpha = (T)al, beta = (T)be;
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const Vec<T, V> rv = vload<T, V>(r + i * V), wv = vload<T, V>(w + i * V);
+        Vec<T, V> dn = rv, sn = wv;
+        if (!first) {
+            dn = rv + beta * vload<T, V>(d + i * V);
+            sn = wv + beta * vload<T, V>(s + i * V);
+        }
+        const Vec<T, V> xn = vload<T, V>(x + i * V) + alpha * dn;
+        vstore<T, V>(d + i * V, dn);
+        vstore<T, V>(s + i * V, sn);
+        vstore<T, V>(x + i * V, xn);
+        vstore<T, V>(r + i * V, rv - alpha * sn);
+        if (x0 != nullptr) {
+            const Vec<T, V> x0v = vload<T, V>(x0 + i * V);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const double e = (double)xn.v[k] - (double)x0v.v[k];
+                acc += 0.5 * e * e;
+            }
+        }
+    }
+    if (x0 != nullptr) {
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+    }
+}
+__global__ void k_cgcg_advance(double* sc) {
+    double al, be;
+    bool first;
+    cgcg_scalars(sc, al, be, first);
+    sc[2] = sc[0];
+    sc[3] = (al != 0.0) ? al : 1e-300;       // never 0 again inside a solve: 0 means "first step"
+}
+// out = a - b; partial <out, out>; optional second copy
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_sub_dot(long long nv, const T* a, const T* b, T* out, T* out2, double* partials) {
+    __shared__ double sm[16];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const Vec<T, V> o = vload<T, V>(a + i * V) - vload<T, V>(b + i * V);
+        vstore<T, V>(out + i * V, o);
+        if (out2 != nullptr) vstore<T, V>(out2 + i * V, o);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc += (double)o.v[k] * (double)o.v[k];
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
 // README.md:122-123: x <- x - step * ((x - x0) + lambda G); partial 1/2 |x - x0|^2
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_sgstep(long long nv, T* x, const T* x0, const T* G, T step, T lambda, double* partials) {
@@ -860,7 +926,17 @@ int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out, d.wv});
-    if (g->scheme != TV_CENTRAL && d.m <= 8 && march_ok(g, d, vec) && !env_int("TV_NO_MARCH_NORMAL", 0)) {
+    // TV_NORMAL_KERNEL: 2 = streaming (k_normal_stream: default for fp32 planes >= TV_MARCH_MIN_PLANE_KB, radius-1 schemes,
+    // any M), 1 = the marching LIGHT kernel of round 1 (M <= 8), 0 = one site per thread
+    const int nkern = env_int("TV_NORMAL_KERNEL", 2);
+    if (nkern == 2 && tvm::N_stream_ok(g, d, vec)) {
+        long long nb;
+        double* w0 = (double*)ws;
+        double* w1 = w0 + nmax + kStage + 16;
+        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, nullptr, (float*)out, nullptr, (float)rho, st, &nb, w0, w1)) return rc;
+        return reduce_partials(w0, nb, nmax, dot, st);
+    }
+    if (nkern >= 1 && g->scheme != TV_CENTRAL && d.m <= 8 && march_ok(g, d, vec) && !env_int("TV_NO_MARCH_NORMAL", 0)) {
         long long nb;
         if (int rc = tvm::D_normal_op(g, d, x, x_prev, x_next, st, &nb, (float*)out, (float)rho, (double*)ws)) return rc;
         return reduce_partials((double*)ws, nb, nmax, dot, st);
@@ -939,8 +1015,18 @@ int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void
     });
 }
 
+static int admm_zu_impl(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* z, void* u,
+                        double thresh, double* tvout, void* ws, void* stream, int tform);
 int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* z, void* u,
                double thresh, double* tvout, void* ws, void* stream) {
+    return admm_zu_impl(g, x, x_prev, x_next, z, u, thresh, tvout, ws, stream, 0);
+}
+int tv_admm_tu(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* t, void* u,
+               double thresh, double* tvout, void* ws, void* stream) {
+    return admm_zu_impl(g, x, x_prev, x_next, t, u, thresh, tvout, ws, stream, 1);
+}
+static int admm_zu_impl(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* z, void* u,
+                        double thresh, double* tvout, void* ws, void* stream, int tform) {
     DG d;
     if (int rc = make_dg(g, d)) return rc;
     if (x == nullptr || z == nullptr || u == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
@@ -950,13 +1036,13 @@ int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* 
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
         long long nb;
-        if (int rc = tvm::D_admm_zu(g, d, x, x_prev, x_next, st, &nb, (float*)z, (float*)u, (float)thresh, (double*)ws))
+        if (int rc = tvm::D_admm_zu(g, d, x, x_prev, x_next, st, &nb, (float*)z, (float*)u, (float)thresh, (double*)ws, tform))
             return rc;
         return reduce_partials((double*)ws, nb, nmax, tvout, st);
     }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lc = launch_cfg(d, V, d.nz);
-        AdmmZU<S, T, V> epi{(T*)z, (T*)u, (T)thresh, (double*)ws};
+        AdmmZU<S, T, V> epi{(T*)z, (T*)u, (T)thresh, (double*)ws, tform};
         hipLaunchKernelGGL((k_D<S, T, V, AdmmZU<S, T, V>>), lc.grid, lc.block, 0, st, d, make_w<T>(g), (const T*)x,
                            (const T*)x_prev, (const T*)x_next, 1, 0, epi);
         HIP_TRY(hipGetLastError());
@@ -1032,6 +1118,55 @@ int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, do
     TV_FLAT_LAUNCH(k_sgstep, g->dtype, nvox(d), ({x, x0, G}), (T*)x, (const T*)x0, (const T*)G, (T)step, (T)lambda, (double*)ws);
     HIP_TRY(hipGetLastError());
     return reduce_partials((double*)ws, kFlatBlocks, max_partials(d), fid, st);
+}
+
+// out = A x (b == NULL) or out = b - A x (b != NULL; out2, when given, receives the same vector), A = I + rho D^T D;
+// dots[0] = <x, A x> resp. <out, out>, dots[1] = <x, x>  (device fp64, local planes)
+int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, const void* b, void* out,
+                  void* out2, double* dots, void* ws, void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (x == nullptr || out == nullptr || dots == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
+    if (out2 != nullptr && b == nullptr) return fail(TV_E_ARG, "out2 is the copy of the residual: it needs b");
+    const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
+    if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr)))
+        return fail(TV_E_HALO, "tv_normal_op2 on a slab needs two halo planes on each interior side");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nmax = max_partials(d);
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out, out2, b, d.wv});
+    if (env_int("TV_NORMAL_KERNEL", 2) == 2 && tvm::N_stream_ok(g, d, vec)) {
+        long long nb;
+        double* w0 = (double*)ws;
+        double* w1 = w0 + nmax + kStage + 16;
+        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, b, (float*)out, (float*)out2, (float)rho, st, &nb, w0, w1)) return rc;
+        if (int rc = reduce_partials(w0, nb, nmax, dots, st)) return rc;
+        return reduce_partials(w1, nb, nmax, dots + 1, st);
+    }
+    // composition of the existing entry points (fp64, central, weight volume, small planes)
+    if (int rc = tv_normal_op(g, x, x_prev, x_next, rho, out, dots, ws, stream)) return rc;
+    if (int rc = tv_dot(g, x, x, dots + 1, ws, stream)) return rc;
+    if (b != nullptr) {
+        TV_FLAT_LAUNCH(k_sub_dot, g->dtype, nvox(d), ({b, out, out2}), (const T*)b, (const T*)out, (T*)out, (T*)out2, (double*)ws);
+        HIP_TRY(hipGetLastError());
+        return reduce_partials((double*)ws, kFlatBlocks, nmax, dots, st);
+    }
+    return 0;
+}
+
+// One step of the single-reduction conjugate gradient (Chronopoulos-Gear): see include/pytv4d.h
+int tv_cg_update(const tv_geom* g, void* x, void* r, void* dvec, void* s, const void* w, double* sc, const void* x0, double* fid,
+                 void* ws, void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (!x || !r || !dvec || !s || !w || !sc || !ws) return fail(TV_E_ARG, "NULL array");
+    if (x0 != nullptr && fid == nullptr) return fail(TV_E_ARG, "x0 without a place for the fidelity");
+    hipStream_t st = (hipStream_t)stream;
+    TV_FLAT_LAUNCH(k_cgcg, g->dtype, nvox(d), ({x, r, dvec, s, w, x0}), (T*)x, (T*)r, (T*)dvec, (T*)s, (const T*)w, (const double*)sc,
+                   (const T*)x0, (double*)ws);
+    hipLaunchKernelGGL(k_cgcg_advance, dim3(1), dim3(1), 0, st, sc);
+    HIP_TRY(hipGetLastError());
+    if (x0 != nullptr) return reduce_partials((double*)ws, kFlatBlocks, max_partials(d), fid, st);
+    return 0;
 }
 
 }  // extern "C"

@@ -27,8 +27,8 @@ int D_cp_dual(const tv_geom* g, const DG& d, const void* x, const void* xp, cons
     return launch_D_march<CpDual>(g, d, x, xp, xn, st, nb, q, sigma, inv_lambda, partials);
 }
 int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
-              float* z, float* u, float thresh, double* partials) {
-    return launch_D_march<AdmmZU>(g, d, x, xp, xn, st, nb, z, u, thresh, partials);
+              float* z, float* u, float thresh, double* partials, int tform) {
+    return launch_D_march<AdmmZU>(g, d, x, xp, xn, st, nb, z, u, thresh, partials, tform);
 }
 int D_norms(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, long long* nb,
             float* norms_ext, double* partials, int ghost_lo, int ghost_hi) {

@@ -1,0 +1,52 @@
+// tv_nstream.hip -- instantiations + launcher of the streaming normal operator (tv_nstream.h).
+#include "tv_host.h"
+#include "tv_stencil.h"
+#include "tv_nstream.h"
+
+namespace tvm {
+
+bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
+    if (g->dtype != TV_F32 || !vec || d.nx < 64 || g->scheme == TV_CENTRAL || d.wv != nullptr) return false;
+    if ((long long)d.ny * d.nx > (1ll << 30)) return false;           // 32-bit per-lane byte offsets inside a frame
+    if (env_int("TV_NO_MARCH", 0) || env_int("TV_NO_MARCH_NORMAL", 0)) return false;
+    // small planes: the z / t neighbours of the one-site kernel stay in L2 (same threshold as the other streaming kernels)
+    return (long long)d.s_z * 4 >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;
+}
+
+int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, float* out, float* out2,
+             float rho, hipStream_t st, long long* nblocks, double* part0, double* part1) {
+    const long long tx = (d.nx / 4 + 63) / 64, ty = (d.ny + 3) / 4;
+    int zc = env_int("TV_ZCHUNK", 0);
+    if (zc <= 0) {
+        const long long want = (4096 + tx * ty - 1) / (tx * ty);
+        zc = (int)(d.nz / (want > 0 ? want : 1));
+        if (zc > 32) zc = 32;
+        if (zc < 8) zc = 8;
+    }
+    if (zc > d.nz) zc = d.nz;
+    const long long nch = (d.nz + zc - 1) / zc;
+    const long long nwin = (d.m > NS_TWN) ? (d.m + NS_TWN - 1) / NS_TWN : 1;
+    const long long nb = tx * ty * nch * nwin, per_xcd = (nb + 7) / 8;
+    const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, 4, 1);
+    *nblocks = 8 * per_xcd;
+    if (*nblocks > max_partials(d)) return fail(TV_E_ARG, "internal: normal-operator partials exceed the workspace");
+    const WT<float> w = make_w<float>(g);
+    NormalArgs a{(const float*)x, (const float*)xp, (const float*)xn, (const float*)b, out, out2, rho, part0, part1};
+#define TV_NS_LAUNCH(MM, TW) hipLaunchKernelGGL((k_normal_stream<MM, TW>), grid, block, 0, st, d, w, a, zc, (int)nch)
+    switch (d.m > NS_TWN ? 0 : d.m) {
+        case 0: TV_NS_LAUNCH(NS_TWN, true); break;
+        case 1: TV_NS_LAUNCH(1, false); break;
+        case 2: TV_NS_LAUNCH(2, false); break;
+        case 3: TV_NS_LAUNCH(3, false); break;
+        case 4: TV_NS_LAUNCH(4, false); break;
+        case 5: TV_NS_LAUNCH(5, false); break;
+        case 6: TV_NS_LAUNCH(6, false); break;
+        case 7: TV_NS_LAUNCH(7, false); break;
+        default: TV_NS_LAUNCH(8, false); break;
+    }
+#undef TV_NS_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace tvm

@@ -213,13 +213,15 @@ template <int S, typename T, int V> struct CpDual {
     }
 };
 
-// ADMM: v = Dx + u;  z = v * max(0, 1 - thresh/|v|);  u = v - z
+// ADMM: v = Dx + u;  z = v * max(0, 1 - thresh/|v|);  u = v - z.   tform: the first array receives t = z - u_new
+// (= 2 z - v) instead of z: the next right-hand side x0 + rho D^T (z - u) then reads ONE gradient array
 template <int S, typename T, int V> struct AdmmZU {
     static constexpr bool REDUCES = true;
     T* z;
     T* u;
     T thresh;
     double* partials;
+    int tform = 0;
     __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8]) const {
         const long long off = (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
         Vec<T, V> v[8];
@@ -241,8 +243,9 @@ template <int S, typename T, int V> struct AdmmZU {
         for_each_channel<S>(g, [&](auto slot, int ch) {
             constexpr int k = decltype(slot)::value;
             const Vec<T, V> zz = v[k] * scale;
-            vstore<T, V>(z + off + (long long)ch * g.s_z, zz);
-            vstore<T, V>(u + off + (long long)ch * g.s_z, v[k] - zz);
+            const Vec<T, V> un = v[k] - zz;
+            vstore<T, V>(z + off + (long long)ch * g.s_z, tform ? zz - un : zz);
+            vstore<T, V>(u + off + (long long)ch * g.s_z, un);
         });
         return acc;
     }

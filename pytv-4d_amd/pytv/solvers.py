@@ -500,19 +500,28 @@ class ADMM(_SlabProblem):
 
       x-step : (I + rho D^T D) x = x0 + rho D^T (z - u)   n_cg CG steps, warm start
       z-step : z = shrink(Dx + u, reg/rho);  u-step: u += Dx - z          (one fused kernel)
-    """
+
+    single_reduction (default): the CG recurrence in its Chronopoulos-Gear form -- w = A r, gamma = <r,r> and
+    delta = <r,w> come out of ONE kernel and are all-reduced together (one collective of two scalars per CG step instead
+    of two collectives), the four vector updates are one kernel, the residual of the warm start and the loss of the
+    outer iteration are fused into the kernels that read those vectors anyway, and the dual pair is kept as
+    (t = z - u, u) so that the right-hand side reads one gradient array: 4 Nd + 11 n_cg + 5 words per voxel and outer
+    iteration instead of 5 Nd + 11 n_cg + 17 (76 instead of 92 for Nd = 4, n_cg = 5).  ``single_reduction=False`` is the
+    textbook recurrence of round 1 (tv_cg_step1 / tv_cg_step2).  Both are the same iteration in exact arithmetic;
+    oracle.admm restates both."""
 
     def __init__(self, x0, regularization, rho, n_cg=10, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None):
+                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True):
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.reg, self.rho, self.n_cg = float(regularization), float(rho), int(n_cg)
+        self.single = bool(single_reduction)
         self.x = self.x0.clone()
-        self.z = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
-        self.u = torch.zeros_like(self.z)
+        self._zt = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)   # z, or t = z - u (single_reduction)
+        self.u = torch.zeros_like(self._zt)
         self.b = torch.empty_like(self.x0)
         self.r = torch.empty_like(self.x0)
         self.d = torch.empty_like(self.x0)
-        self.Ad = torch.empty_like(self.x0)
+        self.Ad = torch.empty_like(self.x0)          # A d (textbook) / s = A d (single reduction)
         self.ws = self.geo.workspace()
         self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
         pl, s_ = self.plan, self.slab
@@ -527,73 +536,129 @@ class ADMM(_SlabProblem):
         self.wh_next = self.new_plane() if pl.g_need_next else None
         self.ws_prev = self.new_plane() if pl.g_send_prev else None
         self.ws_next = self.new_plane() if pl.g_send_next else None
-        self.sc = torch.zeros(4, dtype=torch.float64, device=self.device)   # rs, dAd, rs_new, spare
-        self.dots3 = torch.zeros(3, dtype=torch.float64, device=self.device)
+        self.sc = torch.zeros(4, dtype=torch.float64, device=self.device)   # rs, dAd, rs_new, spare / gamma, delta, gamma_old, alpha_old
+        self.dots3 = torch.zeros((3, 2), dtype=torch.float64, device=self.device)
+        self.dots = torch.zeros(2, dtype=torch.float64, device=self.device)
+
+    @property
+    def z(self):
+        """The split variable z (single_reduction keeps t = z - u: z = t + u)."""
+        return self._zt + self.u if self.single else self._zt
 
     def _halo2(self, v):
         self.slab.wait(self.plan.exchange_image2(v, self.h2_prev, self.h2_next))
         return self.h2_prev, self.h2_next
 
-    def _normal_range(self, v, out, a, b, hp, hn, dot):
-        """out[a:b] = (I + rho D^T D) v on local planes [a, b); hp / hn: two-plane halos of that range."""
+    def _normal_range(self, v, out, a, b, hp, hn, dots, rhs=None, out2=None):
+        """out[a:b] = (I + rho D^T D) v (or rhs - that, with a copy in out2) on local planes [a, b); hp / hn: two-plane
+        halos of that range; dots: two device words."""
         g = self.geom(a, b)
-        _nv.check(self.lib.tv_normal_op(g.ref, _nv.ptr(v[a:b]), _nv.ptr(hp), _nv.ptr(hn), self.rho, _nv.ptr(out[a:b]),
-                                        dot.data_ptr(), _nv.ptr(self.ws), self.stream))
+        _nv.check(self.lib.tv_normal_op2(g.ref, _nv.ptr(v[a:b]), _nv.ptr(hp), _nv.ptr(hn), self.rho,
+                                         _nv.ptr(rhs[a:b]) if rhs is not None else None, _nv.ptr(out[a:b]),
+                                         _nv.ptr(out2[a:b]) if out2 is not None else None, dots.data_ptr(), _nv.ptr(self.ws),
+                                         self.stream))
 
-    def _normal(self, v, out, dot):
+    def _normal(self, v, out, dots, rhs=None, out2=None, reduce=True):
+        """Two-plane halo exchange hidden behind the interior planes, then the operator; dots (2 device words) summed
+        over the launches and, with ``reduce``, over the ranks."""
         nz = self.slab.nz
-        if self.sh and nz >= 6:
-            # interior planes first (their two-plane halos are this rank's own planes) while the exchange is in
-            # flight, then the two 2-plane edges
+        if self.sh and nz >= 5:
             h = self.plan.exchange_image2(v, self.h2_prev, self.h2_next)
-            self._normal_range(v, out, 2, nz - 2, v[0:2], v[nz - 2:nz], self.dots3[0:1])
+            self._normal_range(v, out, 2, nz - 2, v[0:2], v[nz - 2:nz], self.dots3[0], rhs, out2)
             self.slab.wait(h)
-            self._normal_range(v, out, 0, 2, self.h2_prev, v[2:4], self.dots3[1:2])
-            self._normal_range(v, out, nz - 2, nz, v[nz - 4:nz - 2], self.h2_next, self.dots3[2:3])
-            torch.sum(self.dots3, dim=0, keepdim=True, out=dot)
+            self._normal_range(v, out, 0, 2, self.h2_prev, v[2:4], self.dots3[1], rhs, out2)
+            self._normal_range(v, out, nz - 2, nz, v[nz - 4:nz - 2], self.h2_next, self.dots3[2], rhs, out2)
+            torch.sum(self.dots3, dim=0, out=dots)
         else:
             hp, hn = self._halo2(v)
-            self._normal_range(v, out, 0, nz, hp, hn, dot)
-        self.slab.allreduce_sum_(dot)
+            self._normal_range(v, out, 0, nz, hp, hn, dots, rhs, out2)
+        if reduce:
+            self.slab.allreduce_sum_(dots)
 
-    def step(self, out):
-        """One outer iteration; out: fp64 device tensor [tv, fid] of this rank."""
+    def _rhs(self):
+        """b = x0 + rho D^T (z - u); the boundary planes of (z - u) travel to the neighbours first."""
         g, lib, s, nz = self.geo, self.lib, self.slab, self.slab.nz
-        code = _nv.dtype_code(self.dtype)
-        plane = g.plane
-        # ---- rhs b = x0 + rho D^T (z - u), halos of (z - u) differenced on the boundary planes ----
+        code, plane = _nv.dtype_code(self.dtype), g.plane
+        if self.single:          # the first array IS t = z - u
+            h = s.exchange(send_prev=self._zt[0, self.ch_fwd] if self.plan.g_send_prev else None,
+                           send_next=self._zt[nz - 1, self.ch_back] if self.plan.g_send_next else None,
+                           recv_prev=self.wh_prev[0] if self.wh_prev is not None else None,
+                           recv_next=self.wh_next[0] if self.wh_next is not None else None)
+            s.wait(h)
+            _nv.check(lib.tv_DT_axpy(g.ref, _nv.ptr(self._zt), None, _nv.ptr(self.wh_prev), _nv.ptr(self.wh_next),
+                                     _nv.ptr(self.x0), self.rho, _nv.ptr(self.b), self.stream))
+            return
         if self.plan.g_send_next:
-            _nv.check(lib.tv_sub(code, plane, _nv.ptr(self.z[nz - 1, self.ch_back]), _nv.ptr(self.u[nz - 1, self.ch_back]),
+            _nv.check(lib.tv_sub(code, plane, _nv.ptr(self._zt[nz - 1, self.ch_back]), _nv.ptr(self.u[nz - 1, self.ch_back]),
                                  _nv.ptr(self.ws_next), self.stream))
         if self.plan.g_send_prev:
-            _nv.check(lib.tv_sub(code, plane, _nv.ptr(self.z[0, self.ch_fwd]), _nv.ptr(self.u[0, self.ch_fwd]),
+            _nv.check(lib.tv_sub(code, plane, _nv.ptr(self._zt[0, self.ch_fwd]), _nv.ptr(self.u[0, self.ch_fwd]),
                                  _nv.ptr(self.ws_prev), self.stream))
         s.wait(s.exchange(send_prev=self.ws_prev, send_next=self.ws_next, recv_prev=self.wh_prev, recv_next=self.wh_next))
-        _nv.check(lib.tv_DT_axpy(g.ref, _nv.ptr(self.z), _nv.ptr(self.u), _nv.ptr(self.wh_prev), _nv.ptr(self.wh_next),
+        _nv.check(lib.tv_DT_axpy(g.ref, _nv.ptr(self._zt), _nv.ptr(self.u), _nv.ptr(self.wh_prev), _nv.ptr(self.wh_next),
                                  _nv.ptr(self.x0), self.rho, _nv.ptr(self.b), self.stream))
-        # ---- CG on (I + rho D^T D) x = b -----------------------------------------------------------
-        rs, dAd, rs_new, spare = self.sc[0:1], self.sc[1:2], self.sc[2:3], self.sc[3:4]
-        self._normal(self.x, self.Ad, spare)
-        _nv.check(lib.tv_sub(code, self.x.numel(), _nv.ptr(self.b), _nv.ptr(self.Ad), _nv.ptr(self.r), self.stream))
-        self.d.copy_(self.r)
-        _nv.check(lib.tv_dot(g.ref, _nv.ptr(self.r), _nv.ptr(self.r), rs.data_ptr(), _nv.ptr(self.ws), self.stream))
-        s.allreduce_sum_(rs)
+
+    def _zu(self, out_tv):
+        """z / u update (needs one x halo plane per side: the two-plane exchange is reused)."""
+        g, lib = self.geo, self.lib
+        hp, hn = self._halo2(self.x)
+        xp = hp[1:2] if hp is not None else None      # plane z0-1
+        xn = hn[0:1] if hn is not None else None      # plane z0+nz
+        fn = lib.tv_admm_tu if self.single else lib.tv_admm_zu
+        _nv.check(fn(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self._zt), _nv.ptr(self.u),
+                     self.reg / self.rho, out_tv.data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def step(self, out):
+        """One outer iteration; out: fp64 device tensor [tv, |x - x0|^2] of this rank."""
+        if self.single:
+            return self._step_single(out)
+        g, lib, s = self.geo, self.lib, self.slab
+        code = _nv.dtype_code(self.dtype)
+        self._rhs()
+        # ---- CG on (I + rho D^T D) x = b, textbook recurrence -----------------------------------------
+        rs, dAd, rs_new = self.sc[0:1], self.sc[1:2], self.sc[2:3]
+        self._normal(self.x, self.r, self.dots, rhs=self.b, out2=self.d)      # r = d = b - A x, dots[0] = <r, r>
+        rs.copy_(self.dots[0:1])
         for _ in range(self.n_cg):
-            self._normal(self.d, self.Ad, dAd)
+            self._normal(self.d, self.Ad, self.dots)
+            dAd.copy_(self.dots[0:1])
             _nv.check(lib.tv_cg_step1(g.ref, _nv.ptr(self.x), _nv.ptr(self.r), _nv.ptr(self.d), _nv.ptr(self.Ad),
                                       rs.data_ptr(), dAd.data_ptr(), rs_new.data_ptr(), _nv.ptr(self.ws), self.stream))
             s.allreduce_sum_(rs_new)
             _nv.check(lib.tv_cg_step2(g.ref, _nv.ptr(self.d), _nv.ptr(self.r), rs_new.data_ptr(), rs.data_ptr(), self.stream))
             rs.copy_(rs_new)
-        # ---- z / u update (needs one x halo plane per side: reuse the two-plane exchange) ---------------
-        hp, hn = self._halo2(self.x)
-        xp = hp[1:2] if hp is not None else None      # plane z0-1
-        xn = hn[0:1] if hn is not None else None      # plane z0+nz
-        _nv.check(lib.tv_admm_zu(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.z), _nv.ptr(self.u),
-                                 self.reg / self.rho, out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        self._zu(out[0:1])
         # fidelity 1/2 |x - x0|^2 = 1/2 <x-x0, x-x0>: r is free now
         _nv.check(lib.tv_sub(code, self.x.numel(), _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(self.r), self.stream))
         _nv.check(lib.tv_dot(g.ref, _nv.ptr(self.r), _nv.ptr(self.r), out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def _step_single(self, out):
+        g, lib, s = self.geo, self.lib, self.slab
+        sc, w, sv = self.sc, self.b, self.Ad          # w = A r lives in b (free once r is formed), s = A d in Ad
+        self._rhs()
+        # r = b - A x with gamma = <r, r> (local); then w = A r with delta = <r, w>: ONE all-reduce for the pair
+        self._normal(self.x, self.r, self.dots, rhs=self.b, reduce=False)
+        sc[0:1].copy_(self.dots[0:1])
+        self._normal(self.r, w, self.dots, reduce=False)
+        sc[1:2].copy_(self.dots[0:1])
+        sc[2:4].zero_()                               # alpha_old = 0: first step of this solve
+        s.allreduce_sum_(sc[0:2])
+        for c in range(self.n_cg):
+            last = (c + 1 == self.n_cg)
+            _nv.check(lib.tv_cg_update(g.ref, _nv.ptr(self.x), _nv.ptr(self.r), _nv.ptr(self.d), _nv.ptr(sv), _nv.ptr(w),
+                                       sc.data_ptr(), _nv.ptr(self.x0) if last else None, out[1:2].data_ptr() if last else None,
+                                       _nv.ptr(self.ws), self.stream))
+            if last:
+                break
+            self._normal(self.r, w, self.dots, reduce=False)          # dots = {<r, w>, <r, r>}
+            sc[0:1].copy_(self.dots[1:2])
+            sc[1:2].copy_(self.dots[0:1])
+            s.allreduce_sum_(sc[0:2])
+        if self.n_cg == 0:
+            out[1:2] = 0.5 * torch.sum((self.x.double() - self.x0.double()) ** 2)
+        else:
+            out[1:2].mul_(2.0)                        # run() halves: the slot holds |x - x0|^2 like the textbook path
+        self._zu(out[0:1])
 
     def run(self, n_outer):
         hist = torch.zeros((n_outer, 2), dtype=torch.float64, device=self.device)

@@ -291,7 +291,7 @@ def test_config4_admm_end_to_end_two_slabs_against_the_oracle(scheme, production
     assert len(ret) == 2
     rng = np.random.default_rng(33)
     x0 = (60.0 * rng.random(shape)).astype(np.float32).astype(np.float64)
-    wx, wloss, wz, wu = occ.admm(x0, n_outer, 7.0, 0.1, n_cg, scheme=scheme, return_state=True, **kw)
+    wx, wloss, wz, wu = occ.admm(x0, n_outer, 7.0, 0.1, n_cg, scheme=scheme, return_state=True, single_reduction=True, **kw)
     for r in range(2):
         z0, nz = ret[r]["z"]
         assert nz == 32

@@ -98,7 +98,7 @@ def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, z
         assert any(ret[r]["cp_overlap"] for r in range(world))
     if "sg_loss" in ret[0]:
         sx, sloss = orc.subgradient_descent(x0, 5, 7.0, 2e-3, scheme=scheme, **kw)
-        ax, aloss = orc.admm(x0, 3, 7.0, 0.1, 3, scheme=scheme, **kw)
+        ax, aloss = orc.admm(x0, 3, 7.0, 0.1, 3, scheme=scheme, single_reduction=True, **kw)
         for r in range(world):
             z0, nz = ret[r]["z"]
             np.testing.assert_allclose(ret[r]["sg_loss"], sloss, rtol=1e-5)

@@ -203,7 +203,7 @@ def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, tv
         x0 = (50.0 * rng.random(shape)).astype(np.float32)
         ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 5.0, 0.1, n_cg=4, scheme=scheme, reg_time=0.5)
         loss = ad.run(4)
-        wx, wloss = orc.admm(x0.astype(np.float64), 4, 5.0, 0.1, 4, scheme=scheme, reg_time=0.5)
+        wx, wloss = orc.admm(x0.astype(np.float64), 4, 5.0, 0.1, 4, scheme=scheme, reg_time=0.5, single_reduction=True)
         np.testing.assert_allclose(loss, wloss, rtol=2e-5)
         np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=1e-4, atol=2e-3)
 
@@ -470,11 +470,16 @@ def test_admm_matches_oracle(pytv, scheme, shape, lz, mu):
     import torch
     for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-5, 5e-3)):
         x0 = _noisy(shape, 6, dtype)
-        wx, wloss = orc.admm(x0.astype(np.float64), 8, 25.0, 0.05, 6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu)
-        ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 25.0, 0.05, n_cg=6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu)
-        loss = ad.run(8)
-        np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s" % (scheme, shape))
-        np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
+        for single in (True, False):      # Chronopoulos-Gear (default) and textbook CG, each against the oracle's restatement
+            wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 8, 25.0, 0.05, 6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+                                         single_reduction=single, return_state=True)
+            ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 25.0, 0.05, n_cg=6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+                                   single_reduction=single)
+            loss = ad.run(8)
+            np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s single=%s" % (scheme, shape, single))
+            np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
+            np.testing.assert_allclose(ad.z.cpu().numpy(), wz, rtol=rtol * 10, atol=atol)
+            np.testing.assert_allclose(ad.u.cpu().numpy(), wu, rtol=rtol * 10, atol=atol)
 
 
 def test_denoise_tv_chambolle_front_end(pytv):

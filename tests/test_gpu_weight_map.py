@@ -77,7 +77,7 @@ def test_general_weight_map_matches_oracle(pytv, scheme, dtype, shape):
     # ADMM (normal operator, z/u update, D^T axpy all see the map)
     ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, **kw)
     la = ad.run(3)
-    _, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, **kw)
+    _, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, single_reduction=True, **kw)
     np.testing.assert_allclose(la, lref, rtol=1e-4 if dtype == np.float32 else 1e-9)
     # adjointness with the map
     g = nv.Geometry(shape, scheme, torch.float64 if dtype == np.float64 else torch.float32, "cuda", **kw)

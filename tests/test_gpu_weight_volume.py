@@ -97,7 +97,7 @@ def test_general_weight_volume_matches_oracle(pytv, scheme, dtype, shape):
     np.testing.assert_allclose(cp.result().cpu().numpy(), ref_x, rtol=1e-4, atol=1e-3 if dtype == np.float32 else 1e-8)
     ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, **kw)
     la = ad.run(3)
-    ax, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, **kw)
+    ax, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, single_reduction=True, **kw)
     np.testing.assert_allclose(la, lref, rtol=1e-4 if dtype == np.float32 else 1e-9)
     np.testing.assert_allclose(ad.result().cpu().numpy(), ax, rtol=1e-4, atol=5e-3 if dtype == np.float32 else 1e-8)
     sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, **kw)
@@ -213,7 +213,7 @@ def test_sharded_solvers_with_a_weight_volume_equal_the_unsharded_oracle(scheme)
     kwf = dict(kw, mask_static=W)
     wx, wloss = orc.chambolle_pock(x0, 6, 7.0, scheme=scheme, **kwf)
     sx, sloss = orc.subgradient_descent(x0, 4, 7.0, 2e-3, scheme=scheme, **kwf)
-    ax, aloss = orc.admm(x0, 2, 7.0, 0.1, 3, scheme=scheme, **kwf)
+    ax, aloss = orc.admm(x0, 2, 7.0, 0.1, 3, scheme=scheme, single_reduction=True, **kwf)
     for r in range(world):
         z0, nz = ret[r]["z"]
         assert abs(ret[r]["tau"] - orc.cp_step_size(scheme, shape[0], shape[1], 1.3, 0.7, float(W.max()))) < 1e-15

@@ -87,13 +87,16 @@ def main():
         "tv_cp_fixup": lambda G, x: lib.tv_cp_fixup(G, x, N, N, x, x, ctypes.c_double(.1), ctypes.c_int64(0), ctypes.c_int64(-1), dp if x else N, x, N),
         "tv_admm_zu": lambda G, x: lib.tv_admm_zu(G, x, N, N, x, x, ctypes.c_double(1.), dp if x else N, x, N),
         "tv_normal_op": lambda G, x: lib.tv_normal_op(G, x, N, N, ctypes.c_double(.1), x, dp if x else N, x, N),
+        "tv_admm_tu": lambda G, x: lib.tv_admm_tu(G, x, N, N, x, x, ctypes.c_double(1.), dp if x else N, x, N),
+        "tv_normal_op2": lambda G, x: lib.tv_normal_op2(G, x, N, N, ctypes.c_double(.1), N, x, N, dp if x else N, x, N),
+        "tv_cg_update": lambda G, x: lib.tv_cg_update(G, x, x, x, x, x, dp if x else N, N, N, x, N),
         "tv_cg_step1": lambda G, x: lib.tv_cg_step1(G, x, x, x, x, dp if x else N, dp, dp, x, N),
         "tv_cg_step2": lambda G, x: lib.tv_cg_step2(G, x, x, dp if x else N, dp, N),
         "tv_dot": lambda G, x: lib.tv_dot(G, x, x, dp if x else N, x, N),
         "tv_subgrad_step": lambda G, x: lib.tv_subgrad_step(G, x, x, x, ctypes.c_double(.1), ctypes.c_double(1.), dp if x else N, x, N),
     }
     halo_ops = ("tv_D", "tv_DT", "tv_DT_axpy", "tv_subgrad", "tv_subgrad_fused", "tv_subgrad_fused_norms", "tv_cp_dual", "tv_cp_primal",
-                "tv_admm_zu", "tv_normal_op", "tv_cp_fixup")
+                "tv_admm_zu", "tv_admm_tu", "tv_normal_op", "tv_normal_op2", "tv_cp_fixup")
     for name, call in calls.items():
         expect_neg(call(None, a), name + "(NULL geometry)")
         expect_neg(call(ctypes.byref(g), None), name + "(NULL arrays)")

@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pytv-4d_amd", "csrc")
-UNITS = ["tv_kernels", "tv_march_D", "tv_march_DT", "tv_fused", "tv_subgrad", "tv_sgstep", "tv_dstream", "tv_comm"]
+UNITS = ["tv_kernels", "tv_march_D", "tv_march_DT", "tv_fused", "tv_subgrad", "tv_sgstep", "tv_dstream", "tv_comm", "tv_nstream"]
 SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-g", "-O1"]
 
 
