@@ -8,7 +8,9 @@
  *
  * Build: gcc -O3 -fopenmp -shared -fPIC oracle/tv_oracle_c.c -o oracle/_build/libtv_oracle_c.so  (oracle/build_c.py) */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef struct tvc_geom {
     long nz, m, ny, nx;

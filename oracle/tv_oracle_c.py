@@ -87,19 +87,27 @@ def compute_L21_norm(d, shape_img, scheme="upwind"):
 
 
 def chambolle_pock(x0, n_iter, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, sigma_D=0.5, sigma_A=1.0,
-                   tau=None, mask_static=False, factor_reg_static=0):
-    """Same iteration as tv_oracle.chambolle_pock, in C with OpenMP (all host cores unless OMP_NUM_THREADS says otherwise)."""
+                   tau=None, mask_static=False, factor_reg_static=0, numa=False):
+    """Same iteration as tv_oracle.chambolle_pock, in C with OpenMP (all host cores unless OMP_NUM_THREADS says otherwise).
+    numa=True: the working arrays are allocated and first touched by the worker threads (bench.py's multi-core baseline);
+    returns (x, loss, seconds of the iterations alone)."""
     x0 = np.ascontiguousarray(x0, dtype=np.float32 if np.asarray(x0).dtype == np.float32 else np.float64)
     g, keep = _geom(x0.shape, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
     if tau is None:
         from . import tv_oracle as _orc
         tau = _orc.cp_step_size(scheme, x0.shape[0], x0.shape[1], reg_z_over_reg, reg_time,
                                 _orc.time_weight_max(mask_static, factor_reg_static))
+    loss = np.zeros(n_iter)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    if numa:
+        x, secs = np.empty_like(x0), ctypes.c_double(0.0)
+        getattr(lib(), "tvc_cp_numa" + _suf(x0))(ctypes.byref(g), vp(x), vp(x0), ctypes.c_int(n_iter), ctypes.c_double(regularization),
+                                                  ctypes.c_double(sigma_D), ctypes.c_double(sigma_A), ctypes.c_double(tau), vp(loss),
+                                                  ctypes.byref(secs))
+        return x, loss, secs.value
     x, p = x0.copy(), np.zeros_like(x0)
     q = np.zeros((x0.shape[0], g.nd) + x0.shape[1:], dtype=x0.dtype)
     d, dt = np.empty_like(q), np.empty_like(x0)
-    loss = np.zeros(n_iter)
-    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     getattr(lib(), "tvc_cp" + _suf(x0))(ctypes.byref(g), vp(x), vp(x0), vp(p), vp(q), vp(d), vp(dt), ctypes.c_int(n_iter),
                                          ctypes.c_double(regularization), ctypes.c_double(sigma_D), ctypes.c_double(sigma_A),
                                          ctypes.c_double(tau), vp(loss))

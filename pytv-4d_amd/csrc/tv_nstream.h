@@ -32,7 +32,7 @@ struct NormalArgs {
 constexpr int NS_TWN = 8;
 
 template <int M, bool TWIN>
-__global__ __launch_bounds__(256, 3) void k_normal_stream(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
+__global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 3) void k_normal_stream(DG g, WT<float> w, Nor
         {
             const float* pp = g.za ? plane(zs - 1) : nullptr;
             const float* pc = plane(zs);
-            const float* pn = g.za ? plane(zs + 1) : nullptr;
+            const float* pn = (g.za || zs + 1 < ze) ? plane(zs + 1) : nullptr;        // the next centre plane even without a z axis
 #pragma unroll
             for (int t = 0; t < M; ++t) {
                 P[t] = load_c(pp, t);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 3) void k_normal_stream(DG g, WT<float> w, Nor
             const float m_pz = (g.za && gz > 0) ? wz2 : 0.f, m_nz = (g.za && gz + 1 < g.nzg) ? wz2 : 0.f;
             const float* pc = plane(z);
             const float* pc1 = (z + 1 < ze) ? plane(z + 1) : nullptr;             // centre plane of the next step (halo rows, edges)
-            const float* pn2 = (g.za && z + 1 < ze) ? plane(z + 2) : nullptr;      // its next plane
+            const float* pn2 = (z + 1 < ze && (g.za || z + 2 < ze)) ? plane(z + 2) : nullptr;      // its next plane
             F4 cold = zero;
             if (TWIN && g.ta && t0 > 0) cold = ok ? ldu(pc + foff(-1), voff) : zero;
 #pragma unroll
@@ -107,8 +107,11 @@ __global__ __launch_bounds__(256, 3) void k_normal_stream(DG g, WT<float> w, Nor
                 const F4 nr = (row == 3) ? h : sdn, pr = (row == 0) ? h : sup;
                 F4 r = m_pr * (c - pr) - m_nr * (nr - c);
                 {
-                    const float left = (lx == 0) ? E[t] : dpp_from_left(c.v[3]);
-                    const float right = (lx == 15) ? E[t] : dpp_from_right(c.v[0]);
+                    // the cross-lane moves are executed by EVERY lane (a DPP read from a lane that a branch has switched
+                    // off returns 0), the select comes afterwards
+                    const float from_l = dpp_from_left(c.v[3]), from_r = dpp_from_right(c.v[0]);
+                    const float left = (lx == 0) ? E[t] : from_l;
+                    const float right = (lx == 15) ? E[t] : from_r;
                     const float e0 = c.v[1] - c.v[0], e1 = c.v[2] - c.v[1], e2 = c.v[3] - c.v[2];
                     // interior elements of the vector always have both column neighbours inside the frame (nx % 4 == 0)
                     r.v[0] += m_c0 * (c.v[0] - left) - e0;

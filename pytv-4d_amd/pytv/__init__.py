@@ -21,6 +21,16 @@ from . import tv_GPU             # noqa: E402
 from . import solvers            # noqa: E402
 from . import slab               # noqa: E402
 from . import restoration        # noqa: E402
+from . import utils              # noqa: E402
 from .restoration import denoise_tv_chambolle   # noqa: E402
 
-__all__ = ["tv_GPU", "tv_operators_GPU", "solvers", "slab", "restoration", "denoise_tv_chambolle"]
+__all__ = ["tv_GPU", "tv_operators_GPU", "solvers", "slab", "restoration", "utils", "denoise_tv_chambolle"]
+
+
+def __getattr__(name):
+    if name in ("tv_CPU", "tv_operators_CPU", "tests"):
+        raise AttributeError(
+            "pytv.%s is not part of the MI355X build: it replaces the GPU half of PyTV-4D (pytv.tv_GPU, pytv.tv_operators_GPU). "
+            "Use the reference package for its NumPy twins and self-test harness; a NumPy restatement lives under oracle/ of "
+            "this repository as test infrastructure." % name)
+    raise AttributeError("module 'pytv' has no attribute %r" % name)

@@ -119,3 +119,22 @@ def test_product_package_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src and "tv_oracle" not in src.replace("oracle/tv_oracle.py", ""), fn
+
+
+def test_package_surface_says_what_is_missing(monkeypatch, tmp_path):
+    """pytv.utils.cameraman() exists (clear message when the image is not available); the CPU twins are named
+    as absent instead of failing with a bare AttributeError."""
+    import numpy as np
+    import pytv
+    with pytest.raises(AttributeError, match="not part of the MI355X build"):
+        pytv.tv_CPU
+    p = tmp_path / "cam.npy"
+    np.save(p, np.arange(256 * 256).reshape(256, 256))
+    monkeypatch.setenv("PYTV_CAMERAMAN", str(p))
+    assert pytv.utils.cameraman().shape == (256, 256)
+    monkeypatch.delenv("PYTV_CAMERAMAN")
+    try:
+        import skimage  # noqa: F401
+    except ImportError:
+        with pytest.raises(FileNotFoundError, match="PYTV_CAMERAMAN"):
+            pytv.utils.cameraman()

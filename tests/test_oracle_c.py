@@ -69,3 +69,12 @@ def test_single_reduction_cg_is_the_same_iteration(scheme):
     bx, bloss = orc.admm(x0, 5, 5.0, 0.3, 4, scheme=scheme, single_reduction=True, **kw)
     np.testing.assert_allclose(bloss, aloss, rtol=1e-9)
     np.testing.assert_allclose(bx, ax, rtol=1e-8, atol=1e-8)
+
+
+def test_c_oracle_numa_variant_is_the_same_iteration():
+    rng = np.random.default_rng(12)
+    x0 = (50 * rng.random((6, 3, 9, 10))).astype(np.float32)
+    kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
+    ax, aloss = occ.chambolle_pock(x0, 7, 5.0, scheme="hybrid", **kw)
+    bx, bloss, secs = occ.chambolle_pock(x0, 7, 5.0, scheme="hybrid", numa=True, **kw)
+    assert np.array_equal(ax, bx) and np.array_equal(aloss, bloss) and secs > 0
