@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--two-kernel", action="store_true", help="force the dual + primal kernel pair instead of the one-sweep kernel")
+    ap.add_argument("--comm", default="torch", choices=["torch", "cabi"],
+                    help="halo exchange through torch.distributed (RCCL process group, default) or through the C-ABI's own RCCL "
+                         "context (tv_ctx_create / tv_halo_exchange; torch.distributed only hands out the unique id)")
     args = ap.parse_args()
 
     import torch
@@ -151,7 +154,11 @@ def main():
 
     wl = WORKLOADS[args.workload]
     shape = wl["shape"]
-    slab = Slab(shape[0], rank=rank, world=world)
+    native = None
+    if args.comm == "cabi" and dist.is_initialized() and world > 1:
+        from pytv.slab import NativeComm
+        native = NativeComm(device=device)
+    slab = Slab(shape[0], rank=rank, world=world, native_comm=native)
     x0 = synth_slab(shape, slab.z0, slab.nz, device)
     cp = pytv.solvers.ChambollePock(x0, 25.0, scheme=args.scheme, reg_z_over_reg=wl["reg_z"], reg_time=wl["reg_time"],
                                     slab=slab, overlap=not args.no_overlap, fused=False if args.two_kernel else None)
@@ -208,7 +215,7 @@ def main():
                                "two_kernel_(6+3Nd)_words": bytes_iter_fused * it_s / 1e9 / world,
                                "one_sweep_(5+2Nd)_words": 4.0 * (5 + 2 * nd) * V * it_s / 1e9 / world, "per": "GPU"},
         "loss_first_last": [float(loss[W]), float(loss[-1])],
-        "rccl_ranks": rccl_ranks,        # ranks of the RCCL communicator the run used (0: no process group / test backend)
+        "rccl_ranks": rccl_ranks, "comm": args.comm if world > 1 else None,        # ranks of the RCCL communicator the run used (0: no process group / test backend)
         "halo": {"backend": (dist.get_backend() if dist.is_initialized() else None), "planes_per_exchange": 1,
                  "bytes_per_plane": 4 * shape[1] * shape[2] * shape[3], "exchanges_per_iteration": 2 if world > 1 else 0},
     }

@@ -99,6 +99,20 @@ def _worker(rank, world, port, shape, lz, mu, ret):
             slab.allreduce_sum_(part)
             total = orc.compute_L21_norm(orc.D(x_full, scheme, lz, mu))
             errs["tv_" + scheme] = abs(float(part[0]) - total) / total
+        # ---- maximum over the ranks (the largest time weight of a sharded weight volume enters the CP step size) -----
+        mx = torch.tensor([float(rank + 1), -float(rank)], dtype=torch.float64)
+        slab.allreduce_max_(mx)
+        assert mx.tolist() == [float(world), 0.0]
+        # ---- the boundary planes of a per-voxel weight volume travel like image planes (solvers._SlabProblem) ----------
+        W = np.random.default_rng(79).random(shape)
+        wl = torch.as_tensor(slab.local(W).copy())
+        gp, gn = torch.full((1,) + shape[1:], np.nan, dtype=torch.float64), torch.full((1,) + shape[1:], np.nan, dtype=torch.float64)
+        slab.wait(slab.exchange(send_prev=wl[0:1] if slab.prev is not None else None, send_next=wl[nz - 1:nz] if slab.next is not None else None,
+                                recv_prev=gp if slab.prev is not None else None, recv_next=gn if slab.next is not None else None))
+        if slab.prev is not None:
+            assert np.array_equal(gp[0].numpy(), W[z0 - 1])
+        if slab.next is not None:
+            assert np.array_equal(gn[0].numpy(), W[z0 + nz])
         ret[rank] = errs
     finally:
         dist.destroy_process_group()

@@ -20,8 +20,11 @@ def main():
             shape = (shape[0], 3) + shape[2:]
         overlap, zchunk = bool(rng.integers(0, 2)), str(int(rng.choice([0, 1, 2])))
         mp = pytest.MonkeyPatch()
+
+        def tvopt(name, value):          # what the tvopt fixture of tests/conftest.py does: environment (for the spawned ranks) + option
+            mp.setenv(name, str(value))
         try:
-            T.test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, zchunk, mp)
+            T.test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, zchunk, tvopt)
             print("ok  ", scheme, world, shape, overlap, zchunk, flush=True)
         except AssertionError as e:
             if str(e).strip():            # a numeric mismatch; the test's bare asserts only check which path was exercised

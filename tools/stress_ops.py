@@ -31,12 +31,14 @@ for case in range(n_cases):
     if scheme == "central" and (nz == 2 or m == 2):
         nz, m = 3, max(m, 3)
     kw = dict(reg_z_over_reg=lz, reg_time=mu)
-    kind = int(rng.integers(0, 4))             # 0, 1: plain; 2: boolean mask; 3: per-pixel weight map
+    kind = int(rng.integers(0, 5))             # 0, 1: plain; 2: boolean mask; 3: per-pixel weight map; 4: per-voxel weight volume
     if kind == 2:
         kw.update(mask_static=rng.random((ny, nx)) < 0.4, factor_reg_static=2.3)
     elif kind == 3:
         kw.update(mask_static=rng.random((ny, nx)) * 2.0)
-    info = (scheme, (nz, m, ny, nx), lz, mu, ("plain", "plain", "mask", "weights")[kind], os.environ["TV_ZCHUNK"])
+    elif kind == 4:
+        kw.update(mask_static=rng.random((nz, m, ny, nx)) * 2.0)
+    info = (scheme, (nz, m, ny, nx), lz, mu, ("plain", "plain", "mask", "weights", "weight volume")[kind], os.environ["TV_ZCHUNK"])
     dt = np.float64 if rng.random() < 0.25 else np.float32          # fp64: the one-site-per-thread kernels, any M
     tol = dict(rtol=1e-5, atol=2e-5) if dt == np.float32 else dict(rtol=1e-10, atol=1e-9)
     TOL[0] = tol
@@ -60,9 +62,10 @@ for case in range(n_cases):
         cp = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, fused=fused, **kw)
         check("cp loss fused=%s" % cp.fused, cp.run(4), rl, info, rtol=1e-5 * lt, atol=0)
         check("cp x fused=%s" % cp.fused, cp.result().cpu().numpy(), rx, info, rtol=1e-4 * lt, atol=1e-3 * lt)
-    ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, **kw)
-    _, al = orc.admm(x64 * 5, 2, 7.0, 0.1, 3, scheme=scheme, single_reduction=True, **kw)
-    check("admm", ad.run(2), al, info, rtol=1e-4 * lt, atol=0)
+    for single in (True, False):
+        ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, single_reduction=single, **kw)
+        _, al = orc.admm(x64 * 5, 2, 7.0, 0.1, 3, scheme=scheme, single_reduction=single, **kw)
+        check("admm single=%s" % single, ad.run(2), al, info, rtol=1e-4 * lt, atol=0)
     sg = pytv.solvers.SubgradientDescent(x0, 2.0, 0.02, scheme=scheme, **kw)
     _, sl = orc.subgradient_descent(x64 * 5, 3, 2.0, 0.02, scheme=scheme, **kw)
     check("sg", sg.run(3), sl, info, rtol=1e-4 * lt, atol=0)
