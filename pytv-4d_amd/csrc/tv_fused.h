@@ -40,6 +40,9 @@ using F4 = Vec<float, 4>;
 #ifndef TV_FUSED_NW
 #define TV_FUSED_NW 8
 #endif
+#ifndef TV_FUSED_PFQ
+#define TV_FUSED_PFQ 1
+#endif
 constexpr int CP_NW = TV_FUSED_NW;
 constexpr int CP_TR = TV_FUSED_TR, CP_TL = 64 / CP_TR, CP_WC = 4 * CP_TL, CP_BC = CP_NW * CP_WC;
 constexpr int CP_LSH = (CP_TL == 16) ? 4 : 3;
@@ -222,6 +225,24 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
     }
     const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
     F4 C[M], P[M];
+    // PFQ (round 2, central): the four dual channels of the NEXT frame are requested at the top of the current one.  Central
+    // has 1 + 4 streams per frame (hybrid: 1 + 8) but hybrid's per-site arithmetic (every channel plays both adjoint roles),
+    // so its waves waited ~77 % of the time with too few bytes in flight: sweep 26.6 - 27.4 -> 21.2 - 23.0 ms on the
+    // north-star volume (0.52 -> 0.63 of peak; profiles/r2_ab_pfq.txt).  Measured for upwind / downwind too: 3 - 7 % SLOWER
+    // there (they already request plane z+1 of x a step ahead), so it stays off; hybrid has no registers for it.
+    constexpr bool PFQ = (TV_FUSED_PFQ != 0) && (S == CENTRAL) && !TWIN;
+    F4 qpre[PFQ ? 4 : 1];
+    if (PFQ) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qpre[k] = zero;
+        if (c.ok) {
+            const float* qb0 = a.q + (long long)c.zs * g.s_dz;
+            for_each_channel<S>(g, [&](auto slot, int ch) {
+                constexpr int k = decltype(slot)::value;
+                qpre[k & 3] = ldu(qb0 + (long long)ch * g.s_z, voff);
+            });
+        }
+    }
     {
         const float* pc = zplane<float>(g, a.x_in, a.xp, a.xn, 1, c.zs);
         const float* pp = (PREV && g.za) ? zplane<float>(g, a.x_in, a.xp, a.xn, 1, c.zs - 1) : nullptr;
@@ -295,6 +316,19 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             F4 N;
             if constexpr (PFN) N = Nn[t];
             else N = load_next ? ldu(pn + toff, voff) : zero;
+            F4 qcur[PFQ ? 4 : 1];
+            if (PFQ) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qcur[k] = qpre[k];
+                const int tn = (t + 1 < M) ? t + 1 : 0, zn = (t + 1 < M) ? z : z + 1;
+                if (c.ok && zn < c.ze) {
+                    const float* qbn = a.q + (long long)zn * g.s_dz + (long long)tn * g.s_t;
+                    for_each_channel<S>(g, [&](auto slot, int ch) {
+                        constexpr int k = decltype(slot)::value;
+                        qpre[k & 3] = ldu(qbn + (long long)ch * g.s_z, voff);
+                    });
+                }
+            }
             // ------------------------------------------------ neighbourhood of x(z, t)
             XN<float, 4> n;
             n.c = C[t];
@@ -352,7 +386,8 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             if (c.ok) {
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
-                    v[k] = ldu(qbase + (long long)ch * g.s_z, voff) + a.sigma * o[k];
+                    const F4 qv = PFQ ? qcur[k & 3] : ldu(qbase + (long long)ch * g.s_z, voff);
+                    v[k] = qv + a.sigma * o[k];
                     vs = vs + v[k] * v[k];
                 });
                 const F4 ds = sumsq_slots<float, 4>(o);
