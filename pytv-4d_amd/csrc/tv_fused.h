@@ -43,6 +43,9 @@ using F4 = Vec<float, 4>;
 #ifndef TV_FUSED_PFQ
 #define TV_FUSED_PFQ 1
 #endif
+#ifndef TV_FUSED_XE
+#define TV_FUSED_XE 0
+#endif
 constexpr int CP_NW = TV_FUSED_NW;
 constexpr int CP_TR = TV_FUSED_TR, CP_TL = 64 / CP_TR, CP_WC = 4 * CP_TL, CP_BC = CP_NW * CP_WC;
 constexpr int CP_LSH = (CP_TL == 16) ? 4 : 3;
@@ -218,11 +221,16 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
     // plane z only after both neighbours published plane z-1, so neighbouring waves stay within one plane of
     // each other (that is what makes two buffers enough) -- a pairwise hand-off, not a block-wide barrier.
     __shared__ volatile int edge_flag[CP_NW];
+    // XE (round 2, -DTV_FUSED_XE=1, OFF by default): the waves of a block also hand each other the first / last COLUMN of x
+    // of the plane they are about to work on (published together with the column terms of the plane just finished, same
+    // counters, double-buffered by plane parity) instead of loading those 4-byte elements.  Parity green, but no gain:
+    // hybrid 36.4 / 36.4 vs 35.9 / 37.4 ms, upwind 26.7 / 25.4 vs 23.7 / 25.8, central equal (profiles/r2_ab_xe.txt) --
+    // the edge loads are not what the sweep's ~14 GB of over-read consist of.
+    constexpr bool XE = XW && (TV_FUSED_XE != 0);
+    __shared__ float edge_xl[XE ? 2 : 1][XE ? M : 1][CP_NW][CP_TR];
+    __shared__ float edge_xr[XE ? 2 : 1][XE ? M : 1][CP_NW][CP_TR];
     const int wave = (int)threadIdx.y;
-    if (XW) {
-        if (c.lane == 0) edge_flag[wave] = 0;
-        __syncthreads();
-    }
+    if (XW && c.lane == 0) edge_flag[wave] = 0;
     const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
     F4 C[M], P[M];
     // PFQ (round 2, central): the four dual channels of the NEXT frame are requested at the top of the current one.  Central
@@ -253,8 +261,13 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             P[t] = (fok && pp != nullptr) ? ldu(pp + (long long)(t0 + t) * g.s_t, voff) : zero;
             lds_R[t][tid] = zero;
             lds_U[t][tid] = zero;
+            if (XE) {
+                if (c.lx == 0) edge_xl[0][t][wave][c.row] = C[t].v[0];
+                if (c.lx == CP_TL - 1) edge_xr[0][t][wave][c.row] = C[t].v[3];
+            }
         }
     }
+    if (XW) __syncthreads();      // counters zeroed, the first plane's x edges published
 
     // finalise plane zf (its x values are in `xv`), adjoint accumulator `racc` (un-scaled)
     auto finalize = [&](int zf, int t, const F4& xv, F4 racc) {
@@ -354,8 +367,15 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             {   // columns: adjacent lane inside the 16-lane row segment, one scalar at the segment edges
                 const bool le = PREV && (c.lx == 0) && c.ok && (c.col0 > 0);
                 const bool re = NEXT && (c.lx == CP_TL - 1) && c.ok && (c.col0 + 4 < g.nx);
+                // inside the block the neighbouring wave published these elements (XE); the block's own edges are loaded
+                const bool le_lds = XE && le && (wave > 0), re_lds = XE && re && (wave < CP_NW - 1);
                 float edge = 0.f;
-                if (le || re) edge = ldu1(pc + toff, le ? voff - 4u : voff + 16u);
+                if ((le && !le_lds) || (re && !re_lds)) edge = ldu1(pc + toff, le ? voff - 4u : voff + 16u);
+                if (XE) {
+                    const int xb = (z - c.zs) & 1;
+                    if (le_lds) edge = edge_xr[xb][t][wave - 1][c.row];
+                    if (re_lds) edge = edge_xl[xb][t][wave + 1][c.row];
+                }
                 if (NEXT) {
                     const float sh = __shfl_down(C[t].v[0], 1, 64);
                     n.nc = shift_left<float, 4>(C[t], (c.lx == CP_TL - 1) ? edge : sh);
@@ -470,6 +490,11 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             cold = C[t];
             P[t] = C[t];
             C[t] = N;
+            if (XE) {                 // x edges of the plane the block works on next
+                const int nb = (z + 1 - c.zs) & 1;
+                if (c.lx == 0) edge_xl[nb][t][wave][c.row] = N.v[0];
+                if (c.lx == CP_TL - 1) edge_xr[nb][t][wave][c.row] = N.v[3];
+            }
         }
         if (XW) {                     // publish: edge columns of plane z are visible before the counter moves
             __threadfence_block();
