@@ -92,3 +92,31 @@ def test_cabi_rccl_context_with_one_rank():
     p = subprocess.run([sys.executable, "-c", _CTX_SCRIPT % pkg], env=_env(29633), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     assert "TV_CTX_OK" in p.stdout
+
+
+def _bench_line(cmd, env):
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_sharded_over_ranks_gives_the_single_rank_loss(ranks):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with the TEST
+    transport (gloo, the ranks sharing cuda:0, host-staged halos): the N-rank job works on the SAME volume split in
+    z-slabs, so its loss history must equal the single-process one; rank 0 prints one line with n_gpus = N and the CPU
+    baseline.  What this cannot cover is RCCL with N > 1 (needs N GPUs)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TV_BENCH_BACKEND", "TV_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    common = ["--workload", "small", "--steps", "6", "--warmup", "2"]
+    one = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline"] + common, env)
+    env2 = dict(env, TV_BENCH_BACKEND="gloo", TV_BENCH_SHARE_GPU="1", TV_ZCHUNK="1")      # short chunks: interior-first schedule
+    many = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29640 + ranks), os.path.join(ROOT, "bench.py"),
+                        "--gpus", str(ranks)] + common, env2)
+    assert many["n_gpus"] == ranks and many["steps"] == 6 and many["scaling"] == "strong"
+    assert "cpu_baseline" in many and many["cpu_baseline"]["cores"] == 1
+    assert "roofline" in many and many["rccl_ranks"] == 0            # the test transport is not RCCL
+    a, b = one["loss_first_last"], many["loss_first_last"]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1])
