@@ -165,4 +165,173 @@ __global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<
     if (threadIdx.x == 0 && threadIdx.y == 0) a.part1[blockIdx.x] = acc1;
 }
 
+// =============================================================================================
+// central scheme: D^T D = 1/4 sum_a w_a^2 [ v(p-e) (x(p) - x(p-2e)) - v(p+e) (x(p+2e) - x(p)) ],  v(q) = 1 iff q is an
+// interior point of the axis -- a radius-1 stencil on the STRIDE-2 sub-lattice of every axis: even and odd planes (rows,
+// columns, frames) decouple.  So the block marches the even planes of its z-chunk, then the odd ones, with planes z-2, z,
+// z+2 in registers (3 M vectors, as for the other schemes); rows y+-2 are 32-lane shuffles inside the 4-row wave tile (two
+// halo rows on either side: ONE predicated load per lane, rows 0 / 1 upwards, rows 2 / 3 downwards), columns +-2 come from
+// the vector itself and two DPP moves per side (edge lanes: an 8-byte load), frames t+-2 are registers.
+// Two-point z / t axes (forward stencil) stay on the one-site kernel (the host does not launch this one then).
+// =============================================================================================
+__device__ __forceinline__ F4 shfl_up32(const F4& v) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_up(v.v[i], 32, 64);
+    return r;
+}
+__device__ __forceinline__ F4 shfl_down32(const F4& v) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_down(v.v[i], 32, 64);
+    return r;
+}
+struct F2 { float a, b; };
+__device__ __forceinline__ F2 ldu2(const float* ubase, unsigned voff) {
+    const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(ubase) + voff);
+    return F2{v.x, v.y};
+}
+
+template <int M, bool TWIN>
+__global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
+    __shared__ double sm[16];
+    const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
+    const int row = lane >> 4, lx = lane & 15;
+    const int nxv = g.nx / 4;
+    const int tiles_x = (nxv + 63) / 64, tiles_y = (g.ny + 3) / 4;
+    const int Mg = TWIN ? g.m : M;
+    const int nwin = TWIN ? (Mg + NS_TWN - 1) / NS_TWN : 1;
+    const long long ntiles = (long long)tiles_x * tiles_y, total = ntiles * nchunks * nwin, per_xcd = (total + 7) / 8;
+    const long long lid = (long long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (lid < total) {
+        const int win = (int)(lid / (ntiles * nchunks));
+        const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
+        const int t0 = TWIN ? win * NS_TWN : 0;
+        const int bx = tile % tiles_x, by = tile / tiles_x;
+        const int col0 = (bx * 64 + wave * 16 + lx) * 4, y = by * 4 + row;
+        const bool ok = (col0 < g.nx) && (y < g.ny);
+        const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * 4) : 0u;
+        const unsigned row_bytes = (unsigned)g.nx * 4u;
+        const int zs = chunk * zchunk;
+        const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
+        const F4 zero = vsplat<float, 4>(0.f);
+        F4 mf2 = vsplat<float, 4>(1.f);
+        if (g.ta) {
+            const F4 mf = mask_factor<float, 4>(g, w.sf, ok ? y : 0, ok ? col0 : 0);
+            mf2 = (w.wt * w.wt) * (mf * mf);
+        }
+        const float wz2 = g.za ? w.wz * w.wz : 0.f;
+        // a term exists iff the channel it comes from does: backward term <=> p_a >= 2, forward term <=> p_a <= n_a - 3
+        const float m_pr = (ok && y >= 2) ? 1.f : 0.f, m_nr = (ok && y + 2 < g.ny) ? 1.f : 0.f;
+        float m_cb[4], m_cf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m_cb[i] = (ok && col0 + i >= 2) ? 1.f : 0.f;
+            m_cf[i] = (ok && col0 + i + 2 < g.nx) ? 1.f : 0.f;
+        }
+        const bool want_up = (row <= 1) && ok && (y >= 2), want_dn = (row >= 2) && ok && (y + 2 < g.ny);
+        const unsigned hoff = want_up ? voff - 2u * row_bytes : voff + 2u * row_bytes;
+        const bool want_le = (lx == 0) && ok && (col0 >= 2), want_re = (lx == 15) && ok && (col0 + 4 < g.nx);
+        const unsigned eoff = want_le ? voff - 8u : voff + 16u;
+        auto fvalid = [&](int t) { return !TWIN || (t0 + t < Mg); };
+        auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };
+        auto plane = [&](int zl) { return g.za ? zplane<float>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
+        auto load_c = [&](const float* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu(pl + foff(t), voff) : zero; };
+        F4 C[M], P[M], N[M], H[M];
+        F2 E[M];
+        for (int par = 0; par < 2; ++par) {
+            const int zfirst = zs + par;
+            if (zfirst >= ze) break;
+            {
+                const float* pp = g.za ? plane(zfirst - 2) : nullptr;
+                const float* pc = plane(zfirst);
+                const float* pn = (g.za || zfirst + 2 < ze) ? plane(zfirst + 2) : nullptr;
+#pragma unroll
+                for (int t = 0; t < M; ++t) {
+                    P[t] = load_c(pp, t);
+                    C[t] = load_c(pc, t);
+                    N[t] = load_c(pn, t);
+                    H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu(pc + foff(t), hoff) : zero;
+                    E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu2(pc + foff(t), eoff) : F2{0.f, 0.f};
+                }
+            }
+            for (int z = zfirst; z < ze; z += 2) {
+                const int gz = g.z0 + z;
+                const float m_pz = (g.za && gz >= 2) ? wz2 : 0.f, m_nz = (g.za && gz + 2 < g.nzg) ? wz2 : 0.f;
+                const float* pc = plane(z);
+                const float* pc1 = (z + 2 < ze) ? plane(z + 2) : nullptr;
+                const float* pn2 = (z + 2 < ze && (g.za || z + 4 < ze)) ? plane(z + 4) : nullptr;
+                F4 cold1 = zero, cold2 = zero;         // x(z, t-1), x(z, t-2)
+                if (TWIN && g.ta && ok) {
+                    if (t0 >= 1) cold1 = ldu(pc + foff(-1), voff);
+                    if (t0 >= 2) cold2 = ldu(pc + foff(-2), voff);
+                }
+#pragma unroll
+                for (int t = 0; t < M; ++t) {
+                    if (TWIN && !fvalid(t)) break;
+                    const int tg = t0 + t;
+                    const F4 c = C[t], h = H[t];
+                    // rows y-2 / y+2: rows 2, 3 take y-2 from rows 0, 1 of the tile (32 lanes up), rows 0, 1 from the halo load
+                    const F4 sup = shfl_up32(c), sdn = shfl_down32(c);
+                    const F4 pr = (row <= 1) ? h : sup, nr = (row >= 2) ? h : sdn;
+                    F4 r = m_pr * (c - pr) - m_nr * (nr - c);
+                    {
+                        const float l2 = dpp_from_left(c.v[2]), l3 = dpp_from_left(c.v[3]);       // executed by every lane
+                        const float r0 = dpp_from_right(c.v[0]), r1 = dpp_from_right(c.v[1]);
+                        const float lm2 = (lx == 0) ? E[t].a : l2, lm1 = (lx == 0) ? E[t].b : l3;   // x(col0-2), x(col0-1)
+                        const float rp4 = (lx == 15) ? E[t].a : r0, rp5 = (lx == 15) ? E[t].b : r1; // x(col0+4), x(col0+5)
+                        r.v[0] += m_cb[0] * (c.v[0] - lm2) - m_cf[0] * (c.v[2] - c.v[0]);
+                        r.v[1] += m_cb[1] * (c.v[1] - lm1) - m_cf[1] * (c.v[3] - c.v[1]);
+                        r.v[2] += m_cb[2] * (c.v[2] - c.v[0]) - m_cf[2] * (rp4 - c.v[2]);
+                        r.v[3] += m_cb[3] * (c.v[3] - c.v[1]) - m_cf[3] * (rp5 - c.v[3]);
+                    }
+                    r = r + (m_pz * (c - P[t]) - m_nz * (N[t] - c));
+                    if (g.ta) {
+                        F4 tt = zero;
+                        if (tg >= 2) tt = tt + (c - cold2);
+                        if (tg + 2 < Mg) {
+                            if (t + 2 < M) tt = tt - (C[(t + 2 < M) ? t + 2 : t] - c);
+                            else if (TWIN) tt = tt - ((ok ? ldu(pc + foff(t + 2), voff) : zero) - c);
+                        }
+                        r = r + mf2 * tt;
+                    }
+                    cold2 = cold1;
+                    cold1 = c;
+                    P[t] = c;
+                    C[t] = N[t];
+                    N[t] = load_c(pn2, t);
+                    H[t] = (pc1 != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu(pc1 + foff(t), hoff) : zero;
+                    E[t] = (pc1 != nullptr && (want_le || want_re) && fvalid(t)) ? ldu2(pc1 + foff(t), eoff) : F2{0.f, 0.f};
+                    if (!ok) continue;
+                    const long long fo = (long long)z * g.s_z + foff(t);
+                    F4 o;
+                    if (a.b == nullptr) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            o.v[i] = c.v[i] + a.rho * (0.25f * r.v[i]);
+                            acc0 += (double)c.v[i] * (double)o.v[i];
+                            acc1 += (double)c.v[i] * (double)c.v[i];
+                        }
+                    } else {
+                        const F4 bv = ldu(a.b + fo, voff);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            o.v[i] = bv.v[i] - (c.v[i] + a.rho * (0.25f * r.v[i]));
+                            acc0 += (double)o.v[i] * (double)o.v[i];
+                            acc1 += (double)c.v[i] * (double)c.v[i];
+                        }
+                        if (a.out2 != nullptr) stu(a.out2 + fo, voff, o);
+                    }
+                    stu(a.out + fo, voff, o);
+                }
+            }
+        }
+    }
+    acc0 = block_sum(acc0, sm);
+    if (threadIdx.x == 0 && threadIdx.y == 0) a.part0[blockIdx.x] = acc0;
+    acc1 = block_sum(acc1, sm);
+    if (threadIdx.x == 0 && threadIdx.y == 0) a.part1[blockIdx.x] = acc1;
+}
+
 }  // namespace tv

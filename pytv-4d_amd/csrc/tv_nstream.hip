@@ -6,7 +6,8 @@
 namespace tvm {
 
 bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
-    if (g->dtype != TV_F32 || !vec || d.nx < 64 || g->scheme == TV_CENTRAL || d.wv != nullptr) return false;
+    if (g->dtype != TV_F32 || !vec || d.nx < 64 || d.wv != nullptr) return false;
+    if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return false;   // two-point axes: forward stencil
     if ((long long)d.ny * d.nx > (1ll << 30)) return false;           // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_MARCH", 0) || env_int("TV_NO_MARCH_NORMAL", 0)) return false;
     // small planes: the z / t neighbours of the one-site kernel stay in L2 (same threshold as the other streaming kernels)
@@ -32,7 +33,11 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
     if (*nblocks > max_partials(d)) return fail(TV_E_ARG, "internal: normal-operator partials exceed the workspace");
     const WT<float> w = make_w<float>(g);
     NormalArgs a{(const float*)x, (const float*)xp, (const float*)xn, (const float*)b, out, out2, rho, part0, part1};
-#define TV_NS_LAUNCH(MM, TW) hipLaunchKernelGGL((k_normal_stream<MM, TW>), grid, block, 0, st, d, w, a, zc, (int)nch)
+#define TV_NS_LAUNCH(MM, TW)                                                                                            \
+    do {                                                                                                               \
+        if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW>), grid, block, 0, st, d, w, a, zc, (int)nch); \
+        else hipLaunchKernelGGL((k_normal_stream<MM, TW>), grid, block, 0, st, d, w, a, zc, (int)nch);                  \
+    } while (0)
     switch (d.m > NS_TWN ? 0 : d.m) {
         case 0: TV_NS_LAUNCH(NS_TWN, true); break;
         case 1: TV_NS_LAUNCH(1, false); break;
