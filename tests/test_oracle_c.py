@@ -77,4 +77,5 @@ def test_c_oracle_numa_variant_is_the_same_iteration():
     kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
     ax, aloss = occ.chambolle_pock(x0, 7, 5.0, scheme="hybrid", **kw)
     bx, bloss, secs = occ.chambolle_pock(x0, 7, 5.0, scheme="hybrid", numa=True, **kw)
-    assert np.array_equal(ax, bx) and np.array_equal(aloss, bloss) and secs > 0
+    assert np.array_equal(ax, bx) and secs > 0
+    np.testing.assert_allclose(bloss, aloss, rtol=1e-12)          # OpenMP reductions: the summation order is not fixed
