@@ -161,7 +161,7 @@ def test_admm_tu_is_admm_zu_with_t_equal_z_minus_u(nvlib, scheme, shape, dtype):
     tv2 = torch.zeros(1, dtype=torch.float64, device="cuda")
     nv.check(lib.tv_admm_tu(g.ref, nv.ptr(x), None, None, nv.ptr(t), nv.ptr(u2), 3.0, tv2.data_ptr(), nv.ptr(ws), st))
     assert torch.equal(u, u2) and tv1.item() == tv2.item()
-    assert torch.equal(t, z - u)
+    assert torch.allclose(t, z - u, rtol=1e-6, atol=1e-6)        # z - (v - z): the compiler may contract it differently
     v = orc.D(x.double().cpu().numpy(), scheme, **kw) + u0.double().cpu().numpy()
     wz = orc.group_soft_threshold(v, 3.0)
     tol = dict(rtol=1e-5, atol=1e-4) if dtype == np.float32 else dict(rtol=1e-11, atol=1e-10)
