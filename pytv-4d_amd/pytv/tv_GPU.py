@@ -15,7 +15,7 @@ grad_norms has zeros replaced by +inf; the sub-gradient uses unit weights in the
 import torch
 
 from . import _native as _nv
-from .tv_operators_GPU import _to_device
+from .tv_operators_GPU import _to_device, _to_host
 
 __all__ = ["tv_hybrid", "tv_downwind", "tv_upwind", "tv_central"]
 
@@ -71,10 +71,10 @@ def _tv(scheme, img, mask, reg_z_over_reg, reg_time, mask_static, factor_reg_sta
                                       want_norms=bool(return_grad_norms))
     tv = tv.detach().cpu().numpy()          # 0-d numpy, always (tv_GPU.py:85 via compute_L21_norm)
     if not return_grad_norms:
-        return (tv, G) if return_pytorch_tensor else (tv, G.detach().cpu().numpy())
+        return (tv, G) if return_pytorch_tensor else (tv, _to_host(G))
     if return_pytorch_tensor:
         return tv, G, gn
-    return tv, G.detach().cpu().numpy(), gn.detach().cpu().numpy()
+    return tv, _to_host(G), _to_host(gn)
 
 
 def tv_hybrid(img, mask=[], reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0,
