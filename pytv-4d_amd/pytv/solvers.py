@@ -330,12 +330,15 @@ class ChambollePockOperator(_SlabProblem):
 
     ``A`` and ``AT`` are callables taking and returning DEVICE tensors (``A``: image (Nz, M, Ny, Nx) -> data of any
     shape, ``AT``: data -> image); they stay the user's code, the TV part runs in the HIP kernels.  ``tau`` must
-    satisfy tau (sigma_A |A|^2 + sigma_D |D|^2) <= 1; the default assumes |A| <= 1.  Single GPU.
-    """
+    satisfy tau (sigma_A |A|^2 + sigma_D |D|^2) <= 1; the default assumes |A| <= 1.
+
+    With a ``slab`` (one process per GPU) ``x_init`` / ``b`` are this rank's z-slab of the image and its share of the data,
+    ``A`` / ``AT`` act on the slab (operators that couple the slabs -- a cone-beam projector, say -- do their own
+    communication inside the callables); the TV part trades the image / gradient halo planes like ``ChambollePock``."""
 
     def __init__(self, A, AT, b, x_init, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None):
-        super().__init__(x_init, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, None)
+                 mask_static=False, factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None):
+        super().__init__(x_init, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.A, self.AT = A, AT
         self.b = b
         self.reg = float(regularization)
@@ -347,17 +350,28 @@ class ChambollePockOperator(_SlabProblem):
         self.q = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
         self.ws = self.geo.workspace()
         self.x_new = torch.empty_like(self.x)
+        self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
+        pl = self.plan
+        self.xh_prev = self.new_plane() if pl.x_need_prev else None
+        self.xh_next = self.new_plane() if pl.x_need_next else None
+        self.qh_prev = self.new_plane() if pl.g_need_prev else None
+        self.qh_next = self.new_plane() if pl.g_need_next else None
 
     def step(self, out):
-        """out: fp64 device tensor [tv, fid] (fid = 1/2 |A x_new - b|^2)."""
-        g = self.geo
+        """out: fp64 device tensor [tv, fid] (fid = 1/2 |A x_new - b|^2) of this rank."""
+        g, s = self.geo, self.slab
+        h = self.plan.exchange_image(self.x, self.xh_prev, self.xh_next)      # in flight while the user's operator runs
         r = self.A(self.x) - self.b
         self.p = (self.p + self.sigma_A * r) / (1.0 + self.sigma_A)
-        _nv.check(self.lib.tv_cp_dual(g.ref, _nv.ptr(self.x), None, None, _nv.ptr(self.q), self.sigma_D, self.reg,
-                                      out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        s.wait(h)
+        _nv.check(self.lib.tv_cp_dual(g.ref, _nv.ptr(self.x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.q),
+                                      self.sigma_D, self.reg, out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        h = self.plan.exchange_grad(self.q, self.qh_prev[0] if self.qh_prev is not None else None,
+                                    self.qh_next[0] if self.qh_next is not None else None)
         base = (self.x - self.tau * self.AT(self.p)).contiguous()
-        _nv.check(self.lib.tv_DT_axpy(g.ref, _nv.ptr(self.q), None, None, None, _nv.ptr(base), -self.tau, _nv.ptr(self.x_new),
-                                      self.stream))
+        s.wait(h)
+        _nv.check(self.lib.tv_DT_axpy(g.ref, _nv.ptr(self.q), None, _nv.ptr(self.qh_prev), _nv.ptr(self.qh_next), _nv.ptr(base),
+                                      -self.tau, _nv.ptr(self.x_new), self.stream))
         self.x, self.x_new = self.x_new, self.x
         res = self.A(self.x) - self.b
         out[1:2] = 0.5 * torch.sum(res.double() ** 2)
@@ -366,6 +380,7 @@ class ChambollePockOperator(_SlabProblem):
         hist = torch.zeros((n_iter, 2), dtype=torch.float64, device=self.device)
         for it in range(n_iter):
             self.step(hist[it])
+        self.slab.allreduce_sum_(hist)
         h = hist.cpu().numpy()
         return h[:, 1] + self.reg * h[:, 0]
 

@@ -62,6 +62,13 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
             ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, **kw)
             out["ad_loss"] = ad.run(3)
             out["ad_x"] = ad.result().cpu().numpy()
+        # data-fidelity operator slot on a slab: a diagonal operator (local to the slab), TV part with halos
+        a_full = 0.2 + 0.8 * np.random.default_rng(92).random(shape)
+        at = torch.as_tensor(slab.local(a_full).astype(np.float32).copy()).cuda()
+        bt = at * x0 + 0.5
+        op = pytv.solvers.ChambollePockOperator(lambda v: at * v, lambda v: at * v, bt, x0, 7.0, scheme=scheme, slab=slab, **kw)
+        out["op_loss"] = op.run(6)
+        out["op_x"] = op.result().cpu().numpy()
         out["z"] = (slab.z0, slab.nz)
         ret[rank] = out
     finally:
@@ -96,6 +103,24 @@ def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, z
             assert all(ret[r]["cp2_overlap"] for r in range(world))     # interior-first one-sweep path exercised
     if overlap:
         assert any(ret[r]["cp_overlap"] for r in range(world))
+    # operator-slot solver against the same iteration written with the oracle's D / D^T
+    a = 0.2 + 0.8 * np.random.default_rng(92).random(shape)
+    a = a.astype(np.float32).astype(np.float64)
+    b = a * x0 + 0.5
+    tau = orc.cp_step_size(scheme, shape[0], shape[1], kw["reg_z_over_reg"], kw["reg_time"])
+    x, p, q = x0.copy(), np.zeros(shape), np.zeros_like(orc.D(x0, scheme, **kw))
+    want = []
+    for _ in range(6):
+        p = (p + 1.0 * (a * x - b)) / 2.0
+        Dx = orc.D(x, scheme, **kw)
+        v = q + 0.5 * Dx
+        q = v / np.maximum(1.0, np.sqrt(np.sum(v ** 2, axis=1, keepdims=True)) / 7.0)
+        x = x - tau * (a * p) - tau * orc.D_T(q, scheme, **kw)
+        want.append(0.5 * np.sum((a * x - b) ** 2) + 7.0 * orc.compute_L21_norm(Dx))
+    for r in range(world):
+        z0, nz = ret[r]["z"]
+        np.testing.assert_allclose(ret[r]["op_loss"], want, rtol=2e-5, err_msg="operator slot, rank %d" % r)
+        np.testing.assert_allclose(ret[r]["op_x"], x[z0:z0 + nz], rtol=1e-4, atol=2e-3)
     if "sg_loss" in ret[0]:
         sx, sloss = orc.subgradient_descent(x0, 5, 7.0, 2e-3, scheme=scheme, **kw)
         ax, aloss = orc.admm(x0, 3, 7.0, 0.1, 3, scheme=scheme, single_reduction=True, **kw)
