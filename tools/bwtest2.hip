@@ -124,6 +124,32 @@ __global__ __launch_bounds__(256, 2) void k_march(const float* __restrict__ x, f
     }
 }
 
+
+// ---- does the TILE SHAPE matter?  wave tile = ROWS rows x (64 / ROWS) lanes, WAVES waves side by side per block; same traffic
+// as k_march<8, 8, 0> (1 + NC read, NC written per (z, t))
+template <int M, int NC, int ROWS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, (WAVES >= 8) ? 2 : 2) void k_march_tile(const float* __restrict__ x, float* __restrict__ q, int nz, int ny, int nx, int zchunk) {
+    constexpr int TL = 64 / ROWS;
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const int row = lane / TL, lx = lane % TL;
+    const int tiles_x = nx / (WAVES * TL * 4);
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const long long inpl = (long long)(by * ROWS + row) * nx + (bx * WAVES * TL + wave * TL + lx) * 4;
+    const long long s_t = (long long)ny * nx, s_z = s_t * M, s_dz = s_z * NC;
+    const int zs = blockIdx.y * zchunk, ze = min(zs + zchunk, nz);
+    for (int z = zs; z < ze; ++z) {
+#pragma unroll
+        for (int t = 0; t < M; ++t) {
+            const float4_ xv = *(const float4_*)(x + (long long)z * s_z + t * s_t + inpl);
+            float4_ v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = *(const float4_*)(q + (long long)z * s_dz + c * s_z + t * s_t + inpl);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) *(float4_*)(q + (long long)z * s_dz + c * s_z + t * s_t + inpl) = v[c] * 1.0001f + xv;
+        }
+    }
+}
+
 // ---- read-dominated (tv_DT): NC channel vectors read, one image vector written; LATE: the store is issued after the next
 // frame's loads
 template <int M, int NC, bool LATE>
@@ -226,6 +252,13 @@ int main(int argc, char** argv) {
         printf("dstore 1 read 4 write,   zchunk %2d                      : %7.2f ms  %5.0f GB/s\n", zc, ms, 5.0 * 4 * V / ms / 1e6);
         ms = timeit([&] { hipLaunchKernelGGL((k_dstore<8, 1, false>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); });
         printf("dstore 1 read 1 write,   zchunk %2d                      : %7.2f ms  %5.0f GB/s\n", zc, ms, 2.0 * 4 * V / ms / 1e6);
+    }
+        {
+        const int zc = 32;
+#define TILE(R, W) { dim3 grid((nx / (W * (64 / R) * 4)) * (ny / R), (nz + zc - 1) / zc), blk(64, W); \
+        ms = timeit([&] { hipLaunchKernelGGL((k_march_tile<8, 8, R, W>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); }); \
+        printf("march 1+8 read 8 write, wave tile %2d rows x %2d lanes, %d waves/block (block tile %2d x %4d cols): %7.2f ms  %5.0f GB/s\n", R, 64 / R, W, R, W * (64 / R) * 4, ms, b_rw / ms / 1e6); }
+        TILE(4, 4) TILE(8, 4) TILE(8, 8) TILE(4, 8) TILE(16, 8) TILE(16, 16) TILE(2, 4) TILE(1, 4) TILE(8, 16)
     }
     return 0;
 }
