@@ -240,7 +240,7 @@ def main():
                                    "launch stream (includes the tiny partial-sum kernels)" + sharded}
         out["roofline_fixup"] = {"kernel": "tv_cp_fixup: k_cp_fixup<S> (tile-edge rows/cols, chunk-edge planes)", "ms_per_launch": 1e3 * t_k2,
                                  "traffic": traffic.get("fixup"),
-                                 "note": "adds the adjoint terms that cross wave-tile rows, block-tile columns, z-chunks and slabs (about half of the rows: ~2.5 words/voxel)"}
+                                 "note": "adds the adjoint terms that cross wave-tile rows, block-tile columns, z-chunks and slabs (2 of every 8 rows since round 2: ~1.65 words/voxel moved; round 1: 2 of 4, ~2.5)"}
     else:
         b_dual = 4.0 * (1 + 2 * nd) * V_local
         b_primal = 4.0 * (nd + 5) * V_local
