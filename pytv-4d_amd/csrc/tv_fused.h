@@ -46,6 +46,9 @@ using F4 = Vec<float, 4>;
 #ifndef TV_FUSED_XE
 #define TV_FUSED_XE 0
 #endif
+#ifndef TV_FUSED_EA
+#define TV_FUSED_EA 1
+#endif
 constexpr int CP_NW = TV_FUSED_NW;
 constexpr int CP_TR = TV_FUSED_TR, CP_TL = 64 / CP_TR, CP_WC = 4 * CP_TL, CP_BC = CP_NW * CP_WC;
 constexpr int CP_LSH = (CP_TL == 16) ? 4 : 3;
@@ -233,6 +236,16 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
     if (XW && c.lane == 0) edge_flag[wave] = 0;
     const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
     F4 C[M], P[M];
+    // EA (round 2): the 4-byte column neighbours across the wave-tile border (first / last lane of a row segment) are requested
+    // ONE PLANE AHEAD, in the same frame as the wide load of that plane -- i.e. while the neighbouring wave fetches the very
+    // line they live in.  Requested a plane later (as before) the line had left the L2 again (a CU streams ~0.7 MB per plane
+    // through its 128 KiB share) and two thirds of these loads went to the fabric as their own requests: 9.8 GB per sweep of
+    // the north-star volume on the read counter (tools/pmc_calib.sh shows the same +14 % on a kernel with exactly known bytes).
+    constexpr bool EA = (TV_FUSED_EA != 0) && !(XW && (TV_FUSED_XE != 0));
+    const bool e_le = PREV && (c.lx == 0) && c.ok && (c.col0 > 0);
+    const bool e_re = NEXT && (c.lx == CP_TL - 1) && c.ok && (c.col0 + 4 < g.nx);
+    const unsigned eoff = e_le ? voff - 4u : voff + 16u;
+    float E[EA ? M : 1];
     // PFQ (round 2, central): the four dual channels of the NEXT frame are requested at the top of the current one.  Central
     // has 1 + 4 streams per frame (hybrid: 1 + 8) but hybrid's per-site arithmetic (every channel plays both adjoint roles),
     // so its waves waited ~77 % of the time with too few bytes in flight: sweep 26.6 - 27.4 -> 21.2 - 23.0 ms on the
@@ -259,6 +272,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             const bool fok = c.ok && (t0 + t < Mg);
             C[t] = fok ? ldu(pc + (long long)(t0 + t) * g.s_t, voff) : zero;
             P[t] = (fok && pp != nullptr) ? ldu(pp + (long long)(t0 + t) * g.s_t, voff) : zero;
+            if (EA) E[t] = (fok && (e_le || e_re)) ? ldu1(pc + (long long)(t0 + t) * g.s_t, eoff) : 0.f;
             lds_R[t][tid] = zero;
             lds_U[t][tid] = zero;
             if (XE) {
@@ -318,6 +332,12 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
 #pragma unroll
             for (int t = 0; t < M; ++t) Nn[t] = (load_next && t0 + t < Mg) ? ldu(pn + (long long)(t0 + t) * g.s_t, voff) : zero;
         }
+        float En[(PFN && EA) ? M : 1];      // the border elements of plane z+1 travel with its wide loads
+        if (PFN && EA) {
+#pragma unroll
+            for (int t = 0; t < M; ++t)
+                En[t] = (load_next && (e_le || e_re) && t0 + t < Mg) ? ldu1(pn + (long long)(t0 + t) * g.s_t, eoff) : 0.f;
+        }
         F4 cold = zero;        // x(z, t-1)
         F4 ut_prev = zero;     // wt * q'_tup(z, t-1) * mf, already valid-masked
         F4 r_prev = zero;      // accumulator of frame t-1 of THIS plane, still missing its time-down term
@@ -329,6 +349,12 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             F4 N;
             if constexpr (PFN) N = Nn[t];
             else N = load_next ? ldu(pn + toff, voff) : zero;
+            float e_cur = 0.f;
+            if (EA) {
+                e_cur = E[t];
+                if constexpr (PFN) E[t] = En[t];
+                else E[t] = (load_next && (e_le || e_re)) ? ldu1(pn + toff, eoff) : 0.f;
+            }
             F4 qcur[PFQ ? 4 : 1];
             if (PFQ) {
 #pragma unroll
@@ -370,7 +396,8 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
                 // inside the block the neighbouring wave published these elements (XE); the block's own edges are loaded
                 const bool le_lds = XE && le && (wave > 0), re_lds = XE && re && (wave < CP_NW - 1);
                 float edge = 0.f;
-                if ((le && !le_lds) || (re && !re_lds)) edge = ldu1(pc + toff, le ? voff - 4u : voff + 16u);
+                if (EA) edge = e_cur;
+                else if ((le && !le_lds) || (re && !re_lds)) edge = ldu1(pc + toff, le ? voff - 4u : voff + 16u);
                 if (XE) {
                     const int xb = (z - c.zs) & 1;
                     if (le_lds) edge = edge_xr[xb][t][wave - 1][c.row];

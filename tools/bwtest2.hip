@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256, 2) void k_march(const float* __restrict__ x, f
 
 // ---- does the TILE SHAPE matter?  wave tile = ROWS rows x (64 / ROWS) lanes, WAVES waves side by side per block; same traffic
 // as k_march<8, 8, 0> (1 + NC read, NC written per (z, t))
-template <int M, int NC, int ROWS, int WAVES>
+// EDGE: the first / last lane of a row segment also loads the 4-byte element on the other side of the segment border (what the
+// TV kernels do for their column neighbours) -- same exact byte count, used to calibrate FETCH_SIZE for narrow requests
+template <int M, int NC, int ROWS, int WAVES, int EDGE = 0>
 __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8) ? 2 : 2) void k_march_tile(const float* __restrict__ x, float* __restrict__ q, int nz, int ny, int nx, int zchunk) {
     constexpr int TL = 64 / ROWS;
     const int lane = threadIdx.x, wave = threadIdx.y;
@@ -140,7 +142,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES >= 8) ? 2 : 2) void k_march_tile
     for (int z = zs; z < ze; ++z) {
 #pragma unroll
         for (int t = 0; t < M; ++t) {
-            const float4_ xv = *(const float4_*)(x + (long long)z * s_z + t * s_t + inpl);
+            float4_ xv = *(const float4_*)(x + (long long)z * s_z + t * s_t + inpl);
+            if (EDGE) {
+                const int col = (bx * WAVES * TL + wave * TL + lx) * 4;
+                const bool le = (lx == 0) && col > 0, re = (lx == TL - 1) && col + 4 < nx;
+                if (le || re) xv.x += x[(long long)z * s_z + t * s_t + inpl + (le ? -1 : 4)];
+            }
             float4_ v[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) v[c] = *(const float4_*)(q + (long long)z * s_dz + c * s_z + t * s_t + inpl);
@@ -258,6 +265,10 @@ int main(int argc, char** argv) {
 #define TILE(R, W) { dim3 grid((nx / (W * (64 / R) * 4)) * (ny / R), (nz + zc - 1) / zc), blk(64, W); \
         ms = timeit([&] { hipLaunchKernelGGL((k_march_tile<8, 8, R, W>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); }); \
         printf("march 1+8 read 8 write, wave tile %2d rows x %2d lanes, %d waves/block (block tile %2d x %4d cols): %7.2f ms  %5.0f GB/s\n", R, 64 / R, W, R, W * (64 / R) * 4, ms, b_rw / ms / 1e6); }
+#define TILE_E(R, W) { dim3 grid((nx / (W * (64 / R) * 4)) * (ny / R), (nz + zc - 1) / zc), blk(64, W); \
+        ms = timeit([&] { hipLaunchKernelGGL((k_march_tile<8, 8, R, W, 1>), grid, blk, 0, 0, x, q, nz, ny, nx, zc); }); \
+        printf("the same + 4-byte edge loads, wave tile %2d rows x %2d lanes, %d waves/block: %7.2f ms  %5.0f GB/s\n", R, 64 / R, W, ms, b_rw / ms / 1e6); }
+        TILE_E(8, 8) TILE_E(4, 4)
         TILE(4, 4) TILE(8, 4) TILE(8, 8) TILE(4, 8) TILE(16, 8) TILE(16, 16) TILE(2, 4) TILE(1, 4) TILE(8, 16)
     }
     return 0;
