@@ -32,11 +32,32 @@ __device__ __forceinline__ float dpp_from_right(float v) {     // lane+1 inside 
 
 constexpr int DS_TWN = 8;      // frames per time window (M > 8)
 
+// Block composition of the streaming kernels (k_D_stream, k_normal_stream*): ST_NWX waves side by side times ST_NWY waves
+// stacked, each a 4-row x 16-lane wave tile -> block tile 4 ST_NWY rows x 256 ST_NWX bytes.  Waves of one block request
+// their halo rows / border elements in the same frame as the owner of those lines requests them, so inside a block they
+// cost no extra fetch; only the block's outline does: 2 rows per 4 ST_NWY, 2 x 64 B per 256 ST_NWX bytes of row.
+#ifndef TV_STREAM_NWX
+#define TV_STREAM_NWX 4
+#endif
+#ifndef TV_STREAM_NWY
+#define TV_STREAM_NWY 1
+#endif
+// TV_STREAM_SYNC: 1 = the waves of a block meet at a bare s_barrier (no fence, no vmcnt drain) at the top of every plane,
+// 2 = of every frame -- keeps them close enough in time for the shared lines to still be in L2 when the second wave asks
+#ifndef TV_STREAM_SYNC
+#define TV_STREAM_SYNC 2
+#endif
+__device__ __forceinline__ void st_sync_plane() { if (TV_STREAM_SYNC == 1) __builtin_amdgcn_s_barrier(); }
+__device__ __forceinline__ void st_sync_frame() { if (TV_STREAM_SYNC >= 2) __builtin_amdgcn_s_barrier(); }
+constexpr int ST_NWX = TV_STREAM_NWX, ST_NWY = TV_STREAM_NWY, ST_THREADS = 64 * ST_NWX * ST_NWY;
+constexpr int ST_BCV = 16 * ST_NWX;      // 4-column vectors per block-tile row
+constexpr int ST_BR = 4 * ST_NWY;        // rows per block tile
+
 // block (64, 4): wave w covers columns [64 w, 64 w + 64) of a 4-row x 256-column block tile; grid.x = XCD-ordered
 // (tile, chunk, window) ids.  TWIN: the block works on frames [t0, t0 + M) of a volume with more than 8 frames and reads
 // the x frame on either side of its window for the time differences (M == DS_TWN).
 template <int S, int M, bool TWIN>
-__global__ __launch_bounds__(256, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 : 3) void k_D_stream(DG g, WT<float> w, const float* __restrict__ x,
+__global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 : 3) void k_D_stream(DG g, WT<float> w, const float* __restrict__ x,
                                                                        const float* __restrict__ xp, const float* __restrict__ xn,
                                                                        float* __restrict__ d, int zchunk, int nchunks) {
     constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID), CEN = (S == CENTRAL);
@@ -44,7 +65,7 @@ __global__ __launch_bounds__(256, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
     const int nxv = g.nx / 4;
-    const int tiles_x = (nxv + 63) / 64, tiles_y = (g.ny + 3) / 4;
+    const int tiles_x = (nxv + ST_BCV - 1) / ST_BCV, tiles_y = (g.ny + ST_BR - 1) / ST_BR;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + DS_TWN - 1) / DS_TWN : 1;
     // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs; give every XCD a contiguous run of
@@ -56,7 +77,7 @@ __global__ __launch_bounds__(256, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 
     const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
     const int t0 = TWIN ? win * DS_TWN : 0;
     const int bx = tile % tiles_x, by = tile / tiles_x;
-    const int col0 = (bx * 64 + wave * 16 + lx) * 4, y = by * 4 + row;
+    const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * 4, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
     const bool ok = (col0 < g.nx) && (y < g.ny);
     const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * 4) : 0u;      // byte offset inside a frame
     const unsigned row_bytes = (unsigned)g.nx * 4u;
@@ -100,6 +121,7 @@ __global__ __launch_bounds__(256, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 
     const bool trail = g.za && (UP || CEN);
     const int z_last = trail ? ze : ze - 1;
     for (int z = zs; z <= z_last; ++z) {
+        st_sync_plane();
         const int gz = g.z0 + z;
         const bool in_chunk = (z < ze);
         const bool plane_here = (gz < g.nzg);                                 // plane z exists in the volume
@@ -117,6 +139,7 @@ __global__ __launch_bounds__(256, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             if (TWIN && !fvalid(t)) break;                                    // ragged last window (block-uniform)
+            st_sync_frame();
             const int tg = t0 + t;
             const F4 c = C[t];
             // ---- z differences of this step ---------------------------------------------------------------------

@@ -12,7 +12,7 @@ bool D_stream_ok(const tv_geom* g, const DG& d, bool vec) {
 }
 
 int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, float* dout) {
-    const long long tx = (d.nx / 4 + 63) / 64, ty = (d.ny + 3) / 4;
+    const long long tx = (d.nx / 4 + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
     // planes per z-chunk: a chunk re-reads one plane (its trailing step), so chunks are long; >= ~4096 blocks in flight
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
@@ -25,7 +25,7 @@ int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
     const long long nch = (d.nz + zc - 1) / zc;
     const long long nwin = (d.m > DS_TWN) ? (d.m + DS_TWN - 1) / DS_TWN : 1;
     const long long nb = tx * ty * nch * nwin, per_xcd = (nb + 7) / 8;
-    const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, 4, 1);
+    const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, ST_NWX * ST_NWY, 1);
     const WT<float> w = make_w<float>(g);
 #define TV_DS_LAUNCH(SC, MM, TW)                                                                                              \
     hipLaunchKernelGGL((k_D_stream<SC, MM, TW>), grid, block, 0, st, d, w, (const float*)x, (const float*)xp, (const float*)xn, \

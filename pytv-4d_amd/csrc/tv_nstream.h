@@ -31,13 +31,41 @@ struct NormalArgs {
 
 constexpr int NS_TWN = 8;
 
+// The shared z term is added to one plane at one step and subtracted from its neighbour at the next, possibly by a different
+// block (chunk seam) or another rank (slab seam): these three operations must round the same way wherever they are compiled
+// (slab == unsharded bit for bit, tests/test_gpu_parity.py).  Left to the compiler they do not: it fuses m * (a - b) + r into an
+// fma in some specialisations of the plane loop (first step of a chunk, trailing step) and not in others, and the __fmul_rn /
+// __fadd_rn intrinsics do not prevent that (plain * and + from the force-included HIP headers, contraction allowed).  So the
+// three operations are single VALU instructions the compiler cannot look into.
+__device__ __forceinline__ float ns_vmul(float a, float b) { float r; asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float ns_vadd(float a, float b) { float r; asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float ns_vsub(float a, float b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ F4 ns_mul(float m, const F4& a, const F4& b) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = ns_vmul(m, ns_vsub(a.v[i], b.v[i]));
+    return r;
+}
+__device__ __forceinline__ F4 ns_add(const F4& a, const F4& b) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = ns_vadd(a.v[i], b.v[i]);
+    return r;
+}
+__device__ __forceinline__ F4 ns_sub(const F4& a, const F4& b) {
+    F4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = ns_vsub(a.v[i], b.v[i]);
+    return r;
+}
+
 template <int M, bool TWIN>
-__global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
+__global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
     const int nxv = g.nx / 4;
-    const int tiles_x = (nxv + 63) / 64, tiles_y = (g.ny + 3) / 4;
+    const int tiles_x = (nxv + ST_BCV - 1) / ST_BCV, tiles_y = (g.ny + ST_BR - 1) / ST_BR;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + NS_TWN - 1) / NS_TWN : 1;
     const long long ntiles = (long long)tiles_x * tiles_y, total = ntiles * nchunks * nwin, per_xcd = (total + 7) / 8;
@@ -48,7 +76,7 @@ __global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<
         const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
         const int t0 = TWIN ? win * NS_TWN : 0;
         const int bx = tile % tiles_x, by = tile / tiles_x;
-        const int col0 = (bx * 64 + wave * 16 + lx) * 4, y = by * 4 + row;
+        const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * 4, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
         const bool ok = (col0 < g.nx) && (y < g.ny);
         const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * 4) : 0u;
         const unsigned row_bytes = (unsigned)g.nx * 4u;
@@ -72,86 +100,97 @@ __global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<
         const unsigned eoff = want_le ? voff - 4u : voff + 16u;
         auto fvalid = [&](int t) { return !TWIN || (t0 + t < Mg); };
         auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };
-        F4 C[M], P[M], N[M], H[M];
+        // State: plane z (C), plane z-1 (P), the result of plane z-1 still waiting for its forward z term (R), the halo rows /
+        // border elements of plane z (H, E).  The z term is SHARED: dz(z) = wz^2 (x(z) - x(z-1)) is the backward term of plane z
+        // and minus the forward term of plane z-1, so step z finishes and stores plane z-1 and x(z+1) is never needed inside
+        // the step.  That lets the centre vectors, halo rows and border elements of plane z+1 all be requested in the same
+        // frame of step z -- the moment the owners of those lines request them (round 2: requested one step apart they cost
+        // a second trip to memory, 17 GB read for an 8.6 GB image).
+        F4 C[M], P[M], R[M], H[M];
         float E[M];
         auto plane = [&](int zl) { return g.za ? zplane<float>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
         auto load_c = [&](const float* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu(pl + foff(t), voff) : zero; };
         {
             const float* pp = g.za ? plane(zs - 1) : nullptr;
             const float* pc = plane(zs);
-            const float* pn = (g.za || zs + 1 < ze) ? plane(zs + 1) : nullptr;        // the next centre plane even without a z axis
 #pragma unroll
             for (int t = 0; t < M; ++t) {
                 P[t] = load_c(pp, t);
                 C[t] = load_c(pc, t);
-                N[t] = load_c(pn, t);
+                R[t] = zero;
                 H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu(pc + foff(t), hoff) : zero;
                 E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu1(pc + foff(t), eoff) : 0.f;
             }
         }
-        for (int z = zs; z < ze; ++z) {
+        for (int z = zs; z <= ze; ++z) {              // step ze only finishes plane ze - 1
+            st_sync_plane();
+            const bool in_chunk = (z < ze), next_in = (z + 1 < ze);
             const int gz = g.z0 + z;
-            const float m_pz = (g.za && gz > 0) ? wz2 : 0.f, m_nz = (g.za && gz + 1 < g.nzg) ? wz2 : 0.f;
-            const float* pc = plane(z);
-            const float* pc1 = (z + 1 < ze) ? plane(z + 1) : nullptr;             // centre plane of the next step (halo rows, edges)
-            const float* pn2 = (z + 1 < ze && (g.za || z + 2 < ze)) ? plane(z + 2) : nullptr;      // its next plane
+            const float mz = (g.za && gz > 0 && gz < g.nzg) ? wz2 : 0.f;
+            const float* pc = in_chunk ? plane(z) : nullptr;
+            // plane requested now (consumed at step z + 1); the step behind the chunk needs the centre vectors only
+            const float* pn = (next_in || (g.za && z + 1 == ze)) ? plane(z + 1) : nullptr;
             F4 cold = zero;
-            if (TWIN && g.ta && t0 > 0) cold = ok ? ldu(pc + foff(-1), voff) : zero;
+            if (TWIN && g.ta && t0 > 0 && in_chunk) cold = ok ? ldu(pc + foff(-1), voff) : zero;
 #pragma unroll
             for (int t = 0; t < M; ++t) {
                 if (TWIN && !fvalid(t)) break;
+                st_sync_frame();
                 const int tg = t0 + t;
-                const F4 c = C[t], h = H[t];
-                // ---- - Laplacian-like sum: (c - prev) - (next - c) per axis, missing neighbours drop their term ----------
-                const F4 sdn = shfl_down16(c), sup = shfl_up16(c);
-                const F4 nr = (row == 3) ? h : sdn, pr = (row == 0) ? h : sup;
-                F4 r = m_pr * (c - pr) - m_nr * (nr - c);
-                {
-                    // the cross-lane moves are executed by EVERY lane (a DPP read from a lane that a branch has switched
-                    // off returns 0), the select comes afterwards
-                    const float from_l = dpp_from_left(c.v[3]), from_r = dpp_from_right(c.v[0]);
-                    const float left = (lx == 0) ? E[t] : from_l;
-                    const float right = (lx == 15) ? E[t] : from_r;
-                    const float e0 = c.v[1] - c.v[0], e1 = c.v[2] - c.v[1], e2 = c.v[3] - c.v[2];
-                    // interior elements of the vector always have both column neighbours inside the frame (nx % 4 == 0)
-                    r.v[0] += m_c0 * (c.v[0] - left) - e0;
-                    r.v[1] += e0 - e1;
-                    r.v[2] += e1 - e2;
-                    r.v[3] += e2 - m_c3 * (right - c.v[3]);
+                const F4 c = C[t], h = H[t], xm = P[t];
+                const F4 dz = ns_mul(mz, c, xm);
+                const F4 rfin = ns_sub(R[t], dz);            // plane z-1 is complete
+                if (in_chunk) {
+                    // ---- - Laplacian-like sum: (c - prev) - (next - c) per axis, missing neighbours drop their term ------
+                    const F4 sdn = shfl_down16(c), sup = shfl_up16(c);
+                    const F4 nr = (row == 3) ? h : sdn, pr = (row == 0) ? h : sup;
+                    F4 r = m_pr * (c - pr) - m_nr * (nr - c);
+                    {
+                        // the cross-lane moves are executed by EVERY lane (a DPP read from a lane that a branch has switched
+                        // off returns 0), the select comes afterwards
+                        const float from_l = dpp_from_left(c.v[3]), from_r = dpp_from_right(c.v[0]);
+                        const float left = (lx == 0) ? E[t] : from_l;
+                        const float right = (lx == 15) ? E[t] : from_r;
+                        const float e0 = c.v[1] - c.v[0], e1 = c.v[2] - c.v[1], e2 = c.v[3] - c.v[2];
+                        // interior elements of the vector always have both column neighbours inside the frame (nx % 4 == 0)
+                        r.v[0] += m_c0 * (c.v[0] - left) - e0;
+                        r.v[1] += e0 - e1;
+                        r.v[2] += e1 - e2;
+                        r.v[3] += e2 - m_c3 * (right - c.v[3]);
+                    }
+                    if (g.ta) {
+                        F4 tt = zero;
+                        if (tg > 0) tt = tt + (c - cold);
+                        if (t + 1 < M) { if (tg + 1 < Mg) tt = tt - (C[(t + 1 < M) ? t + 1 : t] - c); }
+                        else if (TWIN && tg + 1 < Mg) tt = tt - ((ok ? ldu(pc + foff(t + 1), voff) : zero) - c);
+                        r = r + mf2 * tt;
+                    }
+                    R[t] = ns_add(r, dz);
                 }
-                r = r + (m_pz * (c - P[t]) - m_nz * (N[t] - c));
-                if (g.ta) {
-                    F4 tt = zero;
-                    if (tg > 0) tt = tt + (c - cold);
-                    if (t + 1 < M) { if (tg + 1 < Mg) tt = tt - (C[(t + 1 < M) ? t + 1 : t] - c); }
-                    else if (TWIN && tg + 1 < Mg) tt = tt - ((ok ? ldu(pc + foff(t + 1), voff) : zero) - c);
-                    r = r + mf2 * tt;
-                }
-                // ---- rotate the planes, request the next ones (before the stores of this frame) ----------------------------
+                // ---- rotate the planes, request the next one (before the stores of this frame) ---------------------------
                 cold = c;
                 P[t] = c;
-                C[t] = N[t];
-                N[t] = load_c(pn2, t);
-                H[t] = (pc1 != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu(pc1 + foff(t), hoff) : zero;
-                E[t] = (pc1 != nullptr && (want_le || want_re) && fvalid(t)) ? ldu1(pc1 + foff(t), eoff) : 0.f;
-                // ---- epilogue ---------------------------------------------------------------------------------------------
-                if (!ok) continue;
-                const long long fo = (long long)z * g.s_z + foff(t);
+                C[t] = load_c(pn, t);
+                H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu(pn + foff(t), hoff) : zero;
+                E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu1(pn + foff(t), eoff) : 0.f;
+                // ---- epilogue of plane z-1 --------------------------------------------------------------------------------
+                if (!ok || z == zs) continue;
+                const long long fo = (long long)(z - 1) * g.s_z + foff(t);
                 F4 o;
                 if (a.b == nullptr) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        o.v[i] = c.v[i] + a.rho * r.v[i];
-                        acc0 += (double)c.v[i] * (double)o.v[i];
-                        acc1 += (double)c.v[i] * (double)c.v[i];
+                        o.v[i] = xm.v[i] + a.rho * rfin.v[i];
+                        acc0 += (double)xm.v[i] * (double)o.v[i];
+                        acc1 += (double)xm.v[i] * (double)xm.v[i];
                     }
                 } else {
                     const F4 bv = ldu(a.b + fo, voff);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        o.v[i] = bv.v[i] - (c.v[i] + a.rho * r.v[i]);
+                        o.v[i] = bv.v[i] - (xm.v[i] + a.rho * rfin.v[i]);
                         acc0 += (double)o.v[i] * (double)o.v[i];
-                        acc1 += (double)c.v[i] * (double)c.v[i];
+                        acc1 += (double)xm.v[i] * (double)xm.v[i];
                     }
                     if (a.out2 != nullptr) stu(a.out2 + fo, voff, o);
                 }
@@ -193,12 +232,12 @@ __device__ __forceinline__ F2 ldu2(const float* ubase, unsigned voff) {
 }
 
 template <int M, bool TWIN>
-__global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
+__global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
     const int nxv = g.nx / 4;
-    const int tiles_x = (nxv + 63) / 64, tiles_y = (g.ny + 3) / 4;
+    const int tiles_x = (nxv + ST_BCV - 1) / ST_BCV, tiles_y = (g.ny + ST_BR - 1) / ST_BR;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + NS_TWN - 1) / NS_TWN : 1;
     const long long ntiles = (long long)tiles_x * tiles_y, total = ntiles * nchunks * nwin, per_xcd = (total + 7) / 8;
@@ -209,7 +248,7 @@ __global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g,
         const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
         const int t0 = TWIN ? win * NS_TWN : 0;
         const int bx = tile % tiles_x, by = tile / tiles_x;
-        const int col0 = (bx * 64 + wave * 16 + lx) * 4, y = by * 4 + row;
+        const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * 4, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
         const bool ok = (col0 < g.nx) && (y < g.ny);
         const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * 4) : 0u;
         const unsigned row_bytes = (unsigned)g.nx * 4u;
@@ -238,7 +277,8 @@ __global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g,
         auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };
         auto plane = [&](int zl) { return g.za ? zplane<float>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
         auto load_c = [&](const float* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu(pl + foff(t), voff) : zero; };
-        F4 C[M], P[M], N[M], H[M];
+        // same delayed-store structure as k_normal_stream, on each of the two stride-2 plane lattices: step z finishes plane z-2
+        F4 C[M], P[M], R[M], H[M];
         F2 E[M];
         for (int par = 0; par < 2; ++par) {
             const int zfirst = zs + par;
@@ -246,80 +286,84 @@ __global__ __launch_bounds__(256, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g,
             {
                 const float* pp = g.za ? plane(zfirst - 2) : nullptr;
                 const float* pc = plane(zfirst);
-                const float* pn = (g.za || zfirst + 2 < ze) ? plane(zfirst + 2) : nullptr;
 #pragma unroll
                 for (int t = 0; t < M; ++t) {
                     P[t] = load_c(pp, t);
                     C[t] = load_c(pc, t);
-                    N[t] = load_c(pn, t);
+                    R[t] = zero;
                     H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu(pc + foff(t), hoff) : zero;
                     E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu2(pc + foff(t), eoff) : F2{0.f, 0.f};
                 }
             }
-            for (int z = zfirst; z < ze; z += 2) {
+            for (int z = zfirst; z < ze + 2; z += 2) {          // the step behind the chunk only finishes the lattice's last plane
+                st_sync_plane();
+                const bool in_chunk = (z < ze), next_in = (z + 2 < ze);
                 const int gz = g.z0 + z;
-                const float m_pz = (g.za && gz >= 2) ? wz2 : 0.f, m_nz = (g.za && gz + 2 < g.nzg) ? wz2 : 0.f;
-                const float* pc = plane(z);
-                const float* pc1 = (z + 2 < ze) ? plane(z + 2) : nullptr;
-                const float* pn2 = (z + 2 < ze && (g.za || z + 4 < ze)) ? plane(z + 4) : nullptr;
+                const float mz = (g.za && gz >= 2 && gz < g.nzg) ? wz2 : 0.f;
+                const float* pc = in_chunk ? plane(z) : nullptr;
+                const float* pn = (next_in || (g.za && in_chunk)) ? plane(z + 2) : nullptr;
                 F4 cold1 = zero, cold2 = zero;         // x(z, t-1), x(z, t-2)
-                if (TWIN && g.ta && ok) {
+                if (TWIN && g.ta && ok && in_chunk) {
                     if (t0 >= 1) cold1 = ldu(pc + foff(-1), voff);
                     if (t0 >= 2) cold2 = ldu(pc + foff(-2), voff);
                 }
 #pragma unroll
                 for (int t = 0; t < M; ++t) {
                     if (TWIN && !fvalid(t)) break;
+                    st_sync_frame();
                     const int tg = t0 + t;
-                    const F4 c = C[t], h = H[t];
-                    // rows y-2 / y+2: rows 2, 3 take y-2 from rows 0, 1 of the tile (32 lanes up), rows 0, 1 from the halo load
-                    const F4 sup = shfl_up32(c), sdn = shfl_down32(c);
-                    const F4 pr = (row <= 1) ? h : sup, nr = (row >= 2) ? h : sdn;
-                    F4 r = m_pr * (c - pr) - m_nr * (nr - c);
-                    {
-                        const float l2 = dpp_from_left(c.v[2]), l3 = dpp_from_left(c.v[3]);       // executed by every lane
-                        const float r0 = dpp_from_right(c.v[0]), r1 = dpp_from_right(c.v[1]);
-                        const float lm2 = (lx == 0) ? E[t].a : l2, lm1 = (lx == 0) ? E[t].b : l3;   // x(col0-2), x(col0-1)
-                        const float rp4 = (lx == 15) ? E[t].a : r0, rp5 = (lx == 15) ? E[t].b : r1; // x(col0+4), x(col0+5)
-                        r.v[0] += m_cb[0] * (c.v[0] - lm2) - m_cf[0] * (c.v[2] - c.v[0]);
-                        r.v[1] += m_cb[1] * (c.v[1] - lm1) - m_cf[1] * (c.v[3] - c.v[1]);
-                        r.v[2] += m_cb[2] * (c.v[2] - c.v[0]) - m_cf[2] * (rp4 - c.v[2]);
-                        r.v[3] += m_cb[3] * (c.v[3] - c.v[1]) - m_cf[3] * (rp5 - c.v[3]);
-                    }
-                    r = r + (m_pz * (c - P[t]) - m_nz * (N[t] - c));
-                    if (g.ta) {
-                        F4 tt = zero;
-                        if (tg >= 2) tt = tt + (c - cold2);
-                        if (tg + 2 < Mg) {
-                            if (t + 2 < M) tt = tt - (C[(t + 2 < M) ? t + 2 : t] - c);
-                            else if (TWIN) tt = tt - ((ok ? ldu(pc + foff(t + 2), voff) : zero) - c);
+                    const F4 c = C[t], h = H[t], xm = P[t];
+                    const F4 dz = ns_mul(mz, c, xm);
+                    const F4 rfin = ns_sub(R[t], dz);
+                    if (in_chunk) {
+                        // rows y-2 / y+2: rows 2, 3 take y-2 from rows 0, 1 of the tile (32 lanes up), rows 0, 1 from the halo load
+                        const F4 sup = shfl_up32(c), sdn = shfl_down32(c);
+                        const F4 pr = (row <= 1) ? h : sup, nr = (row >= 2) ? h : sdn;
+                        F4 r = m_pr * (c - pr) - m_nr * (nr - c);
+                        {
+                            const float l2 = dpp_from_left(c.v[2]), l3 = dpp_from_left(c.v[3]);       // executed by every lane
+                            const float r0 = dpp_from_right(c.v[0]), r1 = dpp_from_right(c.v[1]);
+                            const float lm2 = (lx == 0) ? E[t].a : l2, lm1 = (lx == 0) ? E[t].b : l3;   // x(col0-2), x(col0-1)
+                            const float rp4 = (lx == 15) ? E[t].a : r0, rp5 = (lx == 15) ? E[t].b : r1; // x(col0+4), x(col0+5)
+                            r.v[0] += m_cb[0] * (c.v[0] - lm2) - m_cf[0] * (c.v[2] - c.v[0]);
+                            r.v[1] += m_cb[1] * (c.v[1] - lm1) - m_cf[1] * (c.v[3] - c.v[1]);
+                            r.v[2] += m_cb[2] * (c.v[2] - c.v[0]) - m_cf[2] * (rp4 - c.v[2]);
+                            r.v[3] += m_cb[3] * (c.v[3] - c.v[1]) - m_cf[3] * (rp5 - c.v[3]);
                         }
-                        r = r + mf2 * tt;
+                        if (g.ta) {
+                            F4 tt = zero;
+                            if (tg >= 2) tt = tt + (c - cold2);
+                            if (tg + 2 < Mg) {
+                                if (t + 2 < M) tt = tt - (C[(t + 2 < M) ? t + 2 : t] - c);
+                                else if (TWIN) tt = tt - ((ok ? ldu(pc + foff(t + 2), voff) : zero) - c);
+                            }
+                            r = r + mf2 * tt;
+                        }
+                        R[t] = ns_add(r, dz);
                     }
                     cold2 = cold1;
                     cold1 = c;
                     P[t] = c;
-                    C[t] = N[t];
-                    N[t] = load_c(pn2, t);
-                    H[t] = (pc1 != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu(pc1 + foff(t), hoff) : zero;
-                    E[t] = (pc1 != nullptr && (want_le || want_re) && fvalid(t)) ? ldu2(pc1 + foff(t), eoff) : F2{0.f, 0.f};
-                    if (!ok) continue;
-                    const long long fo = (long long)z * g.s_z + foff(t);
+                    C[t] = load_c(pn, t);
+                    H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu(pn + foff(t), hoff) : zero;
+                    E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu2(pn + foff(t), eoff) : F2{0.f, 0.f};
+                    if (!ok || z == zfirst) continue;
+                    const long long fo = (long long)(z - 2) * g.s_z + foff(t);
                     F4 o;
                     if (a.b == nullptr) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            o.v[i] = c.v[i] + a.rho * (0.25f * r.v[i]);
-                            acc0 += (double)c.v[i] * (double)o.v[i];
-                            acc1 += (double)c.v[i] * (double)c.v[i];
+                            o.v[i] = xm.v[i] + a.rho * (0.25f * rfin.v[i]);
+                            acc0 += (double)xm.v[i] * (double)o.v[i];
+                            acc1 += (double)xm.v[i] * (double)xm.v[i];
                         }
                     } else {
                         const F4 bv = ldu(a.b + fo, voff);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            o.v[i] = bv.v[i] - (c.v[i] + a.rho * (0.25f * r.v[i]));
+                            o.v[i] = bv.v[i] - (xm.v[i] + a.rho * (0.25f * rfin.v[i]));
                             acc0 += (double)o.v[i] * (double)o.v[i];
-                            acc1 += (double)c.v[i] * (double)c.v[i];
+                            acc1 += (double)xm.v[i] * (double)xm.v[i];
                         }
                         if (a.out2 != nullptr) stu(a.out2 + fo, voff, o);
                     }

@@ -1,4 +1,7 @@
 // tv_nstream.hip -- instantiations + launcher of the streaming normal operator (tv_nstream.h).
+#ifdef TV_NSTREAM_NOCONTRACT
+#pragma clang fp contract(off)
+#endif
 #include "tv_host.h"
 #include "tv_stencil.h"
 #include "tv_nstream.h"
@@ -16,7 +19,7 @@ bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
 
 int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, float* out, float* out2,
              float rho, hipStream_t st, long long* nblocks, double* part0, double* part1) {
-    const long long tx = (d.nx / 4 + 63) / 64, ty = (d.ny + 3) / 4;
+    const long long tx = (d.nx / 4 + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
         const long long want = (4096 + tx * ty - 1) / (tx * ty);
@@ -28,7 +31,7 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
     const long long nch = (d.nz + zc - 1) / zc;
     const long long nwin = (d.m > NS_TWN) ? (d.m + NS_TWN - 1) / NS_TWN : 1;
     const long long nb = tx * ty * nch * nwin, per_xcd = (nb + 7) / 8;
-    const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, 4, 1);
+    const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, ST_NWX * ST_NWY, 1);
     *nblocks = 8 * per_xcd;
     if (*nblocks > max_partials(d)) return fail(TV_E_ARG, "internal: normal-operator partials exceed the workspace");
     const WT<float> w = make_w<float>(g);
