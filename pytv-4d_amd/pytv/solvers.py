@@ -107,18 +107,19 @@ class _SlabProblem:
 class ChambollePock(_SlabProblem):
     """min_x 1/2 |x - x0|^2 + regularization * TV(x), README.md:141-157 with the state on the GPU.
 
-    Per-step scalars: ``SLOTS`` fp64 device words, TV parts in [0:6], fidelity parts in [6:12] (one slot per
+    Per-step scalars: ``SLOTS`` fp64 device words, TV parts in [0:7], fidelity parts in [7:14] (one slot per
     launch; they are summed, over launches and over ranks, only when the loss is asked for).
 
     x0 : this rank's slab (device tensor).  ``step()`` enqueues one iteration; ``run(n)`` enqueues n
     and returns the loss history (one host synchronisation at the end)."""
 
-    SLOTS = 12
+    SLOTS = 14
+    F = 7               # first fidelity slot
 
     @classmethod
     def loss_from_slots(cls, h, regularization):
         """README.md:157 loss from an (n, SLOTS) array of (already rank-summed) per-step scalars."""
-        return h[:, 6:12].sum(axis=1) + regularization * h[:, 0:6].sum(axis=1)
+        return h[:, cls.F:cls.SLOTS].sum(axis=1) + regularization * h[:, 0:cls.F].sum(axis=1)
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
                  factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None):
@@ -189,8 +190,10 @@ class ChambollePock(_SlabProblem):
 
     def _step_fused(self, out):
         """One-sweep iteration: x halos -> sweep (x -> x_alt) -> q' halos -> fix-up -> swap.  With a sharded
-        slab the interior chunks / planes run while the halo planes are in flight."""
-        s, nz = self.slab, self.slab.nz
+        slab the interior chunks / planes run while the halo planes are in flight: the first half of the interior chunks
+        hides the x exchange, then the two edge chunks run, and the SECOND half of the interior chunks (with the interior
+        fix-up behind it) hides the q' exchange -- the interior fix-up alone is too short for that on a 32-plane slab."""
+        s, nz, F = self.slab, self.slab.nz, self.F
         ev = self._events()
         qhp = self.qh_prev[0] if self.qh_prev is not None else None
         qhn = self.qh_next[0] if self.qh_next is not None else None
@@ -199,24 +202,31 @@ class ChambollePock(_SlabProblem):
             ev[0].record()
         if self.overlap_fused:
             nch = self.nchunks
-            self._sweep(1, nch - 2, None, None, out[0:1], out[6:7])
+            na = (nch - 2 + 1) // 2                      # interior chunks before the edge chunks, nb after them
+            nb = nch - 2 - na
+            self._sweep(1, na, None, None, out[0:1], out[F:F + 1])
             s.wait(h)
-            self._sweep(0, 1, self.xh_prev, None, out[1:2], out[7:8])
-            self._sweep(nch - 1, 1, None, self.xh_next, out[2:3], out[8:9])
+            self._sweep(0, 1, self.xh_prev, None, out[1:2], out[F + 1:F + 2])
+            self._sweep(nch - 1, 1, None, self.xh_next, out[2:3], out[F + 2:F + 3])
+            h = self.plan.exchange_grad(self.q, qhp, qhn)
+            if nb > 0:
+                self._sweep(1 + na, nb, None, None, out[3:4], out[F + 3:F + 4])
+            if ev:
+                ev[1].record()
         else:
             s.wait(h)
-            self._sweep(0, -1, self.xh_prev, self.xh_next, out[0:1], out[6:7])
-        if ev:
-            ev[1].record()
-        h = self.plan.exchange_grad(self.q, qhp, qhn)
+            self._sweep(0, -1, self.xh_prev, self.xh_next, out[0:1], out[F:F + 1])
+            if ev:
+                ev[1].record()
+            h = self.plan.exchange_grad(self.q, qhp, qhn)
         if self.overlap_fused:
-            self._fixup(1, nz - 2, None, None, out[9:10])
+            self._fixup(1, nz - 2, None, None, out[F + 4:F + 5])
             s.wait(h)
-            self._fixup(0, 1, self.qh_prev, None, out[10:11])
-            self._fixup(nz - 1, 1, None, self.qh_next, out[11:12])
+            self._fixup(0, 1, self.qh_prev, None, out[F + 5:F + 6])
+            self._fixup(nz - 1, 1, None, self.qh_next, out[F + 6:F + 7])
         else:
             s.wait(h)
-            self._fixup(0, -1, self.qh_prev, self.qh_next, out[9:10])
+            self._fixup(0, -1, self.qh_prev, self.qh_next, out[F + 4:F + 5])
         if ev:
             ev[2].record()
         self.x, self.x_alt = self.x_alt, self.x
@@ -231,11 +241,11 @@ class ChambollePock(_SlabProblem):
 
     def step(self, out=None):
         """Enqueue one iteration.  out: fp64 device tensor of SLOTS words receiving this rank's TV parts
-        [0:6] and fidelity parts [6:12] (summed later); defaults to an internal scratch."""
+        [0:7] and fidelity parts [7:14] (summed later); defaults to an internal scratch."""
         out = self._scratch if out is None else out
         if self.fused:
             return self._step_fused(out)
-        nz, s = self.slab.nz, self.slab
+        nz, s, F = self.slab.nz, self.slab, self.F
         x, q = self.x, self.q
         ev = self._events()
         # ---------------- dual: q <- proj(q + sigma D x) -----------------------------------------
@@ -256,13 +266,13 @@ class ChambollePock(_SlabProblem):
         h = self.plan.exchange_grad(q, self.qh_prev[0] if self.qh_prev is not None else None,
                                     self.qh_next[0] if self.qh_next is not None else None)
         if self.overlap:
-            self._primal(1, nz - 1, q[0, self.ch_back], q[nz - 1, self.ch_fwd], out[6:7])
+            self._primal(1, nz - 1, q[0, self.ch_back], q[nz - 1, self.ch_fwd], out[F:F + 1])
             s.wait(h)
-            self._primal(0, 1, self.qh_prev, q[1, self.ch_fwd], out[7:8])
-            self._primal(nz - 1, nz, q[nz - 2, self.ch_back], self.qh_next, out[8:9])
+            self._primal(0, 1, self.qh_prev, q[1, self.ch_fwd], out[F + 1:F + 2])
+            self._primal(nz - 1, nz, q[nz - 2, self.ch_back], self.qh_next, out[F + 2:F + 3])
         else:
             s.wait(h)
-            self._primal(0, nz, self.qh_prev, self.qh_next, out[6:7])
+            self._primal(0, nz, self.qh_prev, self.qh_next, out[F:F + 1])
         if ev:
             ev[2].record()
         self.it += 1
