@@ -110,6 +110,68 @@ def cpu_baseline_openmp(shape, reg_z, reg_time):
                       "%.2f s/iteration; it/s extrapolated linearly in Nz to %s" % (sub, n_it, dt, tuple(shape))}
 
 
+def live_traffic(args):
+    """HBM bytes per launch of the CP kernels from rocprofv3 PMC counters, measured NOW: two child runs of this very command
+    (--steps 2 --warmup 1, no CPU baseline), one per counter because FETCH_SIZE and WRITE_SIZE do not fit one pass
+    (MI355X_MICROARCH.md, HBM / rocprofv3 sections: separate --pmc passes, no tracing next to them; read bytes = 2 x FETCH_SIZE KiB
+    on gfx950, write bytes = WRITE_SIZE KiB -- both checked against kernels with exactly known byte counts,
+    profiles/r2_pmc_calibration.txt).  Runs BEFORE this process touches the GPU, so the children have the whole HBM.
+    Returns ({kernel key: bytes per launch}, note) or (None, reason)."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "already running under a profiler"
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pmc", "off",
+             "--workload", args.workload, "--scheme", args.scheme] + (["--two-kernel"] if args.two_kernel else [])
+    sums = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="tvpmc_", dir="/tmp")
+        try:
+            proc = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp",
+                                    env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=300)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)          # exactly the process group started above
+                proc.wait()
+                return None, "rocprofv3 --pmc %s pass timed out" % counter
+            if rc != 0:
+                return None, "rocprofv3 --pmc %s pass exited with %d" % (counter, rc)
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == counter and "tv::k_" in r.get("Kernel_Name", "") and "k_reduce" not in r["Kernel_Name"]:
+                        per.setdefault(r["Kernel_Name"].split("(")[0].replace("void ", ""), []).append(float(r["Counter_Value"]))
+            if not per:
+                return None, "no counter rows for the tv:: kernels in the %s pass" % counter
+            for k, v in per.items():
+                kib = sum(v) / len(v)
+                sums.setdefault(k, {})[counter] = (2.0 if counter == "FETCH_SIZE" else 1.0) * kib * 1024.0
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {"fused": 0.0, "fixup": 0.0, "dual": 0.0, "primal": 0.0}
+    for k, c in sums.items():
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        b = c["FETCH_SIZE"] + c["WRITE_SIZE"]
+        if "k_cp_fused" in k:
+            out["fused"] += b
+        elif "k_cp_fixup" in k:
+            out["fixup"] += b
+        elif "CpDual" in k:
+            out["dual"] += b
+        elif "CpPrimal" in k:
+            out["primal"] += b
+    note = ("LIVE: two rocprofv3 child passes of this command (--pmc FETCH_SIZE, --pmc WRITE_SIZE; --steps 2 --warmup 1) in %.0f s; "
+            "bytes per launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md, HBM section; both counters are exact on "
+            "kernels with known byte counts, profiles/r2_pmc_calibration.txt)" % (time.perf_counter() - t0))
+    return {k: (v if v > 0 else None) for k, v in out.items()}, note
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,7 +185,20 @@ def main():
     ap.add_argument("--comm", default="torch", choices=["torch", "cabi"],
                     help="halo exchange through torch.distributed (RCCL process group, default) or through the C-ABI's own RCCL "
                          "context (tv_ctx_create / tv_halo_exchange; torch.distributed only hands out the unique id)")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
+                    help="auto (1 GPU only): measure roofline.traffic live with two rocprofv3 --pmc child passes before the timed run; "
+                         "off: copy the committed numbers of profiles/traffic.json and label them STATIC")
     args = ap.parse_args()
+
+    live, live_note = None, "--pmc off"
+    if args.pmc == "auto":
+        if args.gpus == 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("TV_BENCH_PMC", "1") != "0":
+            try:
+                live, live_note = live_traffic(args)
+            except Exception as e:          # the profiler is evidence, not the product: never let it take the bench down
+                live, live_note = None, "live PMC passes failed: %r" % (e,)
+        else:
+            live_note = "PMC passes run with one GPU only"
 
     import torch
     import torch.distributed as dist
@@ -224,6 +299,9 @@ def main():
         traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s|%s" % (args.workload, args.scheme), {})
     except Exception:
         pass
+    traffic_source = "STATIC, not measured in this run (%s): %s" % (live_note, traffic.get("source"))
+    if live is not None:
+        traffic, traffic_source = live, live_note
     torch.cuda.synchronize()
     t_k1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
     t_k2 = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
@@ -234,7 +312,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_fused: k_cp_fused<S,M> (dual update + lagged primal update, one pass over q)",
                            "achieved": b_k1 / t_k1 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_k1 / t_k1 / 1e9 / HBM_PEAK_GBPS,
                            "traffic": traffic.get("fused"),
-                           "traffic_source": "STATIC, not measured in this run: " + str(traffic.get("source")), "bytes_per_launch": b_k1,
+                           "traffic_source": traffic_source, "bytes_per_launch": b_k1,
                            "ms_per_launch": 1e3 * t_k1,
                            "note": "algorithmic bytes (5+2Nd)*4 per voxel: q read+written once, x/x0/p read, x/p written; HIP events on the "
                                    "launch stream (includes the tiny partial-sum kernels)" + sharded}
@@ -248,7 +326,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_dual: k_D_march<S,M,CpDual> (fp32, planes >= 4 MiB) or k_D<S,T,V,CpDual>",
                            "achieved": b_dual / t_k1 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_dual / t_k1 / 1e9 / HBM_PEAK_GBPS,
                            "traffic": traffic.get("dual"),
-                           "traffic_source": "STATIC, not measured in this run: " + str(traffic.get("source")), "bytes_per_launch": b_dual,
+                           "traffic_source": traffic_source, "bytes_per_launch": b_dual,
                            "ms_per_launch": 1e3 * t_k1,
                            "note": "algorithmic bytes (1+2Nd)*4 per voxel; HIP events on the launch stream (includes the tiny partial-sum kernels)" + sharded}
         out["roofline_primal"] = {"bound": "hbm", "kernel": "tv_cp_primal: k_DT_march<S,M,CpPrimal> or k_DT<S,T,V,SrcPlain,CpPrimal>",

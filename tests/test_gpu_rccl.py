@@ -110,7 +110,7 @@ def test_bench_sharded_over_ranks_gives_the_single_rank_loss(ranks):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TV_BENCH_BACKEND", "TV_BENCH_SHARE_GPU"):
         env.pop(k, None)
     common = ["--workload", "small", "--steps", "6", "--warmup", "2"]
-    one = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline"] + common, env)
+    one = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--pmc", "off"] + common, env)
     env2 = dict(env, TV_BENCH_BACKEND="gloo", TV_BENCH_SHARE_GPU="1", TV_ZCHUNK="1")      # short chunks: interior-first schedule
     many = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                         "--master-addr", "127.0.0.1", "--master-port", str(29640 + ranks), os.path.join(ROOT, "bench.py"),
@@ -120,3 +120,21 @@ def test_bench_sharded_over_ranks_gives_the_single_rank_loss(ranks):
     assert "roofline" in many and many["rccl_ranks"] == 0            # the test transport is not RCCL
     a, b = one["loss_first_last"], many["loss_first_last"]
     assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1])
+
+
+def test_bench_measures_its_hbm_traffic_live():
+    """`python bench.py` on one GPU (no launcher environment): roofline.traffic comes from two rocprofv3 --pmc child passes of the
+    same command, not from the committed table; it can only exceed the algorithmic bytes (by the halo rows / prologues)."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "config2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    r = out["roofline"]
+    assert r["traffic_source"].startswith("LIVE"), r["traffic_source"]
+    assert 0.98 * r["bytes_per_launch"] <= r["traffic"] <= 1.25 * r["bytes_per_launch"], (r["traffic"], r["bytes_per_launch"])
+    assert out["roofline_fixup"]["traffic"] > 0

@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for v in base ${VARIANT:-ea}; do
   if [ $v != base ]; then export PYTV4D_LIB=$R/pytv-4d_amd/pytv/libpytv4d_hip_$v.so; else unset PYTV4D_LIB; fi
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$v -o f -- python3 $R/${SCRIPT:-bench.py --no-cpu-baseline --steps 2 --warmup 1} $BENCH_ARGS > $OUT/$v.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$v -o f -- python3 $R/${SCRIPT:-bench.py --pmc off --no-cpu-baseline --steps 2 --warmup 1} $BENCH_ARGS > $OUT/$v.log 2>&1
   python3 - $OUT/$v $v "${KFILTER:-cp_f}" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)
