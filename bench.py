@@ -134,7 +134,7 @@ def live_traffic(args):
                                     env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                     start_new_session=True)
             try:
-                rc = proc.wait(timeout=300)
+                rc = proc.wait(timeout=240 if counter == "FETCH_SIZE" else 120)      # the first pass may be the box's first `import torch`
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, signal.SIGKILL)          # exactly the process group started above
                 proc.wait()
