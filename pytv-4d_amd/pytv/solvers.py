@@ -685,13 +685,46 @@ class ADMM(_SlabProblem):
             out[1:2].mul_(2.0)                        # run() halves: the slot holds |x - x0|^2 like the textbook path
         self._zu(out[0:1])
 
-    def run(self, n_outer):
+    GRAPH_BLOCK = 4             # outer iterations captured per hipGraph
+    GRAPH_MAX_VOXELS = 1 << 23  # below this an outer iteration (~10 + 2 n_cg launches) is launch-bound
+
+    def run(self, n_outer, graph=None):
+        """n_outer outer iterations; returns the loss history.  graph: None = replay blocks of GRAPH_BLOCK outer iterations
+        from a hipGraph when the problem is small enough to be launch-bound and not sharded (every scalar of the CG recurrence
+        lives on the device, so an outer iteration has no host round trip to break the capture); True / False force it."""
         hist = torch.zeros((n_outer, 2), dtype=torch.float64, device=self.device)
-        for k in range(n_outer):
+        use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS) if graph is None else bool(graph)
+        start = 0
+        if use_graph and not self.slab.sharded and n_outer >= 2 + 2 * self.GRAPH_BLOCK:
+            self.step(hist[0])                   # eager: also the warm-up of the capture
+            self.step(hist[1])
+            start = 2 + self._run_graphed_from(hist, 2, n_outer)
+        for k in range(start, n_outer):
             self.step(hist[k])
         self.slab.allreduce_sum_(hist)
         h = hist.cpu().numpy()
         return 0.5 * h[:, 1] + self.reg * h[:, 0]
+
+    def _run_graphed_from(self, hist, first, n_outer):
+        """Capture GRAPH_BLOCK outer iterations (not executed during capture) and replay them over hist[first:]."""
+        K = self.GRAPH_BLOCK
+        nrep = (n_outer - first) // K
+        if nrep < 1:
+            return 0
+        try:
+            buf = torch.zeros((K, 2), dtype=torch.float64, device=self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for k in range(K):
+                    self.step(buf[k])
+        except Exception:
+            return 0                             # nothing ran: stay eager
+        done = 0
+        for r in range(nrep):
+            graph.replay()
+            hist[first + done:first + done + K].copy_(buf)
+            done += K
+        return done
 
     def result(self):
         return self.x
