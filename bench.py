@@ -115,7 +115,7 @@ def live_traffic(args):
     (--steps 2 --warmup 1, no CPU baseline), one per counter because FETCH_SIZE and WRITE_SIZE do not fit one pass
     (MI355X_MICROARCH.md, HBM / rocprofv3 sections: separate --pmc passes, no tracing next to them; read bytes = 2 x FETCH_SIZE KiB
     on gfx950, write bytes = WRITE_SIZE KiB -- both checked against kernels with exactly known byte counts,
-    profiles/r2_pmc_calibration.txt).  Runs BEFORE this process touches the GPU, so the children have the whole HBM.
+    profiles/r2_pmc_calibration.txt).  Runs AFTER the timed region, once this process has released its device memory.
     Returns ({kernel key: bytes per launch}, note) or (None, reason)."""
     import csv, glob, shutil, signal, subprocess, tempfile
     exe = shutil.which("rocprofv3")
@@ -186,18 +186,16 @@ def main():
                     help="halo exchange through torch.distributed (RCCL process group, default) or through the C-ABI's own RCCL "
                          "context (tv_ctx_create / tv_halo_exchange; torch.distributed only hands out the unique id)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
-                    help="auto (1 GPU only): measure roofline.traffic live with two rocprofv3 --pmc child passes before the timed run; "
+                    help="auto (1 GPU only): measure roofline.traffic live with two rocprofv3 --pmc child passes after the timed run; "
                          "off: copy the committed numbers of profiles/traffic.json and label them STATIC")
     args = ap.parse_args()
 
     live, live_note = None, "--pmc off"
+    want_live = False
     if args.pmc == "auto":
-        if args.gpus == 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("TV_BENCH_PMC", "1") != "0":
-            try:
-                live, live_note = live_traffic(args)
-            except Exception as e:          # the profiler is evidence, not the product: never let it take the bench down
-                live, live_note = None, "live PMC passes failed: %r" % (e,)
-        else:
+        want_live = (args.gpus == 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1
+                     and os.environ.get("TV_BENCH_PMC", "1") != "0")
+        if not want_live:
             live_note = "PMC passes run with one GPU only"
 
     import torch
@@ -299,14 +297,25 @@ def main():
         traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s|%s" % (args.workload, args.scheme), {})
     except Exception:
         pass
-    traffic_source = "STATIC, not measured in this run (%s): %s" % (live_note, traffic.get("source"))
-    if live is not None:
-        traffic, traffic_source = live, live_note
     torch.cuda.synchronize()
     t_k1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
     t_k2 = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    cp_fused = bool(cp.fused)
+    if want_live:
+        # AFTER the timed region, with this process's device memory handed back: the child passes need the HBM for the same
+        # volume, and a process that starts right after another one released ~100 GB can run 5 - 7 % slower for its whole life
+        #  -- the children do not care, the timed run above would
+        del cp, x0, ev, hist, hist_r
+        torch.cuda.empty_cache()
+        try:
+            live, live_note = live_traffic(args)
+        except Exception as e:              # the profiler is evidence, not the product: never let it take the bench down
+            live, live_note = None, "live PMC passes failed: %r" % (e,)
+    traffic_source = "STATIC, not measured in this run (%s): %s" % (live_note, traffic.get("source"))
+    if live is not None:
+        traffic, traffic_source = live, live_note
     sharded = " (per GPU; kernel 2 interval includes the halo wait)" if world > 1 else ""
-    if cp.fused:
+    if cp_fused:
         b_k1 = 4.0 * (5 + 2 * nd) * V_local      # read x, x0, p, q ; write q, x, p
         out["config"]["kernels"] = "one-sweep: tv_cp_fused + tv_cp_fixup"
         out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_fused: k_cp_fused<S,M> (dual update + lagged primal update, one pass over q)",
@@ -337,7 +346,8 @@ def main():
     if dist.is_initialized():
         dist.barrier()          # the other ranks wait at the final barrier while rank 0 times the host baseline
     if rank == 0 and not args.no_cpu_baseline:
-        del cp, x0
+        if not want_live:
+            del cp, x0
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(shape, wl["reg_z"], wl["reg_time"], nd)
         try:
