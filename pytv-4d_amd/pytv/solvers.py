@@ -143,12 +143,12 @@ class ChambollePock(_SlabProblem):
         self.qh_prev = self.new_plane() if pl.g_need_prev else None
         self.qh_next = self.new_plane() if pl.g_need_next else None
         if fused is None:
-            # one-sweep kernel where supported -- except on small planes (z / t neighbours stay L2-resident there and
-            # the one-site-per-thread kernel pair is faster: 840 vs 778 it/s on 256x1x512x512); same threshold and
-            # override (TV_MARCH_MIN_PLANE_KB) as the marching kernels
-            min_plane = _nv.get_option("TV_MARCH_MIN_PLANE_KB", 4096) * 1024
-            plane_bytes = self.geo.plane * self.x0.element_size()
-            fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) and plane_bytes >= min_plane
+            # one-sweep kernel where supported -- except on volumes so small that an iteration is launch-bound, where the
+            # kernel pair has fewer launches (tools/fused_vs_pair.py: the pair is ~10 % faster at <= 4 Mvoxel, the one-sweep
+            # path 1.15 - 1.25 x faster from 16 Mvoxel on, whatever the plane size: 256x1x512x512 runs 990 - 1040 it/s
+            # against 870).  Option TV_FUSED_MIN_KVOXELS (thousands of voxels of this rank's slab) moves the switch.
+            min_vox = 1024 * _nv.get_option("TV_FUSED_MIN_KVOXELS", 8192)
+            fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) and self.x0.numel() >= min_vox
         self.fused = bool(fused)
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
             raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry (tv_cp_fused_supported: "

@@ -14,6 +14,7 @@ from oracle import tv_oracle as orc
 pytestmark = pytest.mark.gpu
 
 os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+os.environ["TV_FUSED_MIN_KVOXELS"] = "0"      # small test volumes take the one-sweep Chambolle-Pock path too
 
 SHAPES = [(7, 3, 9, 256), (6, 2, 5, 132), (9, 8, 6, 192), (3, 16, 5, 128), (4, 12, 7, 64), (1, 1, 33, 68), (1, 4, 8, 64), (8, 5, 3, 64),
           (1, 20, 2, 72), (11, 1, 1, 260), (5, 3, 8, 12)]

@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 # exercise the plane-marching kernels on the small test shapes too (production threshold: 4 MiB planes)
 os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+os.environ["TV_FUSED_MIN_KVOXELS"] = "0"      # small test volumes take the one-sweep Chambolle-Pock path too
 
 
 def _free_port():

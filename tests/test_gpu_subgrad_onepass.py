@@ -12,6 +12,7 @@ from oracle import tv_oracle as orc
 
 pytestmark = pytest.mark.gpu
 os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+os.environ["TV_FUSED_MIN_KVOXELS"] = "0"      # small test volumes take the one-sweep Chambolle-Pock path too
 
 ONE_PASS_SCHEMES = ["upwind", "downwind", "hybrid", "central"]
 F32 = dict(rtol=1e-5, atol=1e-5)

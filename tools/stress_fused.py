@@ -6,6 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
 os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+os.environ["TV_FUSED_MIN_KVOXELS"] = "0"
 import torch, pytv
 rng = np.random.default_rng(0)
 shapes = [(7, 8, 9, 320), (5, 3, 13, 260), (33, 8, 64, 512), (4, 4, 6, 1028), (9, 2, 31, 68),

@@ -5,6 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
 os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+os.environ["TV_FUSED_MIN_KVOXELS"] = "0"
 import numpy as np, torch, pytv
 from pytv import _native as nv
 from oracle import tv_oracle as orc
