@@ -26,6 +26,29 @@ template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
     return fail(TV_E_ARG, "unsupported (scheme, M) for the one-sweep path");
 }
 
+// planes per z-chunk of the one-sweep path (sweep, fix-up and the host's interior-first schedule share it): its blocks are
+// CP_TR rows x CP_BC columns, half as many per plane as the marching kernels' -- with march_zchunk's rule (round 1) BASELINE
+// config 2 ran on 8-plane chunks and config 1 on 16, 3 - 5 % slower than with 16 - 32 / 32 - 64 (tools/ab_cp.py --shape).
+// Long chunks mean fewer chunk-edge fix-up planes; >= ~1024 blocks keep the 256 CUs busy for several rounds; a slab (one rank
+// of a sharded volume) keeps >= 4 chunks so that the halo exchanges can hide behind interior chunks.  TV_ZCHUNK overrides.
+static int fused_zchunk(const DG& d) {
+    int zc = env_int("TV_ZCHUNK", 0);
+    if (zc <= 0) {
+        const long long tiles = (long long)((d.nx / 4 + CP_NW * CP_TL - 1) / (CP_NW * CP_TL)) * ((d.ny + CP_TR - 1) / CP_TR);
+        const long long want = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);
+        zc = (int)(d.nz / (want > 0 ? want : 1));
+        if (zc > 32) zc = 32;
+        if (zc < 8) zc = 8;
+        if (d.nz < d.nzg) {                              // a slab: interior chunks for the overlap
+            const int q4 = (int)(d.nz / 4);
+            if (zc > q4) zc = q4 < 4 ? 4 : q4;
+        }
+    }
+    if (zc < 1) zc = 1;
+    if (zc > d.nz) zc = (int)d.nz;
+    return zc;
+}
+
 namespace tvm {
 bool subgrad_pass2_ok(const tv_geom* g, const DG& d) { return g->scheme != TV_CENTRAL && d.m >= 1 && d.m <= 8; }
 int subgrad_pass2(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st,
@@ -61,7 +84,7 @@ int tv_cp_fused_supported(const tv_geom* g) {
 int tv_cp_zchunk(const tv_geom* g) {
     DG d;
     if (int rc = make_dg(g, d)) return rc;
-    return march_zchunk(d);
+    return fused_zchunk(d);
 }
 
 int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* x0,
@@ -76,7 +99,7 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     if (!aligned16({x_in, x_prev, x_next, q, x0, p, x_out})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    const int zc = march_zchunk(d);
+    const int zc = fused_zchunk(d);
     {   // halos are only needed by the chunks that touch the slab boundary
         const long long nch_all = (d.nz + zc - 1) / zc;
         const long long cb = (chunk_count < 0) ? 0 : chunk_begin, ce = (chunk_count < 0) ? nch_all : chunk_begin + chunk_count;
@@ -137,7 +160,7 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     if (!aligned16({q, q_prev, q_next, x_out, x0})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    const int zc = march_zchunk(d);
+    const int zc = fused_zchunk(d);
     if (z_count < 0) { z_begin = 0; z_count = d.nz; }
     if (z_begin < 0 || z_begin + z_count > d.nz) return fail(TV_E_ARG, "plane range outside the slab");
     if (z_count == 0) {
