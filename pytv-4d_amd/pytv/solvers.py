@@ -143,11 +143,13 @@ class ChambollePock(_SlabProblem):
         self.qh_prev = self.new_plane() if pl.g_need_prev else None
         self.qh_next = self.new_plane() if pl.g_need_next else None
         if fused is None:
-            # one-sweep kernel where supported -- except on volumes so small that an iteration is launch-bound, where the
-            # kernel pair has fewer launches (tools/fused_vs_pair.py: the pair is ~10 % faster at <= 4 Mvoxel, the one-sweep
-            # path 1.15 - 1.25 x faster from 16 Mvoxel on, whatever the plane size: 256x1x512x512 runs 990 - 1040 it/s
-            # against 870).  Option TV_FUSED_MIN_KVOXELS (thousands of voxels of this rank's slab) moves the switch.
-            min_vox = 1024 * _nv.get_option("TV_FUSED_MIN_KVOXELS", 8192)
+            # one-sweep kernel where supported -- except on volumes too small to fill the GPU with its blocks (8 rows x 256
+            # columns x >= 8 planes x all frames each: a block holds >= 16 k x M voxels and a CU takes 8 / M of them, so
+            # 256 CUs want >= 33 Mvoxel for one full round; tools/fused_vs_pair.py: 0.5 - 0.7 x of the kernel pair at
+            # 6 - 8 Mvoxel with few planes, break-even at 8 - 13 Mvoxel, 1.15 - 1.25 x faster from 16 Mvoxel on whatever
+            # the plane size -- 256x1x512x512 runs 990 - 1040 it/s against 870).  Option TV_FUSED_MIN_KVOXELS (thousands of
+            # voxels of this rank's slab) moves the switch.
+            min_vox = 1024 * _nv.get_option("TV_FUSED_MIN_KVOXELS", 16384)
             fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) and self.x0.numel() >= min_vox
         self.fused = bool(fused)
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
