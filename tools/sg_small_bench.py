@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""TV + sub-gradient: the one-pass kernel against the two-pass forms on small and mid-size volumes.
+usage: python tools/sg_small_bench.py [NzxMxNyxNx ...]"""
 import sys, os, time
-sys.path.insert(0, "pytv-4d_amd"); sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
 import torch, pytv
 def bench(f, reps=20):
     f(); torch.cuda.synchronize()
@@ -8,7 +12,8 @@ def bench(f, reps=20):
     for _ in range(reps): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
-for shape in [(1,1,512,512), (1,1,2048,2048), (256,1,512,512), (128,8,512,512), (64,1,1024,1024), (16,4,256,256), (32,2,1024,1024)]:
+SHAPES = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(1,1,512,512), (1,1,2048,2048), (256,1,512,512), (128,8,512,512), (64,1,1024,1024), (16,4,256,256), (32,2,1024,1024)]
+for shape in SHAPES:
     x = torch.rand(shape, device="cuda") * 100
     for scheme in ("hybrid", "upwind"):
         kw = dict(reg_time=1.0 if shape[1] > 1 else 0.0)
