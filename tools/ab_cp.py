@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process interleaved A/B of Chambolle-Pock variants on the north-star shape (the knobs go through
-tv_set_option).  usage: python tools/ab_cp.py NAME=ENV1=V1,ENV2=V2 NAME2=... [--rounds 4] [--shape ...]"""
+tv_set_option).  usage: python tools/ab_cp.py NAME=ENV1=V1,ENV2=V2 NAME2=... [--rounds 4] [--shape ...] [--scheme hybrid]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,7 @@ from bench import synth_slab
 args = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 4
 shape = tuple(int(v) for v in sys.argv[sys.argv.index("--shape") + 1].split("x")) if "--shape" in sys.argv else (256, 8, 1024, 1024)
+scheme = sys.argv[sys.argv.index("--scheme") + 1] if "--scheme" in sys.argv else "hybrid"
 variants = []
 for a in args:
     name, rest = a.split("=", 1)
@@ -23,7 +24,7 @@ for r in range(rounds):
             if k.startswith("TV_"):
                 pytv._native.set_option(k, int(v))
         fused = None if env.get("FUSED", "1") == "1" else False
-        cp = pytv.solvers.ChambollePock(x0, 25.0, reg_time=1.0, fused=fused)
+        cp = pytv.solvers.ChambollePock(x0, 25.0, scheme=scheme, reg_time=1.0 if shape[1] > 1 else 0.0, fused=fused)
         for _ in range(2):
             cp.step()
         cp.timing = []
