@@ -37,7 +37,19 @@ def pytv():
 def production(tvopt):
     """The library's own dispatch (other test modules lower the marching threshold for their small shapes)."""
     tvopt("TV_MARCH_MIN_PLANE_KB", 4096)
+    tvopt("TV_FUSED_MIN_KVOXELS", 16384)
     tvopt("TV_ZCHUNK", 0)
+
+
+def test_default_cp_path_follows_the_voxel_count(pytv, production):
+    """solvers.ChambollePock(fused=None): the one-sweep path from 16 Mvoxel per slab on, whatever the plane size (round 1's
+    plane-size rule kept BASELINE config 1 on the slower kernel pair); the kernel pair below (tools/fused_vs_pair.py)."""
+    import torch
+    for shape, want in (((16, 4, 256, 256), False), ((32, 8, 256, 256), True), ((64, 1, 512, 512), True), ((8, 1, 1024, 1024), False)):
+        cp = pytv.solvers.ChambollePock(torch.zeros(shape, device="cuda"), 25.0)
+        assert cp.fused == want, (shape, cp.fused)
+        del cp
+    torch.cuda.empty_cache()
 
 
 def _noisy_dev(shape, seed):
