@@ -32,7 +32,8 @@ static float* to_device(const std::vector<float>& h) {
 }
 
 int main() {
-    tv_geom g{};
+    tv_geom g;
+    tv_geom_init(&g);            // zeroes the struct and stamps it with sizeof(tv_geom) / TV_ABI_VERSION
     g.nz = 6; g.m = 4; g.ny = 40; g.nx = 128;
     g.nz_global = g.nz; g.z0 = 0;
     g.scheme = TV_HYBRID; g.dtype = TV_F32;

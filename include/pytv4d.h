@@ -44,7 +44,17 @@ extern "C" {
 /* Geometry and weights of one z-slab.  Mirrors the keyword arguments every reference operator
  * takes: reg_z_over_reg, reg_time, mask_static, factor_reg_static
  * (pytv/tv_operators_GPU.py:134,253,362,471,583,719,828,938; pytv/tv_GPU.py:47,142,217,290). */
+/* Version of the binary interface declared in this header: bumped whenever tv_geom, the workspace layout or the
+ * meaning of an entry point's arguments changes incompatibly (round 1: 1; round 2 added the three weight-volume
+ * pointers and a second partial-sum array in the workspace: 2; round 3 added the two leading fields below: 3).
+ * Every entry point that takes a tv_geom rejects a struct whose struct_size / abi_version are not the library's own
+ * with TV_E_ARG -- a host built against an older header fails loudly instead of having its trailing fields read as
+ * garbage.  tv_geom_init() fills the two fields in. */
+#define TV_ABI_VERSION 3
+
 typedef struct tv_geom {
+    uint32_t struct_size;       /* sizeof(tv_geom) of the header the HOST was compiled against   */
+    uint32_t abi_version;       /* TV_ABI_VERSION of that header                                  */
     int64_t nz;                 /* planes held by this rank                                  */
     int64_t m, ny, nx;          /* time frames, rows, cols                                   */
     int64_t nz_global;          /* planes of the whole volume (== nz when not sharded)       */
@@ -74,9 +84,18 @@ typedef struct tv_geom {
     const void* time_weight_next;/* ghost-plane norms of tv_subgrad on a slab read them                                       */
 } tv_geom;
 
+/* zero a tv_geom and stamp it with the header's struct size and interface version */
+static inline void tv_geom_init(tv_geom* g) {
+    unsigned char* b = (unsigned char*)g;
+    for (size_t i = 0; i < sizeof(tv_geom); ++i) b[i] = 0;
+    g->struct_size = (uint32_t)sizeof(tv_geom);
+    g->abi_version = TV_ABI_VERSION;
+}
+
 /* ---- housekeeping ------------------------------------------------------------------------ */
 const char* tv_last_error(void);
 int         tv_version(void);                         /* 10000*major + 100*minor + patch     */
+int         tv_abi_version(void);                     /* TV_ABI_VERSION the library was built with */
 /* Tuning / debugging options (TV_ZCHUNK, TV_NO_FUSED, ...: DESIGN.md section 7).  The table is process-wide and explicit:
  * every entry is initialised ONCE from the environment variable of the same name when the library first consults it,
  * and afterwards changes only through these calls -- no entry point reads the environment per call.

@@ -36,6 +36,9 @@ inline int hipfail(hipError_t e, const char* where) {
 
 inline int make_dg(const tv_geom* g, DG& d) {
     if (g == nullptr) return fail(TV_E_ARG, "tv_geom is NULL");
+    if (g->struct_size != (uint32_t)sizeof(tv_geom) || g->abi_version != TV_ABI_VERSION)
+        return fail(TV_E_ARG, "tv_geom was built against another version of pytv4d.h (struct_size / abi_version mismatch): "
+                              "rebuild the host against this library's header and call tv_geom_init()");
     if (g->nz < 1 || g->m < 1 || g->ny < 1 || g->nx < 1) return fail(TV_E_ARG, "every dimension must be >= 1");
     if (g->nz_global < g->nz || g->z0 < 0 || g->z0 + g->nz > g->nz_global)
         return fail(TV_E_ARG, "slab [z0, z0+nz) must lie inside [0, nz_global)");

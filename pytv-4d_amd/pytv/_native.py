@@ -26,6 +26,7 @@ _c_double_p = ctypes.c_void_p   # device pointers to fp64 scalars are passed as 
 class TvGeom(ctypes.Structure):
     """struct tv_geom of include/pytv4d.h"""
     _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("abi_version", ctypes.c_uint32),
         ("nz", ctypes.c_int64), ("m", ctypes.c_int64), ("ny", ctypes.c_int64), ("nx", ctypes.c_int64),
         ("nz_global", ctypes.c_int64), ("z0", ctypes.c_int64),
         ("scheme", ctypes.c_int32), ("dtype", ctypes.c_int32),
@@ -38,11 +39,23 @@ class TvGeom(ctypes.Structure):
     ]
 
 
+ABI_VERSION = 3      # TV_ABI_VERSION of include/pytv4d.h this binding was written against
+
+
+def new_geom():
+    """A zeroed ``tv_geom`` stamped with this binding's struct size and interface version (tv_geom_init of the header)."""
+    g = TvGeom()
+    g.struct_size = ctypes.sizeof(TvGeom)
+    g.abi_version = ABI_VERSION
+    return g
+
+
 _G = ctypes.POINTER(TvGeom)
 _SIGNATURES = {
     # name: (restype, argtypes)
     "tv_last_error": (ctypes.c_char_p, []),
     "tv_version": (ctypes.c_int, []),
+    "tv_abi_version": (ctypes.c_int, []),
     "tv_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "tv_unset_option": (ctypes.c_int, [ctypes.c_char_p]),
     "tv_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
@@ -101,6 +114,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.tv_abi_version() != ABI_VERSION:
+            raise ImportError("pytv: %s implements interface version %d, this binding %d -- rebuild the library "
+                              "(python pytv-4d_amd/build.py --force)" % (LIB_PATH, handle.tv_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 
@@ -199,7 +215,7 @@ class Geometry:
                 self.mask_dev = mk.to(torch.uint8).contiguous().to(self.device)
                 if bool(mk.any()):
                     self.time_weight_max = float(factor_reg_static) if bool(mk.all()) else max(1.0, float(factor_reg_static))
-        g = TvGeom()
+        g = new_geom()
         g.nz, g.m, g.ny, g.nx = nz, m, ny, nx
         g.nz_global = nz if nz_global is None else int(nz_global)
         g.z0 = int(z0)

@@ -682,7 +682,7 @@ class ADMM(_SlabProblem):
             sc[1:2].copy_(self.dots[0:1])
             s.allreduce_sum_(sc[0:2])
         if self.n_cg == 0:
-            out[1:2] = 0.5 * torch.sum((self.x.double() - self.x0.double()) ** 2)
+            out[1:2] = torch.sum((self.x.double() - self.x0.double()) ** 2)     # the slot holds |x - x0|^2: run() halves it
         else:
             out[1:2].mul_(2.0)                        # run() halves: the slot holds |x - x0|^2 like the textbook path
         self._zu(out[0:1])

@@ -16,6 +16,8 @@ square (the reference uses ``N = img.shape[-1]`` for both axes); the GPU twin's 
 (N >= 3 / 5) do not apply; ``central`` with Nz == 2 uses the forward z stencil instead
 of raising.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -43,7 +45,11 @@ def _to_device(arr):
     return t, was_torch
 
 
-_PIN_MIN, _PIN_MAX = 1 << 20, 16 << 30
+# results between these sizes come back through pinned host memory; PYTV_PIN_MAX_MB=0 switches the pinned path off
+# (page-locked memory is a limited resource in containers / under `ulimit -l`, and the caching host allocator keeps
+# the blocks)
+_PIN_MIN = 1 << 20
+_PIN_MAX = int(float(os.environ.get("PYTV_PIN_MAX_MB", 16 << 10)) * (1 << 20))
 
 
 def _to_host(t):
@@ -55,10 +61,14 @@ def _to_host(t):
     t = t.detach()
     nbytes = t.numel() * t.element_size()
     if t.is_cuda and _PIN_MIN <= nbytes <= _PIN_MAX:
-        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        h.copy_(t, non_blocking=True)
-        torch.cuda.current_stream(t.device).synchronize()
-        return h.numpy()
+        try:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        except RuntimeError:              # page-locking refused (ulimit -l, container limits, host memory): pageable copy
+            h = None
+        if h is not None:
+            h.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+            return h.numpy()
     return t.cpu().numpy()
 
 

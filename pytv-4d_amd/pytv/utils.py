@@ -4,6 +4,7 @@ README loops start from (README.md:113,141).  The image file is the reference's 
 it there, or takes scikit-image's ``camera()`` (512 x 512, averaged 2 x 2 down to 256 x 256) when that package is
 installed; otherwise it says exactly that."""
 import os
+import warnings
 
 import numpy as np
 
@@ -22,5 +23,8 @@ def cameraman():
         raise FileNotFoundError(
             "pytv.utils.cameraman(): the reference's media/cameraman.npy is not shipped with this package. Set PYTV_CAMERAMAN "
             "to a 256 x 256 .npy image, copy the reference's file to %s, or install scikit-image." % os.path.join(here, "media", "cameraman.npy"))
+    warnings.warn("pytv.utils.cameraman(): the reference's media/cameraman.npy is not available; returning scikit-image's "
+                  "camera() averaged 2 x 2 down to 256 x 256 -- a DIFFERENT photograph: TV and loss values will not match the "
+                  "numbers of the reference's README.  Set PYTV_CAMERAMAN to the reference's file to compare.", stacklevel=2)
     img = np.asarray(data.camera(), dtype=np.float64)
     return img.reshape(256, 2, 256, 2).mean(axis=(1, 3)).astype(np.int64)

@@ -164,8 +164,34 @@ def gen_trajectories():
     print("wrote trajectories_2d.npz")
 
 
+def gen_trajectory_512():
+    """BASELINE configs[0] at its SIZE (512 x 512, hybrid sub-gradient loop, 300 iterations, README.md:107-124) on a
+    synthetic phantom -- the cameraman image itself is the reference's data and stays in /root/reference
+    (tests/test_oracle_vs_reference.py pins the oracle on it in the authoring container).  Only the phantom (it
+    compresses), the seed and the outputs are stored: the noise is np.random.RandomState(0).rand, which NumPy keeps
+    bit-stable across versions."""
+    noise_level, nb_it, regularization, step_size = 100, 300, 25, 5e-3
+    truth = phantom2d(512, 11).reshape(1, 1, 512, 512)
+    np.random.seed(0)
+    noisy = truth + noise_level * np.random.rand(*truth.shape)
+    assert np.array_equal(noisy, truth + noise_level * np.random.RandomState(0).rand(*truth.shape))
+    est = np.copy(noisy)
+    loss = np.zeros([nb_it, ])
+    for it in range(nb_it):
+        tvv, G = tvc.tv_hybrid(est)
+        est += - step_size * ((est - noisy) + regularization * G)
+        loss[it] = 0.5 * np.sum(np.square(est - noisy)) + regularization * tvv
+    np.savez_compressed(os.path.join(OUT, "trajectory_512.npz"), truth=truth,
+                        params=np.array([noise_level, nb_it, regularization, step_size, 0], dtype=np.float64),
+                        gd_loss_hybrid=loss, gd_final_mean=np.array(est.mean()), gd_final_row=est[0, 0, 200].copy(),
+                        noisy_checksum=np.array(noisy.sum()))
+    print("wrote trajectory_512.npz")
+
+
 if __name__ == "__main__":
-    gen_ops()
-    gen_known_answers()
-    gen_trajectories()
+    if "--only-512" not in sys.argv:
+        gen_ops()
+        gen_known_answers()
+        gen_trajectories()
+    gen_trajectory_512()
     sys.exit(0)

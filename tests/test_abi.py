@@ -40,9 +40,32 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from pytv import _native as nv
-    # 6 x int64 + 2 x int32 + 3 x double + pointer, no padding surprises
-    assert ctypes.sizeof(nv.TvGeom) == 6 * 8 + 2 * 4 + 3 * 8 + 8 + 8 + 3 * 8
-    assert nv.TvGeom.scheme.offset == 48 and nv.TvGeom.reg_z_over_reg.offset == 56 and nv.TvGeom.mask_static.offset == 80 and nv.TvGeom.time_factor.offset == 88 and nv.TvGeom.time_weight_vol.offset == 96 and nv.TvGeom.time_weight_next.offset == 112
+    # 2 x uint32 (struct_size, abi_version) + 6 x int64 + 2 x int32 + 3 x double + 5 pointers, no padding surprises
+    assert ctypes.sizeof(nv.TvGeom) == 8 + 6 * 8 + 2 * 4 + 3 * 8 + 8 + 8 + 3 * 8
+    assert nv.TvGeom.struct_size.offset == 0 and nv.TvGeom.abi_version.offset == 4 and nv.TvGeom.nz.offset == 8
+    assert nv.TvGeom.scheme.offset == 56 and nv.TvGeom.reg_z_over_reg.offset == 64 and nv.TvGeom.mask_static.offset == 88 and nv.TvGeom.time_factor.offset == 96 and nv.TvGeom.time_weight_vol.offset == 104 and nv.TvGeom.time_weight_next.offset == 120
+
+
+def test_struct_version_stamp_is_enforced():
+    """round-2 advice: the C-ABI changed incompatibly while tv_version() stood still.  tv_geom now starts with its own
+    size and the interface version; a struct from another header is refused by every entry point, not mis-read."""
+    from pytv import _native as nv
+    lib = nv.lib()
+    assert lib.tv_version() >= 300 and lib.tv_abi_version() == nv.ABI_VERSION
+    # the header and the binding agree on the number
+    hdr = open(os.path.join(ROOT, "include", "pytv4d.h")).read()
+    assert "#define TV_ABI_VERSION %d" % nv.ABI_VERSION in hdr
+    g = nv.new_geom()
+    g.nz, g.m, g.ny, g.nx, g.nz_global, g.z0 = 4, 1, 8, 8, 4, 0
+    assert lib.tv_num_channels(ctypes.byref(g)) == 2
+    for field, val in (("struct_size", ctypes.sizeof(nv.TvGeom) - 24), ("struct_size", 0), ("abi_version", nv.ABI_VERSION - 1), ("abi_version", 0)):
+        h = nv.new_geom()
+        h.nz, h.m, h.ny, h.nx, h.nz_global, h.z0 = 4, 1, 8, 8, 4, 0
+        setattr(h, field, val)
+        assert lib.tv_num_channels(ctypes.byref(h)) == -1
+        assert b"pytv4d.h" in lib.tv_last_error()
+        assert lib.tv_workspace_bytes(ctypes.byref(h)) == 0
+        assert lib.tv_D(ctypes.byref(h), None, None, None, None, None) == -1
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
@@ -53,7 +76,7 @@ def test_channel_count_rule_matches_oracle(scheme):
         for m in (1, 2, 5):
             for lz in (0.0, 1.0, 2.5):
                 for mu in (0.0, 0.7):
-                    g = nv.TvGeom()
+                    g = nv.new_geom()
                     g.nz, g.m, g.ny, g.nx, g.nz_global, g.z0 = nz, m, 6, 6, nz, 0
                     g.scheme, g.dtype = nv.SCHEMES[scheme], 0
                     g.reg_z_over_reg, g.reg_time = lz, mu
@@ -63,7 +86,7 @@ def test_channel_count_rule_matches_oracle(scheme):
 def test_argument_errors_are_reported_not_thrown():
     from pytv import _native as nv
     lib = nv.lib()
-    g = nv.TvGeom()
+    g = nv.new_geom()
     g.nz, g.m, g.ny, g.nx, g.nz_global, g.z0 = 4, 1, 8, 8, 4, 0
     g.scheme, g.dtype = 9, 0
     assert lib.tv_num_channels(ctypes.byref(g)) == -1

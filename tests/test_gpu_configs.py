@@ -337,3 +337,23 @@ def test_subgradient_descent_300_iterations_against_the_reference_golden(pytv, s
     assert len(loss) == len(want) == 300
     np.testing.assert_allclose(loss[:40], want[:40], rtol=2e-5 if one_pass else 1e-9)
     np.testing.assert_allclose(loss, want, rtol=1e-3)
+
+
+@pytest.mark.parametrize("one_pass", [True, False])
+def test_subgradient_descent_at_config0_size_against_the_reference_golden(pytv, one_pass):
+    """BASELINE configs[0] at its size: 512 x 512, hybrid, 300 iterations -- the loss curve the REAL reference produced
+    (tests/golden/trajectory_512.npz, make_golden.py gen_trajectory_512) against the device-resident solver, one-pass
+    (fp32) and two-pass (fp64) kernels."""
+    import torch
+    from test_oracle_golden import load_trajectory_512
+    z, noisy, nb_it, reg, step = load_trajectory_512()
+    want = z["gd_loss_hybrid"]
+    x0 = torch.as_tensor(noisy).cuda()
+    if one_pass:
+        x0 = x0.float()
+    sg = pytv.solvers.SubgradientDescent(x0, reg, step, scheme="hybrid", one_pass=one_pass)
+    assert sg.one_pass == one_pass
+    loss = sg.run(nb_it)
+    np.testing.assert_allclose(loss[:40], want[:40], rtol=2e-5 if one_pass else 1e-9)
+    np.testing.assert_allclose(loss, want, rtol=1e-3)
+    assert abs(float(sg.x.double().mean()) - float(z["gd_final_mean"])) < 1e-2

@@ -129,6 +129,29 @@ def test_readme_loops_2d(scheme):
     np.testing.assert_allclose(x, z["cp_final_" + scheme], rtol=1e-8, atol=1e-8)
 
 
+def load_trajectory_512():
+    """inputs of tests/golden/trajectory_512.npz: the stored phantom plus the seeded noise (legacy RandomState: bit-stable)"""
+    z = np.load(os.path.join(GOLDEN, "trajectory_512.npz"))
+    truth = z["truth"]
+    noise_level, nb_it, reg, step, seed = z["params"]
+    noisy = truth + noise_level * np.random.RandomState(int(seed)).rand(*truth.shape)
+    assert noisy.shape == (1, 1, 512, 512) and noisy.sum() == float(z["noisy_checksum"])
+    return z, noisy, int(nb_it), float(reg), float(step)
+
+
+def test_readme_subgradient_loop_at_config0_size():
+    """BASELINE configs[0] is a 512 x 512 image: the reference's own 300-iteration hybrid loop at that size
+    (make_golden.py gen_trajectory_512) against the oracle.  Same head / tail bounds as the 64 x 64 case."""
+    z, noisy, nb_it, reg, step = load_trajectory_512()
+    x, loss = orc.subgradient_descent(noisy, nb_it, reg, step, scheme="hybrid")
+    want = z["gd_loss_hybrid"]
+    np.testing.assert_allclose(loss[:60], want[:60], rtol=1e-11)
+    np.testing.assert_allclose(loss, want, rtol=1e-3)
+    assert np.all(np.diff(loss) < 0)
+    assert abs(x.mean() - float(z["gd_final_mean"])) < 1e-3
+    np.testing.assert_allclose(x[0, 0, 200], z["gd_final_row"], atol=2.0)       # chaotic tail: pixels move by O(step * reg)
+
+
 # ---- structural invariants restated from pytv/tests.py ------------------------------------
 GEOMS = [((1, 1, 12, 12), 1.0, 0.0), ((6, 1, 10, 10), 1.0, 0.0), ((6, 1, 10, 10), 0.0, 0.0)] + \
         [((1, m, 9, 9), 1.0, 1.0) for m in (2, 3, 4, 8)] + \

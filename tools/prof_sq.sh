@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o p -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $OUT/pmc$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o p -- python3 $R/bench.py --no-cpu-baseline --pmc off --steps 2 --warmup 1 "$@" > $OUT/pmc$i.log 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, collections, glob, json, sys
