@@ -188,7 +188,12 @@ def main():
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto (1 GPU only): measure roofline.traffic live with two rocprofv3 --pmc child passes after the timed run; "
                          "off: copy the committed numbers of profiles/traffic.json and label them STATIC")
+    ap.add_argument("--phases", action="store_true", help="per-phase HIP-event times of the schedule in the JSON line (always on at N > 1)")
     args = ap.parse_args()
+    # must be in the environment BEFORE the HIP runtime starts (the pool's driver only supports dmabuf IPC; RCCL's
+    # cross-process buffer sharing fails with hipIpcGetMemHandle: invalid argument otherwise).  Round 2 set it after
+    # torch.cuda.set_device(), where it could no longer take effect.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     live, live_note = None, "--pmc off"
     want_live = False
@@ -216,22 +221,42 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())      # launchers that pin one visible device per rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1 or "RANK" in os.environ:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL on ROCm
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
     wl = WORKLOADS[args.workload]
     shape = wl["shape"]
     native = None
-    if args.comm == "cabi" and dist.is_initialized() and world > 1:
-        from pytv.slab import NativeComm
-        native = NativeComm(device=device)
-    slab = Slab(shape[0], rank=rank, world=world, native_comm=native)
+    comm_name = "none (one process, no process group)"
+    try:
+        if world > 1 or "RANK" in os.environ:
+            import datetime
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            tmo = datetime.timedelta(seconds=int(os.environ.get("TV_BENCH_INIT_TIMEOUT", "300")))
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=tmo)   # RCCL on ROCm
+                comm_name = "torch.distributed nccl (= RCCL): batch_isend_irecv halos, device all-reduces"
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+                comm_name = "torch.distributed %s (TEST backend: host-staged halos)" % backend
+        if args.comm == "cabi" and dist.is_initialized() and world > 1:
+            from pytv.slab import NativeComm
+            native = NativeComm(device=device)
+            comm_name = "C-ABI RCCL context (tv_ctx_create / tv_halo_exchange / tv_allreduce_f64); unique id handed out over torch.distributed " + dist.get_backend()
+        slab = Slab(shape[0], rank=rank, world=world, native_comm=native)
+        if dist.is_initialized():
+            # first contact with the transport BEFORE any work is queued: a failure here is reported as such
+            probe = torch.ones(1, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            assert int(probe.item()) == world, "all-reduce over %d ranks returned %r" % (world, probe.item())
+    except Exception as exc:              # noqa: BLE001 -- whatever the transport throws: say so in the JSON line, fail the run
+        if rank == 0:
+            print(json.dumps({"metric": "chambolle_pock_iters_per_sec", "value": None, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                              "data": "synthetic", "config": {"workload": args.workload}, "comm": comm_name,
+                              "error": "communicator setup failed on rank %d of %d (backend %s, comm %s): %s: %s"
+                                       % (rank, world, backend, args.comm, type(exc).__name__, str(exc)[:600])}), flush=True)
+        sys.stderr.write("[bench rank %d] communicator setup failed: %r\n" % (rank, exc))
+        sys.stderr.flush()
+        os._exit(3)                       # every rank that fails exits non-zero at once (no destructor tries the dead communicator)
     x0 = synth_slab(shape, slab.z0, slab.nz, device)
     cp = pytv.solvers.ChambollePock(x0, 25.0, scheme=args.scheme, reg_z_over_reg=wl["reg_z"], reg_time=wl["reg_time"],
                                     slab=slab, overlap=not args.no_overlap, fused=False if args.two_kernel else None)
@@ -249,6 +274,9 @@ def main():
         cp.step(hist[it])
     # per-kernel HIP events on the launch stream (torch's current stream == the stream the C-ABI enqueues on)
     cp.timing = []
+    want_phases = args.phases or world > 1
+    if want_phases:
+        cp.phase_timing = []      # one event per phase boundary of the schedule (interior / wait / edges ...), see solvers.py
 
     barrier()
     t0 = time.perf_counter()
@@ -258,6 +286,22 @@ def main():
     elapsed = time.perf_counter() - t0
     ev = cp.timing[:K]
     cp.timing = None
+    phases = None
+    if want_phases:
+        pm = pytv.solvers.ChambollePock.phase_means_ms(cp.phase_timing[:K])
+        cp.phase_timing = None
+        names = list(pm)
+        pt = torch.tensor([pm[k] for k in names], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        pmax, psum = pt.clone(), pt.clone()
+        if dist.is_initialized():
+            dist.all_reduce(pmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(psum, op=dist.ReduceOp.SUM)
+        phases = {"unit": "ms per step", "max_over_ranks": {k: float(v) for k, v in zip(names, pmax.tolist())},
+                  "mean_over_ranks": {k: float(v) / world for k, v in zip(names, psum.tolist())},
+                  "rank0": pm,
+                  "note": "HIP events on the launch stream at every phase boundary of the schedule (pytv/solvers.py _step_fused / step); "
+                          "*_halo_wait_exposed = time the launch stream sat in wait(handle) with nothing left to overlap (0 when the "
+                          "transfer finished behind the interior work); the per-rank sums need not equal ms_per_step (max over ranks of the whole run)"}
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     hist_r = hist if backend == "nccl" else hist.cpu()
@@ -288,10 +332,12 @@ def main():
                                "two_kernel_(6+3Nd)_words": bytes_iter_fused * it_s / 1e9 / world,
                                "one_sweep_(5+2Nd)_words": 4.0 * (5 + 2 * nd) * V * it_s / 1e9 / world, "per": "GPU"},
         "loss_first_last": [float(loss[W]), float(loss[-1])],
-        "rccl_ranks": rccl_ranks, "comm": args.comm if world > 1 else None,        # ranks of the RCCL communicator the run used (0: no process group / test backend)
+        "rccl_ranks": rccl_ranks, "comm": comm_name,        # rccl_ranks: size of the RCCL communicator the run used (0: no process group / test backend)
         "halo": {"backend": (dist.get_backend() if dist.is_initialized() else None), "planes_per_exchange": 1,
                  "bytes_per_plane": 4 * shape[1] * shape[2] * shape[3], "exchanges_per_iteration": 2 if world > 1 else 0},
     }
+    if phases is not None:
+        out["phases"] = phases
     traffic = {}
     try:
         traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s|%s" % (args.workload, args.scheme), {})

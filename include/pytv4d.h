@@ -169,7 +169,7 @@ int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void
  *   tv_cp_fused_supported : 1 if this geometry can take the one-sweep path, else 0
  *   tv_cp_fused           : q <- proj(q + sigma_D D x_in); p <- (p + sigma_A (x_in - x0)) / (1 + sigma_A);
  *                           x_out <- x_in - tau p - tau D^T q   EXCEPT the adjoint terms that cross a
- *                           wave tile (4 rows x 64 cols), a z-chunk, a time window or the slab; *tv = |D x_in|_{2,1},
+ *                           wave tile (8 rows x 32 cols; columns: only the 256-col block tile), a z-chunk, a time window or the slab; *tv = |D x_in|_{2,1},
  *                           *fid = 1/2 |x_out - x0|^2 over the sites that are already complete
  *   tv_cp_fixup           : adds the missing terms to x_out (q_prev / q_next as in tv_DT) and returns
  *                           the fidelity of those sites in *fid; total fidelity = sum of the two.

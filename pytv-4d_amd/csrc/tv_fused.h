@@ -12,10 +12,11 @@
 //     R[t]  := own-site terms of q'(z,t) + row / col neighbour terms (wave shuffles)
 //              + wz q'_zup(z-1,t) (carried) + wt q'_tup(z,t-1) (carried);   R[t-1] -= wt q'_tdown(z,t)
 //
-// A wave covers a 4-row x 64-col tile (16 lanes x 4 rows): row and column neighbours of both x and q'
-// are lane shuffles, so there is no LDS tile and no barrier.  Terms that live in ANOTHER wave's tile or
-// another z-chunk (tile-edge rows / columns, chunk-edge planes) are left out by the sweep and added by
-// the thin fix-up kernel k_cp_fixup afterwards (it touches only those rows / planes: ~2.5 words/voxel).
+// A wave covers a CP_TR-row x (64 / CP_TR * 4)-col tile -- 8 rows x 8 lanes (32 columns) since round 2, 4 rows x 16 lanes
+// (64 columns) in round 1 (-DTV_FUSED_TR=4): row and column neighbours of both x and q' are lane shuffles, so there is
+// no LDS tile and no barrier.  Terms that live in ANOTHER wave's tile or another z-chunk (tile-edge rows / columns,
+// chunk-edge planes) are left out by the sweep and added by the thin fix-up kernel k_cp_fixup afterwards (it touches
+// only those rows / planes: ~1.65 words/voxel with 8-row tiles, ~2.5 with 4-row tiles).
 // x is ping-ponged (x_in -> x_out) because neighbouring tiles read old halo values at their own pace.
 #pragma once
 #include "tv_device.h"
@@ -60,7 +61,8 @@ struct FusedCoord {
     long long inpl;
 };
 
-// block (64, 4): wave = threadIdx.y covers columns [64 w, 64 w + 64) of a 4-row x 256-col block tile
+// block (64, CP_NW): wave = threadIdx.y covers columns [CP_WC w, CP_WC w + CP_WC) of a CP_TR-row x CP_BC-col block tile
+// (default: 8 waves side by side, 8 rows x 256 columns)
 __device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk, int chunk0) {
     FusedCoord c;
     c.lane = (int)threadIdx.x;
@@ -115,7 +117,7 @@ __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, in
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND);
     constexpr int CM = XW ? CP_BC - 1 : CP_WC - 1;   // column period of the tiles whose edges are left to the fix-up
     bool f = false;
-    // rows: every wave tile (4 rows); columns: only the 256-column BLOCK tile edges -- the four waves
+    // rows: every wave tile (CP_TR rows); columns: only the BLOCK tile edges (CP_BC columns) -- the CP_NW waves
     // of a block hand their edge columns to each other through LDS inside the sweep
     if (UP) f = f || ((y & (CP_TR - 1)) == 0 && y >= 1) || ((col0 & CM) == 0 && col0 >= 1);
     if (DN) f = f || ((y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - 2) || ((col0 & CM) == CM - 3 && col0 + 4 <= g.nx - 1);
@@ -188,7 +190,7 @@ struct FusedArgs {
     double* part_fid;
 };
 
-// XW: the four waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
+// XW: the CP_NW waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
 // TWIN: time windows for volumes with more than CP_TWN frames -- grid z = window, the block works on the frames
 // [t0, t0 + M) of the volume (M = CP_TWN), reads x of the frame on either side of its window for the time differences
 // and leaves the adjoint terms that cross a window seam to the fix-up (exactly like the z-chunk edges)

@@ -1,0 +1,597 @@
+// tv_subgrad2.h -- ONE-PASS TV value + sub-gradient (pytv/tv_GPU.py:47-375 of the reference), round-3 kernel.
+//
+// Same mathematics as tv_subgrad.h (the scatter form: a site hands the PRODUCTS d * 1/|Dx| of its gradient channels to
+// its neighbours, 1/|Dx| never leaves the chip, the result is a pure function of x), rebuilt around what an instruction
+// costs on a gfx950 SIMD (tools/issue_bench.hip, profiles/r3_issue_bench.txt): a plain fp32 VALU op 2 cycles, DPP / compare
+// / select / packed / fp64 4, v_rsq 6 - 8, and ds_bpermute_b32 -- what __shfl_up/down compile to -- 18 per dword.  The
+// round-1 kernel (a lane = 1 row x 4 columns, wave = 4 rows x 16 lanes) spent a third of its issue time in the 19
+// bpermutes per frame that move row neighbours between lanes.  Here
+//
+//   a lane = R ROWS x 1 column (a column strip), a wave = R rows x 64 columns, NW waves stacked in y form the block;
+//   * row neighbours are registers of the same thread;
+//   * column neighbours are ONE DPP move each (wave_shr:1 / wave_shl:1 cross the 16-lane rows on gfx9);
+//   * only the first / last row of a wave's strip talks to another wave: one float per lane through LDS, double
+//     buffered so that ONE barrier per plane suffices (x of plane z+1 is published while plane z is computed);
+//   * the tile-overlap ring costs one or two COLUMNS on either side (2 - 4 of 64 lanes) instead of one 4-column lane (2 of 16);
+//   * a block whose tile lies strictly inside the frame runs a variant without any border multiplier / select
+//     (block-uniform branch), the zero-gradient rule is a wave-uniform branch around the selects;
+//   * z marching as before: x(z-1), x(z) and the accumulators G(z-1), G(z) of all M frames in registers, x(z+1) arrives
+//     through a short ring of loads issued two frames ahead.
+// Global accesses are 4 bytes per lane, 256 contiguous bytes per row and wave.
+#pragma once
+#include "tv_device.h"
+#include "tv_stencil.h"
+#include "tv_subgrad.h"
+
+namespace tv {
+
+template <typename T, int R> struct Col { T v[R]; };
+
+// lane i gets the value of lane i-1 / i+1 of the WAVE (0 at the wave's ends: those are ring lanes)
+__device__ __forceinline__ float from_left(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float from_right(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ double from_left(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double from_right(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ float rsq_fast(float v) { return __builtin_amdgcn_rsqf(v); }
+// fp64: v_rsq_f64 is good to ~2^-26; two Newton steps y <- y (1.5 - 0.5 v y^2) bring it to ~1 ulp
+__device__ __forceinline__ double rsq_fast(double v) {
+    double y = __builtin_amdgcn_rsq(v);
+    const double h = 0.5 * v;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+// ---- buffer addressing ------------------------------------------------------------------------------------------------
+// Every global access of the kernel is a raw buffer load / store: a wave-uniform descriptor (base = one frame of one plane,
+// num_records = bytes of a frame) + a per-lane byte offset.  The hardware's range check does the predication: a load whose
+// offset lies beyond num_records returns 0, such a store is dropped.  Sites outside the frame, ring rows / lanes that must not
+// be stored, planes that do not exist (descriptor with num_records = 0) therefore need NO branch and NO exec masking -- which
+// matters beyond the instruction count: gfx950 has one in-order vmcnt for loads and stores, and with control flow around
+// memory operations the compiler can only wait with vmcnt(0), i.e. for every outstanding store and look-ahead load, once
+// per frame (the first version of this kernel did: 53 % of its wave cycles waiting).  Straight-line code gets counted waits.
+using Rsrc = __amdgpu_buffer_rsrc_t;
+constexpr unsigned SG2_OOB = 0x80000000u;         // beyond any frame (frames are < 2^31 bytes: sg2_supported)
+typedef int sg2_v2i __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ Rsrc sg2_rsrc(const T* base, bool valid, int nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, valid ? nbytes : 0, 0x00020000);
+}
+__device__ __forceinline__ float sg2_ld(Rsrc r, unsigned off, float) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0)); }
+__device__ __forceinline__ double sg2_ld(Rsrc r, unsigned off, double) {
+    const sg2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    return __longlong_as_double(((long long)v.y << 32) | (unsigned)v.x);
+}
+__device__ __forceinline__ void sg2_st(Rsrc r, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, (int)off, 0, 0); }
+__device__ __forceinline__ void sg2_st(Rsrc r, unsigned off, double v) {
+    const long long b = __double_as_longlong(v);
+    sg2_v2i w;
+    w.x = (int)b;
+    w.y = (int)(b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)off, 0, 0);
+}
+template <typename T> __device__ __forceinline__ void pin1(T& a);
+template <> __device__ __forceinline__ void pin1<float>(float& a) { asm volatile("" : "+v"(a)); }
+template <> __device__ __forceinline__ void pin1<double>(double& a) { asm volatile("" : "+v"(a)); }
+
+template <typename T> struct SgArgs2 {
+    const T* x0;
+    T* x_out;
+    T step, lambda;
+    double* part_fid;
+    T* norms;
+};
+
+constexpr int SG2_TWN = 8, SG2_TWU = SG2_TWN - 2;      // time windows for M > 8: 8 frames computed, 6 stored
+#ifndef TV_SG2_D
+#define TV_SG2_D 2
+#endif
+#ifndef TV_SG2_X0_AHEAD
+#define TV_SG2_X0_AHEAD 1
+#endif
+#ifndef TV_SG2_SCHED_BARRIER
+#define TV_SG2_SCHED_BARRIER 1
+#endif
+constexpr int SG2_D = TV_SG2_D;                        // depth of the x(z+1) load ring (frames ahead)
+
+// MODE 0: G stored.  MODE 1: the descent step x_out = x - step ((x - x0) + lambda G), 1/2 |x_out - x0|^2 reduced (README.md:118-124).
+// MODE 2: G and the per-voxel norms |Dx| (zeros -> +inf: the reference's grad_norms, pytv/tv_GPU.py:88,135-139).
+template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN>
+struct SgCol {
+    static constexpr bool CEN = (S == CENTRAL);
+    static constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
+    static constexpr bool HALO = (S == HYBRID || CEN);     // the norm of a ring row looks at the row outside the tile
+    // ring of the tile: one row on either side (the first / last wave reads the row outside the tile from memory for the
+    // schemes whose norm looks both ways); columns: a lane's norm needs x of BOTH neighbouring lanes for hybrid / central, so
+    // x is valid on lanes 0..63, 1/|Dx| on 1..62 and G on 2..61; upwind / downwind look one way only: G on 1..62
+    static constexpr int RING = HALO ? 2 : 1;
+    static constexpr int RB = R * NW, UR = RB - 2, UC = 64 - 2 * RING;
+    static constexpr int H = (SG2_D < M) ? SG2_D : M;          // frames of the next plane requested before a step starts
+    static constexpr bool HEADS = (M % SG2_D != 0);            // M a multiple of the ring depth: the ring slot of a frame never changes, no staging registers
+    static constexpr int ROWS = 2 * NW + 1, ZR = 2 * NW;       // hand-off rows per (parity, frame): two per wave + one row of zeros
+    using C = Col<T, R>;
+
+    struct Shared {
+        // [parity][frame][row][lane]; row 2 w = first row of wave w's strip, 2 w + 1 = its last row, row ZR = zeros (what the
+        // first / last wave of the block reads instead of a neighbour: no select, no multiplier)
+        T xe[2][M][ROWS][64];       // x of plane z (parity z & 1)
+        T ye[2][M][ROWS][64];       // row products of step z: [2 w] for the wave above, [2 w + 1] for the wave below
+        double sm[16];
+    };
+
+    // FAST: the tile (ring included) lies strictly inside the frame and there is no per-pixel time factor: no border
+    // multipliers.  Everything else takes the generic variant (same memory operations, masks on the differences).
+    template <bool FAST>
+    static __device__ __forceinline__ void run(const DG& g, const WT<T>& w, const T* __restrict__ x, const T* __restrict__ xp,
+                                               const T* __restrict__ xn, T* __restrict__ G, int zchunk, int chunk, int tile_x, int tile_y,
+                                               int win, long long lid, double* __restrict__ partials, const SgArgs2<T>& sa, Shared& sh) {
+        const int lane = (int)threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);     // the wave index is uniform: keep it scalar
+        const int Mg = TWIN ? g.m : M;
+        const int t0 = TWIN ? win * SG2_TWU - 1 : 0;
+        auto fvalid = [&](int t) { return !TWIN || (t0 + t >= 0 && t0 + t < Mg); };
+        auto fstore = [&](int t) { return !TWIN || (t0 + t >= win * SG2_TWU && t0 + t < win * SG2_TWU + SG2_TWU && t0 + t < Mg); };
+        auto foff_t = [&](int t) { return (long long)(t0 + t) * g.s_t; };     // uniform
+        const int fbytes = (int)(g.s_t * (long long)sizeof(T));
+        const int cx = tile_x * UC - RING + lane;
+        const int yb = tile_y * UR - 1 + wv * R;               // first row of this wave's strip
+        const bool in_x = FAST || (cx >= 0 && cx < g.nx);
+        // per-lane byte offsets inside a frame: roff = where this thread's sites are (out of range if outside the frame: loads
+        // give 0), soff = where it STORES (only sites the tile owns: not the ring, not outside the frame)
+        unsigned roff[R], soff[R];
+        C mi, mfr, mbr, mfc, mbc, mft, cm;
+        const bool lane_ok = in_x && lane >= RING && lane <= 63 - RING;
+
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int y = yb + i;
+            const bool in = in_x && (FAST || (y >= 0 && y < g.ny));
+            const bool own = in && lane_ok && !(wv == 0 && i == 0) && !(wv == NW - 1 && i == R - 1);
+            const unsigned off = (unsigned)(((long long)y * g.nx + cx) * (long long)sizeof(T));
+            roff[i] = in ? off : SG2_OOB;
+            soff[i] = own ? off : SG2_OOB;
+            cm.v[i] = own ? T(1) : T(0);
+            // border multipliers of the generic variant: mi: site exists; mfr / mbr: it has a next / previous row; mfc / mbc:
+            // a next / previous column (central: both, for a difference to exist)
+            const bool hn = in && (y + 1 < g.ny), hp = in && (y > 0), cn = in && (cx + 1 < g.nx), cp = in && (cx > 0);
+            mi.v[i] = in ? T(1) : T(0);
+            mfr.v[i] = (CEN ? (hn && hp) : hn) ? T(1) : T(0);
+            mbr.v[i] = (CEN ? (hn && hp) : hp) ? T(1) : T(0);
+            mfc.v[i] = (CEN ? (cn && cp) : cn) ? T(1) : T(0);
+            mbc.v[i] = (CEN ? (cn && cp) : cp) ? T(1) : T(0);
+            mft.v[i] = T(0);
+            if (!FAST && g.ta && in) mft.v[i] = w.wt * mask_factor1<T>(g, w.sf, y, cx);
+        }
+        const int zs = chunk * zchunk;
+        const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
+        const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : (CEN ? T(0.5) : T(1));
+        const T thr = tiny_sumsq<T>() / (s * s);               // zero-gradient rule on the UNSCALED sum of squares: s^2 ss < tiny
+        const T a_step = (MODE == 1) ? sa.step * sa.lambda * s : T(0);
+        const T kap = (MODE == 1) ? -(T(1) - sa.step) / a_step : T(0);
+        const T wt_u = g.ta ? w.wt : T(0);                     // FAST: uniform time weight
+        const T wz_u = g.za ? w.wz : T(0);
+        // the row just outside the tile (hybrid / central: the norm of a ring row needs it): read from memory by the first /
+        // last wave; every other wave requests an out-of-range offset and gets 0
+        unsigned hoff = SG2_OOB;
+        if (HALO && in_x) {
+            if (wv == 0 && yb > 0) hoff = (unsigned)(((long long)(yb - 1) * g.nx + cx) * (long long)sizeof(T));
+            if (wv == NW - 1 && yb + R < g.ny) hoff = (unsigned)(((long long)(yb + R) * g.nx + cx) * (long long)sizeof(T));
+        }
+        // LDS hand-off rows: own pair, the neighbour's row above / below (the zero row at the block's ends)
+        const int r_own = 2 * wv, r_up = (wv > 0) ? 2 * (wv - 1) + 1 : ZR, r_dn = (wv < NW - 1) ? 2 * (wv + 1) : ZR;
+        if (wv == 0) {
+#pragma unroll
+            for (int t = 0; t < M; ++t) sh.xe[0][t][ZR][lane] = sh.xe[1][t][ZR][lane] = sh.ye[0][t][ZR][lane] = sh.ye[1][t][ZR][lane] = T(0);
+        }
+#pragma unroll
+        for (int t = 0; t < M; ++t)        // the first step reads the "previous step's" products for a store that is dropped: keep them finite
+            sh.ye[0][t][r_own][lane] = sh.ye[0][t][r_own + 1][lane] = sh.ye[1][t][r_own][lane] = sh.ye[1][t][r_own + 1][lane] = T(0);
+        static_assert(NW >= 2, "one halo load per thread serves the first OR the last wave");
+        const T m_hu = (wv == 0) ? T(1) : T(0), m_hd = (wv == NW - 1) ? T(1) : T(0);
+        double acc = 0.0, acc_fid = 0.0;
+
+        auto frame = [&](const T* plane, int t) { return sg2_rsrc<T>(plane + foff_t(t), plane != nullptr && fvalid(t), fbytes); };
+        auto load_rows = [&](Rsrc r, C& o) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) o.v[i] = sg2_ld(r, roff[i], T(0));
+        };
+
+        // per-frame state carried from plane to plane: x(z); the accumulators of G(z-1) and G(z); and ONE more array only where
+        // the scheme looks backwards in z -- central: x(z-1); downwind / hybrid: the weighted forward z difference of plane z-1,
+        // which IS the backward difference of plane z (upwind carries nothing: 96 registers of state at M = 8 instead of 128)
+        constexpr bool PZ = DN || CEN;
+        C Cc[M], Pz[PZ ? M : 1], Gp[M], Gc[M], Nq[SG2_D], Nh[HEADS ? H : 1];
+        const int z_lo = g.za ? zs - 1 : zs;
+        {
+            const T* pp = g.za ? zplane<T>(g, x, xp, xn, 2, z_lo - 1) : nullptr;
+            const T* pc = zplane<T>(g, x, xp, xn, 2, z_lo);
+            const int gz0 = g.z0 + z_lo;
+            const bool zp0 = (gz0 > 0) && (gz0 < g.nzg) && g.za;       // planes z_lo - 1 and z_lo both exist
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+                load_rows(frame(pc, t), Cc[t]);
+                if (PZ) {
+                    C pv;
+                    load_rows(frame(pp, t), pv);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        if (CEN) Pz[t].v[i] = pv.v[i];
+                        else Pz[t].v[i] = (zp0 ? wz_u : T(0)) * (Cc[t].v[i] - pv.v[i]) * (FAST ? T(1) : mi.v[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) Gp[t].v[i] = Gc[t].v[i] = T(0);
+                sh.xe[z_lo & 1][t][r_own][lane] = Cc[t].v[0];
+                sh.xe[z_lo & 1][t][r_own + 1][lane] = Cc[t].v[R - 1];
+            }
+        }
+        auto next_plane = [&](int zl) -> const T* {                 // plane zl+1 if this chunk needs it
+            const T* pn = zplane<T>(g, x, xp, xn, 2, zl + 1);
+            return (pn != nullptr && (g.za || zl + 1 < ze)) ? pn : nullptr;
+        };
+        {
+            const T* pn = next_plane(z_lo);
+#pragma unroll
+            for (int d = 0; d < H; ++d) load_rows(frame(pn, d), HEADS ? Nh[HEADS ? d : 0] : Nq[d]);
+        }
+        __syncthreads();
+
+        for (int zl = z_lo; zl <= ze; ++zl) {
+            const int gz = g.z0 + zl, par = zl & 1;
+            const bool plane_in = (gz >= 0) && (gz < g.nzg) && (zl < ze || g.za);
+            const T* pc = zplane<T>(g, x, xp, xn, 2, zl);
+            const T* pn = next_plane(zl);
+            const T* pn2 = (zl + 1 <= ze) ? next_plane(zl + 1) : nullptr;
+            const bool z_prev = plane_in && (gz > 0), z_next = plane_in && (gz + 1 < g.nzg);
+            const T wzn = (CEN ? (z_prev && z_next) : z_next) ? wz_u : T(0), wzp = (CEN ? (z_prev && z_next) : z_prev) ? wz_u : T(0);
+            const T m_pl = plane_in ? T(1) : T(0);
+            const bool count = plane_in && (zl >= zs) && (zl < ze);
+            const bool store = (zl - 1 >= zs) && (zl - 1 < ze);
+            T hq[2] = {T(0), T(0)};
+            if (HALO) {
+                hq[0] = sg2_ld(frame(pc, 0), hoff, T(0));
+                if (M > 1) hq[1] = sg2_ld(frame(pc, 1), hoff, T(0));
+            }
+            C x0q;                                  // MODE 1: x0 of the frame about to be stored, requested a frame ahead
+            if (MODE == 1 && TV_SG2_X0_AHEAD) {
+                const Rsrc r0 = sg2_rsrc<T>(sa.x0 + (long long)(zl - 1) * g.s_z + foff_t(0), store && fstore(0), fbytes);
+#pragma unroll
+                for (int i = 0; i < R; ++i) x0q.v[i] = sg2_ld(r0, soff[i], T(0));
+            }
+            if (HEADS) {
+#pragma unroll
+                for (int d = 0; d < H; ++d) Nq[d] = Nh[HEADS ? d : 0];
+            }
+            C pf_t_prev, f_t_prev, c_old_prev;      // time-axis carries: product / forward difference / x of frame t-1
+#pragma unroll
+            for (int i = 0; i < R; ++i) pf_t_prev.v[i] = f_t_prev.v[i] = c_old_prev.v[i] = T(0);
+#pragma unroll
+            for (int t = 0; t < M; ++t) {
+                const C c = Cc[t];
+                const C nx = Nq[t % SG2_D];          // x(zl+1, t)
+                // ---- row neighbours across the strip's ends -----------------------------------------------------------
+                T xu = T(0), xd = T(0);
+                if (DN || CEN) xu = sh.xe[par][t][r_up][lane];
+                if (UP || CEN) xd = sh.xe[par][t][r_dn][lane];
+                if (HALO) {                          // first / last wave: LDS gave 0, the halo load the value; every other wave: the reverse
+                    const T h = hq[t & 1];
+                    if (t + 2 < M) hq[t & 1] = sg2_ld(frame(pc, t + 2), hoff, T(0));
+                    xu += h * m_hu;
+                    xd += h * m_hd;
+                }
+                C x0n;
+                if (MODE == 1 && TV_SG2_X0_AHEAD && t + 1 < M) {
+                    const Rsrc r0 = sg2_rsrc<T>(sa.x0 + (long long)(zl - 1) * g.s_z + foff_t(t + 1), store && fstore(t + 1), fbytes);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) x0n.v[i] = sg2_ld(r0, soff[i], T(0));
+                }
+                // publish the strip ends of plane zl+1 for the next step
+                sh.xe[par ^ 1][t][r_own][lane] = nx.v[0];
+                sh.xe[par ^ 1][t][r_own + 1][lane] = nx.v[R - 1];
+                // ---- raw differences --------------------------------------------------------------------------------------
+                // dr[i] = x(row i+1) - x(row i) for i = -1 .. R-1 (index shifted by one): the forward row differences of the
+                // strip and of the row above it
+                T dr[R + 1];
+                dr[0] = c.v[0] - xu;
+#pragma unroll
+                for (int i = 0; i + 1 < R; ++i) dr[i + 1] = c.v[i + 1] - c.v[i];
+                dr[R] = xd - c.v[R - 1];
+                C xr, xl;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    xr.v[i] = from_right(c.v[i]);
+                    xl.v[i] = from_left(c.v[i]);
+                }
+                C f_r, b_r, f_c, b_c, f_z, b_z, f_t, b_t;     // weighted channels (central: f_* only)
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    if (CEN) {
+                        f_r.v[i] = ((i + 1 < R) ? c.v[(i + 1 < R) ? i + 1 : i] : xd) - ((i > 0) ? c.v[(i > 0) ? i - 1 : 0] : xu);   // x(i+1) - x(i-1), one rounding
+                        f_c.v[i] = xr.v[i] - xl.v[i];
+                        f_z.v[i] = wzn * (nx.v[i] - Pz[t].v[i]);
+                        if (!FAST) { f_r.v[i] *= mfr.v[i] * m_pl; f_c.v[i] *= mfc.v[i] * m_pl; f_z.v[i] *= mi.v[i]; }
+                        b_r.v[i] = b_c.v[i] = b_z.v[i] = T(0);
+                    } else {
+                        f_r.v[i] = dr[i + 1];
+                        b_r.v[i] = dr[i];
+                        f_c.v[i] = xr.v[i] - c.v[i];
+                        b_c.v[i] = c.v[i] - xl.v[i];
+                        f_z.v[i] = wzn * (nx.v[i] - c.v[i]);
+                        b_z.v[i] = DN ? Pz[DN ? t : 0].v[i] : T(0);          // = the forward difference of plane zl-1, weights and masks included
+                        if (!FAST) {
+                            f_r.v[i] *= mfr.v[i] * m_pl; b_r.v[i] *= mbr.v[i] * m_pl;
+                            f_c.v[i] *= mfc.v[i] * m_pl; b_c.v[i] *= mbc.v[i] * m_pl;
+                            f_z.v[i] *= mi.v[i];
+                        }
+                    }
+                }
+                // time axis: forward difference to frame t+1 (of the OLD plane zl: Cc[t+1] has not been rotated yet)
+                bool has_tn, has_tp;        // frame t+1 / t-1 exists in the volume
+                if (!TWIN) { has_tn = (t + 1 < M); has_tp = (t > 0); }
+                else { has_tn = fvalid(t) && (t0 + t + 1 < Mg); has_tp = fvalid(t) && (t0 + t > 0); }
+                C xtn, xtp = c_old_prev;    // x(zl, t+1), x(zl, t-1)
+                if (t + 1 < M) xtn = Cc[(t + 1 < M) ? t + 1 : t];
+                else if (TWIN) load_rows(sg2_rsrc<T>(pc + foff_t(t + 1), pc != nullptr && has_tn, fbytes), xtn);
+                else xtn = c;
+                if (TWIN && t == 0 && (CEN || DN)) load_rows(sg2_rsrc<T>(pc + foff_t(-1), pc != nullptr && has_tp, fbytes), xtp);
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const T wti = FAST ? wt_u : mft.v[i] * m_pl;
+                    if (CEN) {
+                        f_t.v[i] = (has_tn && has_tp) ? wti * (xtn.v[i] - xtp.v[i]) : T(0);
+                        b_t.v[i] = T(0);
+                    } else {
+                        f_t.v[i] = has_tn ? wti * (xtn.v[i] - c.v[i]) : T(0);
+                        b_t.v[i] = f_t_prev.v[i];
+                        if (TWIN && t == 0 && DN) b_t.v[i] = has_tp ? wti * (c.v[i] - xtp.v[i]) : T(0);   // backward difference of the window's first frame
+                    }
+                }
+                f_t_prev = f_t;
+                c_old_prev = c;
+                // ---- 1 / |Dx| -------------------------------------------------------------------------------------------
+                C ss, n;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    T a = f_r.v[i] * f_r.v[i] + f_c.v[i] * f_c.v[i];
+                    a = a + f_z.v[i] * f_z.v[i];
+                    a = a + f_t.v[i] * f_t.v[i];
+                    if (S == HYBRID || S == DOWNWIND) {
+                        T b = b_r.v[i] * b_r.v[i] + b_c.v[i] * b_c.v[i];
+                        b = b + b_z.v[i] * b_z.v[i];
+                        b = b + b_t.v[i] * b_t.v[i];
+                        a = (S == HYBRID) ? a + b : b;
+                    }
+                    ss.v[i] = a;
+                }
+                {
+                    T mn = ss.v[0];
+#pragma unroll
+                    for (int i = 1; i < R; ++i) mn = mn < ss.v[i] ? mn : ss.v[i];
+                    // a wave that holds no vanishing gradient (the usual case) skips the selects
+                    if (__builtin_expect(__any(!(mn >= thr)), 0)) {
+#pragma unroll
+                        for (int i = 0; i < R; ++i) n.v[i] = (ss.v[i] >= thr) ? rsq_fast(ss.v[i]) : T(0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < R; ++i) n.v[i] = rsq_fast(ss.v[i]);
+                    }
+                }
+                // TV: |Dx| = s * ss * (1 / sqrt(ss)); sites the tile owns, planes this chunk owns (uniform multiplier, no branch)
+                {
+                    const bool cnt = count && fstore(t);
+                    T sum = T(0);
+                    Rsrc rn_rs;
+                    if (MODE == 2) rn_rs = sg2_rsrc<T>(sa.norms + (long long)zl * g.s_z + foff_t(t), cnt, fbytes);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const T rn = ss.v[i] * n.v[i];
+                        sum += rn * cm.v[i];
+                        if (MODE == 2) sg2_st(rn_rs, soff[i], (n.v[i] > T(0)) ? s * rn : (T)__builtin_inff());
+                    }
+                    acc += (double)(sum * (cnt ? s : T(0)));
+                    pin1<double>(acc);        // or LLVM sinks the sums of all M frames below the frame loop and keeps their operands alive
+                }
+                // ---- scatter the products -------------------------------------------------------------------------------
+                C gc = Gc[t], gn;
+                T to_up = T(0), to_dn = T(0);          // products handed to the wave above / below
+                if (CEN) {
+                    // one product per axis, +1/2 to the site after, -1/2 to the site before
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const T p_r = f_r.v[i] * n.v[i];
+                        if (i + 1 < R) gc.v[(i + 1 < R) ? i + 1 : i] += p_r; else to_dn = p_r;
+                        if (i > 0) gc.v[(i > 0) ? i - 1 : 0] -= p_r; else to_up = p_r;
+                        const T p_c = f_c.v[i] * n.v[i];
+                        gc.v[i] += from_left(p_c) - from_right(p_c);
+                        const T p_z = f_z.v[i] * n.v[i];
+                        gn.v[i] = p_z;
+                        Gp[t].v[i] -= p_z;
+                        const T p_t = f_t.v[i] * n.v[i];
+                        gc.v[i] += pf_t_prev.v[i];
+                        pf_t_prev.v[i] = p_t;
+                        if (t > 0) { Gp[(t > 0) ? t - 1 : 0].v[i] -= p_t; pin1<T>(Gp[(t > 0) ? t - 1 : 0].v[i]); }   // G(zl, t-1): rotated into Gp at the end of frame t-1
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) gn.v[i] = T(0);
+                    if (UP) {       // forward channels: - to the site itself, + to the next site
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const T p_r = f_r.v[i] * n.v[i];
+                            gc.v[i] -= p_r;
+                            if (i + 1 < R) gc.v[(i + 1 < R) ? i + 1 : i] += p_r; else to_dn = p_r;
+                            const T p_c = f_c.v[i] * n.v[i];
+                            gc.v[i] += from_left(p_c) - p_c;
+                            const T p_z = f_z.v[i] * n.v[i];
+                            gc.v[i] -= p_z;
+                            gn.v[i] = p_z;
+                            const T p_t = f_t.v[i] * n.v[i];
+                            gc.v[i] += pf_t_prev.v[i] - p_t;
+                            pf_t_prev.v[i] = p_t;
+                        }
+                    }
+                    if (DN) {       // backward channels: + to the site itself, - to the previous site
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const T p_r = b_r.v[i] * n.v[i];
+                            gc.v[i] += p_r;
+                            if (i > 0) gc.v[(i > 0) ? i - 1 : 0] -= p_r; else to_up = p_r;
+                            const T p_c = b_c.v[i] * n.v[i];
+                            gc.v[i] += p_c - from_right(p_c);
+                            const T p_z = b_z.v[i] * n.v[i];
+                            gc.v[i] += p_z;
+                            Gp[t].v[i] -= p_z;
+                            const T p_t = b_t.v[i] * n.v[i];
+                            gc.v[i] += p_t;
+                            if (t > 0) { Gp[(t > 0) ? t - 1 : 0].v[i] -= p_t; pin1<T>(Gp[(t > 0) ? t - 1 : 0].v[i]); }   // G(zl, t-1): rotated into Gp at the end of frame t-1
+                        }
+                    }
+                }
+                if (DN || CEN) sh.ye[par][t][r_own][lane] = to_up;
+                if (UP || CEN) sh.ye[par][t][r_own + 1][lane] = to_dn;
+#pragma unroll
+                for (int i = 0; i < R; ++i) pin1<T>(gc.v[i]);
+                if (MODE == 1) {
+                    // the descent step needs x(zl) when G(zl) is complete, one step from now: instead of carrying x for a plane
+                    // (32 registers at M = 8) its share of the step rides in the accumulator: x_out = step x0 - a (G + kap x),
+                    // a = step lambda s, kap = -(1 - step) / a.  The accumulator then holds |kap x| ~ 10^3 next to G's O(1) terms:
+                    // x_out is good to a few ulp of x, like the direct form (host: only for step * lambda >= 1e-6)
+#pragma unroll
+                    for (int i = 0; i < R; ++i) gc.v[i] += kap * c.v[i];
+                }
+                // ---- plane zl-1 is complete: store (sites the tile owns; everything else has an out-of-range offset) -----------
+                {
+                    const bool st = store && fstore(t);
+                    const long long foff = (long long)(zl - 1) * g.s_z + foff_t(t);      // uniform
+                    // the row products the neighbouring waves published in the previous step (zero row at the block's ends)
+                    if (UP || CEN) Gp[t].v[0] += sh.ye[par ^ 1][t][r_up][lane];
+                    if (DN || CEN) Gp[t].v[R - 1] -= sh.ye[par ^ 1][t][r_dn][lane];
+                    if (MODE != 1) {
+                        const Rsrc rg = sg2_rsrc<T>(G + foff, st, fbytes);
+#pragma unroll
+                        for (int i = 0; i < R; ++i) sg2_st(rg, soff[i], s * Gp[t].v[i]);
+                    } else {
+                        const Rsrc ro = sg2_rsrc<T>(sa.x_out + foff, st, fbytes);
+                        if (!TV_SG2_X0_AHEAD) {
+                            const Rsrc r0 = sg2_rsrc<T>(sa.x0 + foff, st, fbytes);
+#pragma unroll
+                            for (int i = 0; i < R; ++i) x0q.v[i] = sg2_ld(r0, soff[i], T(0));
+                        }
+                        T e2 = T(0);
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const T x0v = x0q.v[i];
+                            const T xo = sa.step * x0v - a_step * Gp[t].v[i];
+                            const T e = xo - x0v;
+                            e2 += (e * e) * cm.v[i];
+                            sg2_st(ro, soff[i], xo);
+                        }
+                        acc_fid += (double)(e2 * (st ? T(0.5) : T(0)));
+                        pin1<double>(acc_fid);
+                        if (TV_SG2_X0_AHEAD && t + 1 < M) x0q = x0n;
+                    }
+                }
+                // rotate this frame: the finished slot carries the start of G(zl+1); x(zl) -> x(zl-1), x(zl+1) -> x(zl)
+#pragma unroll
+                for (int i = 0; i < R; ++i) pin1<T>(gn.v[i]);
+                Gp[t] = gc;          // G(zl, t): still misses its z+1 term, the time term of frame t+1 and the cross-wave row terms
+                Gc[t] = gn;          // the start of G(zl+1, t)
+                if (CEN) Pz[CEN ? t : 0] = c;
+                else if (DN) Pz[DN ? t : 0] = f_z;
+                Cc[t] = nx;
+                // next load of the ring: frame t + D of plane zl+1, or -- at the end of the step -- frame t + D - M of plane zl+2
+                if (t + SG2_D < M) load_rows(frame(pn, t + SG2_D), Nq[t % SG2_D]);
+                if (t >= M - H) load_rows(frame(pn2, t - (M - H)), HEADS ? Nh[(HEADS && t >= M - H) ? t - (M - H) : 0] : Nq[t % SG2_D]);
+#if TV_SG2_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);   // keep the frames apart: interleaving them costs registers (scratch) for nothing
+#endif
+            }
+            __syncthreads();
+        }
+        acc = block_sum(acc, sh.sm);
+        if (threadIdx.x == 0 && threadIdx.y == 0) partials[lid] = acc;
+        if (MODE == 1) {
+            acc_fid = block_sum(acc_fid, sh.sm);
+            if (threadIdx.x == 0 && threadIdx.y == 0) sa.part_fid[lid] = acc_fid;
+        }
+    }
+};
+
+// Which tiles a launch works on.  The tiles whose 16 x 64 sites (ring included) lie strictly inside the frame form a rectangle
+// [ix0, ix1] x [iy0, iy1] of the tile grid: they run the FAST instantiation (no border multipliers), everything else -- the
+// frame's outline, or every tile when a per-pixel time factor is set -- the generic one.
+struct SgTiles {
+    int tx, ty;                  // tile grid
+    int ix0, ix1, iy0, iy1;      // the interior rectangle (empty if ix1 < ix0 or iy1 < iy0)
+    long long nfast, nborder;    // tiles inside / outside the rectangle
+};
+__device__ __forceinline__ void sg2_tile(const SgTiles& tm, bool fast, long long k, int& bx, int& by) {
+    const int nxi = tm.ix1 - tm.ix0 + 1, nyi = tm.iy1 - tm.iy0 + 1;
+    if (fast) {
+        bx = tm.ix0 + (int)(k % nxi);
+        by = tm.iy0 + (int)(k / nxi);
+        return;
+    }
+    if (nxi <= 0 || nyi <= 0) {          // no interior: all tiles
+        bx = (int)(k % tm.tx);
+        by = (int)(k / tm.tx);
+        return;
+    }
+    const long long top = (long long)tm.iy0 * tm.tx, wmid = tm.tx - nxi, mid = (long long)nyi * wmid;
+    if (k < top) {
+        bx = (int)(k % tm.tx);
+        by = (int)(k / tm.tx);
+    } else if (k < top + mid) {
+        k -= top;
+        const int c = (int)(k % wmid);
+        by = tm.iy0 + (int)(k / wmid);
+        bx = (c < tm.ix0) ? c : c + nxi;
+    } else {
+        k -= top + mid;
+        bx = (int)(k % tm.tx);
+        by = tm.iy1 + 1 + (int)(k / tm.tx);
+    }
+}
+
+template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN>
+__global__ __launch_bounds__(64 * NW, (NW <= 4) ? 2 : 1) void k_subgrad_col(DG g, WT<T> w, const T* __restrict__ x, const T* __restrict__ xp,
+                                                                            const T* __restrict__ xn, T* __restrict__ G, int zchunk, int nchunks,
+                                                                            double* __restrict__ partials, SgArgs2<T> sa, SgTiles tm) {
+    using K = SgCol<S, T, M, R, NW, MODE, TWIN>;
+    __shared__ typename K::Shared sh;
+    const int Mg = TWIN ? g.m : M;
+    const int nwin = TWIN ? (Mg + SG2_TWU - 1) / SG2_TWU : 1;
+    // ONE launch for both variants (two launches would serialise, and the outline tiles alone do not fill the GPU): logical
+    // ids [0, nb_border) are the generic tiles -- first, they take longer -- then the interior ones.  Inside each range the
+    // XCD-aware order (consecutive workgroup ids go round-robin to the 8 XCDs; neighbouring tiles share ring rows / columns):
+    // logical id = (id % 8) * per_xcd + id / 8
+    const long long per_tile = (long long)nchunks * nwin;
+    const long long nb_border = tm.nborder * per_tile, nb_fast = tm.nfast * per_tile;
+    const long long pb = (nb_border + 7) / 8 * 8;                  // grid: [border range padded to 8][interior range padded to 8]
+    const bool fast = (long long)blockIdx.x >= pb;
+    const long long id = fast ? (long long)blockIdx.x - pb : (long long)blockIdx.x;
+    const long long total = fast ? nb_fast : nb_border, ntiles = fast ? tm.nfast : tm.nborder, per_xcd = (total + 7) / 8;
+    const long long lid = (id % 8) * per_xcd + id / 8;
+    if (lid >= total) return;
+    const int win = (int)(lid / (ntiles * nchunks));
+    const int chunk = (int)((lid / ntiles) % nchunks);
+    int bx, by;
+    sg2_tile(tm, fast, lid % ntiles, bx, by);
+    const long long slot = (fast ? nb_border : 0) + lid;
+    if (fast) K::template run<true>(g, w, x, xp, xn, G, zchunk, chunk, bx, by, win, slot, partials, sa, sh);
+    else K::template run<false>(g, w, x, xp, xn, G, zchunk, chunk, bx, by, win, slot, partials, sa, sh);
+}
+
+}  // namespace tv

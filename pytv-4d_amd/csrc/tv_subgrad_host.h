@@ -4,6 +4,7 @@
 #include "tv_host.h"
 #include "tv_stencil.h"
 #include "tv_subgrad.h"
+#include "tv_subgrad2.h"
 
 // every M <= 8 has its own instantiation; more frames run as overlapping time windows of 8 frames (tv_subgrad.h)
 inline bool sg_m_ok(int m) { return m >= 1; }
@@ -40,6 +41,60 @@ template <typename F> inline int dispatch_sg(int scheme, int m, F&& f) {
     return fail(TV_E_ARG, "unsupported (scheme, M) for the one-pass sub-gradient");
 }
 
+// ---- round-3 kernel (tv_subgrad2.h): a lane = R rows x 1 column -----------------------------------------------------------
+// fp32: R = 4, 4 waves per block (tile 16 rows x 64 columns, 14 x 60 / 62 stored).  TV_SG_KERNEL=1 selects the round-1 kernel
+// (k_subgrad_one) for A/B.
+template <int MODE>
+inline int sg2_launch_f32(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
+                          double* fidout, void* ws, hipStream_t st, const SgStepArgs& so) {
+    constexpr int R = 4, NW = 4;
+    const long long nmax = max_partials(d);
+    const bool halo = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL);
+    const int UR = R * NW - 2, UC = halo ? 60 : 62;
+    const long long tx = (d.nx + UC - 1) / UC, ty = (d.ny + UR - 1) / UR;
+    const long long nwin = (d.m > SG2_TWN) ? (d.m + SG2_TWU - 1) / SG2_TWU : 1;
+    // planes per z-chunk (TV_ZCHUNK overrides): 16.  A chunk computes two extra planes of norms, so longer chunks waste less
+    // -- and still measured slower on the north-star volume (256 planes: 8.2 / 8.3 / 8.8 / 8.9 ms per descent step with 16 /
+    // 32 / 64 / 86 planes per chunk, profiles/r3_sg2_zchunk.txt): many short blocks balance the 512 block slots better than
+    // few long ones.  Shorter only when the volume would not give 2048 blocks otherwise.
+    int zc = env_int("TV_ZCHUNK", 0);
+    if (zc <= 0) {
+        zc = 16;
+        while (zc > 8 && tx * ty * nwin * ((d.nz + zc - 1) / zc) < 2048) zc -= 4;
+    }
+    if (zc > d.nz) zc = d.nz;
+    const long long nch = (d.nz + zc - 1) / zc;
+    // interior rectangle of the tile grid (tv_subgrad2.h, SgTiles): tiles with every site, ring included, strictly inside the frame
+    const int RING = halo ? 2 : 1, RB = R * NW;
+    SgTiles tm{};
+    tm.tx = (int)tx; tm.ty = (int)ty;
+    int ix0 = 1, ix1 = (int)((d.nx - 2 - 63 + RING) / UC), iy0 = 1, iy1 = (int)((d.ny - RB) / UR);
+    if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || ix1 < ix0 || iy1 < iy0) { ix0 = iy0 = 1; ix1 = iy1 = 0; }
+    tm.ix0 = ix0; tm.ix1 = ix1; tm.iy0 = iy0; tm.iy1 = iy1;
+    tm.nfast = (long long)(ix1 - ix0 + 1) * (iy1 - iy0 + 1);
+    tm.nborder = tx * ty - tm.nfast;
+    const long long nbf = tm.nfast * nch * nwin, nbb = tm.nborder * nch * nwin, nb = nbf + nbb;
+    if (nb > nmax) return fail(TV_E_ARG, "internal: partials exceed the workspace");
+    const long long ngrid = (nbb + 7) / 8 * 8 + (nbf + 7) / 8 * 8;
+    if (ngrid > 0x7fffffffll) return fail(TV_E_ARG, "volume too large for the one-pass sub-gradient grid");
+    const dim3 block(64, NW, 1);
+    double* w0 = (double*)ws;
+    double* w1 = w0 + nmax + kStage + 16;
+    SgArgs2<float> sa{so.x0, so.x_out, so.step, so.lambda, w1, so.norms};
+    int rc = dispatch_sg(g->scheme, d.m > SG2_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
+        constexpr int MM = (M == 0) ? SG2_TWN : M;
+        constexpr bool TW = (M == 0);
+        hipLaunchKernelGGL((k_subgrad_col<S, float, MM, R, NW, MODE, TW>), dim3((unsigned)ngrid), block, 0, st, d, make_w<float>(g),
+                           (const float*)x, (const float*)x_prev, (const float*)x_next, (float*)G, zc, (int)nch, w0, sa, tm);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    });
+    if (rc) return rc;
+    if (int r2 = reduce_partials(w0, nb, nmax, tvout, st)) return r2;
+    if (MODE == 1) return reduce_partials(w1, nb, nmax, fidout, st);
+    return 0;
+}
+
 // common argument checks + launch geometry; MODE 1 passes the step arguments, MODE 0 an empty struct
 template <int MODE>
 inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout, double* fidout,
@@ -52,6 +107,10 @@ inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const 
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
     if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr))) return fail(TV_E_HALO, who);
     hipStream_t st = (hipStream_t)stream;
+    // round-3 kernel unless switched off; its descent step divides by step * lambda (tv_subgrad2.h): tiny or zero products
+    // take the round-1 kernel; frames must stay below 2^31 bytes for its buffer addressing
+    if (env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * 4 < (1ll << 31) && (MODE != 1 || (double)sa.step * (double)sa.lambda >= 1e-6))
+        return sg2_launch_f32<MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, sa);
     const long long nmax = max_partials(d);
     constexpr int NW = 4, UR = 4 * NW - 2, UC = 14;
     const long long tx = (d.nx / 4 + UC - 1) / UC, ty = (d.ny + UR - 1) / UR;

@@ -5,10 +5,13 @@ iteration (README.md:118-124 sub-gradient descent, :141-157 Chambolle-Pock; ADMM
 :26,135).  Here the state lives on the GPU(s) for the whole run and every iteration is a handful of
 fused HIP kernels (include/pytv4d.h):
 
-    ChambollePock       tv_cp_dual  (D + sigma-step + projection, TV partial)        (1+2Nd) words/voxel
-                        tv_cp_primal(fidelity dual + D^T + primal step, loss partial) (Nd+5) words/voxel
-    ADMM                tv_DT_axpy, tv_normal_op (I + rho D^T D from x alone), tv_cg_step1/2, tv_admm_zu
-    SubgradientDescent  tv_subgrad + tv_subgrad_step
+    ChambollePock       tv_cp_fused + tv_cp_fixup (one sweep: q read and written once)  (5+2Nd) words/voxel + fix-up
+                        or the pair tv_cp_dual (D + sigma-step + projection, TV partial) (1+2Nd)
+                        + tv_cp_primal (fidelity dual + D^T + primal step, loss partial)  (Nd+5)
+    ChambollePockOperator  the same with a user data-fidelity operator A / A^T on device tensors (tv_cp_dual + tv_cpop_*)
+    ADMM                tv_admm_tu / tv_admm_zu, tv_DT_axpy, tv_normal_op2 (I + rho D^T D from x alone, two dot products) +
+                        tv_cg_update (single-reduction CG; textbook tv_cg_step1/2 kept)
+    SubgradientDescent  tv_subgrad_step_fused (TV, G and the descent step in ONE pass over x) or tv_subgrad + tv_subgrad_step
 
 With a ``Slab`` (one process per GPU) each rank holds a contiguous z-slab; one boundary plane per
 neighbour is exchanged per operator apply (two for the radius-2 kernels) and, for Chambolle-Pock,
@@ -160,6 +163,7 @@ class ChambollePock(_SlabProblem):
         self.hist = None
         self.it = 0
         self.timing = None      # set to a list to collect (start, after kernel 1, after kernel 2) HIP events per step
+        self.phase_timing = None  # set to a list to collect one (name, event) list per step: every phase boundary of the schedule
         self._scratch = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
         if self.fused:
             self.zchunk = int(self.lib.tv_cp_zchunk(self.geo.ref))
@@ -194,11 +198,15 @@ class ChambollePock(_SlabProblem):
         """One-sweep iteration: x halos -> sweep (x -> x_alt) -> q' halos -> fix-up -> swap.  With a sharded
         slab the interior chunks / planes run while the halo planes are in flight: the first half of the interior chunks
         hides the x exchange, then the two edge chunks run, and the SECOND half of the interior chunks (with the interior
-        fix-up behind it) hides the q' exchange -- the interior fix-up alone is too short for that on a 32-plane slab."""
+        fix-up behind it) hides the q' exchange -- the interior fix-up alone is too short for that on a 32-plane slab.
+        ``phase_timing`` (a list): one event per phase boundary on the launch stream, so that a scaling run can say where an
+        iteration's time went -- in particular how long the stream sat in ``s.wait(h)`` with nothing left to overlap."""
         s, nz, F = self.slab, self.slab.nz, self.F
         ev = self._events()
+        mark = self._phase_marker()
         qhp = self.qh_prev[0] if self.qh_prev is not None else None
         qhn = self.qh_next[0] if self.qh_next is not None else None
+        mark("start")
         h = self.plan.exchange_image(self.x, self.xh_prev, self.xh_next)
         if ev:
             ev[0].record()
@@ -207,32 +215,68 @@ class ChambollePock(_SlabProblem):
             na = (nch - 2 + 1) // 2                      # interior chunks before the edge chunks, nb after them
             nb = nch - 2 - na
             self._sweep(1, na, None, None, out[0:1], out[F:F + 1])
+            mark("sweep_interior_a")
             s.wait(h)
+            mark("x_halo_wait_exposed")
             self._sweep(0, 1, self.xh_prev, None, out[1:2], out[F + 1:F + 2])
             self._sweep(nch - 1, 1, None, self.xh_next, out[2:3], out[F + 2:F + 3])
+            mark("sweep_edges")
             h = self.plan.exchange_grad(self.q, qhp, qhn)
             if nb > 0:
                 self._sweep(1 + na, nb, None, None, out[3:4], out[F + 3:F + 4])
+            mark("sweep_interior_b")
             if ev:
                 ev[1].record()
         else:
             s.wait(h)
+            mark("x_halo_wait_exposed")
             self._sweep(0, -1, self.xh_prev, self.xh_next, out[0:1], out[F:F + 1])
+            mark("sweep")
             if ev:
                 ev[1].record()
             h = self.plan.exchange_grad(self.q, qhp, qhn)
         if self.overlap_fused:
             self._fixup(1, nz - 2, None, None, out[F + 4:F + 5])
+            mark("fixup_interior")
             s.wait(h)
+            mark("q_halo_wait_exposed")
             self._fixup(0, 1, self.qh_prev, None, out[F + 5:F + 6])
             self._fixup(nz - 1, 1, None, self.qh_next, out[F + 6:F + 7])
+            mark("fixup_edges")
         else:
             s.wait(h)
+            mark("q_halo_wait_exposed")
             self._fixup(0, -1, self.qh_prev, self.qh_next, out[F + 4:F + 5])
+            mark("fixup")
         if ev:
             ev[2].record()
         self.x, self.x_alt = self.x_alt, self.x
         self.it += 1
+
+    def _phase_marker(self):
+        """mark(name): record an event on the launch stream that closes phase `name` (no-op unless ``phase_timing`` is a list)"""
+        if self.phase_timing is None:
+            return lambda name: None
+        rec = []
+        self.phase_timing.append(rec)
+
+        def mark(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            rec.append((name, e))
+        return mark
+
+    @staticmethod
+    def phase_means_ms(phase_timing):
+        """{phase: mean milliseconds per step} from the event lists collected in ``phase_timing`` (synchronise first)"""
+        acc, order = {}, []
+        for rec in phase_timing:
+            for (_, a), (name, b) in zip(rec[:-1], rec[1:]):
+                if name not in acc:
+                    acc[name] = []
+                    order.append(name)
+                acc[name].append(a.elapsed_time(b))
+        return {k: float(sum(acc[k]) / len(acc[k])) for k in order}
 
     def _events(self):
         if self.timing is None:
@@ -250,18 +294,25 @@ class ChambollePock(_SlabProblem):
         nz, s, F = self.slab.nz, self.slab, self.F
         x, q = self.x, self.q
         ev = self._events()
+        mark = self._phase_marker()
+        mark("start")
         # ---------------- dual: q <- proj(q + sigma D x) -----------------------------------------
         h = self.plan.exchange_image(x, self.xh_prev, self.xh_next)
         if ev:
             ev[0].record()
         if self.overlap:
             self._dual(1, nz - 1, x[0:1], x[nz - 1:nz], out[0:1])
+            mark("dual_interior")
             s.wait(h)
+            mark("x_halo_wait_exposed")
             self._dual(0, 1, self.xh_prev, x[1:2], out[1:2])
             self._dual(nz - 1, nz, x[nz - 2:nz - 1], self.xh_next, out[2:3])
+            mark("dual_edges")
         else:
             s.wait(h)
+            mark("x_halo_wait_exposed")
             self._dual(0, nz, self.xh_prev, self.xh_next, out[0:1])
+            mark("dual")
         if ev:
             ev[1].record()
         # ---------------- primal: x <- x - tau p - tau D^T q ---------------------------------------
@@ -269,12 +320,17 @@ class ChambollePock(_SlabProblem):
                                     self.qh_next[0] if self.qh_next is not None else None)
         if self.overlap:
             self._primal(1, nz - 1, q[0, self.ch_back], q[nz - 1, self.ch_fwd], out[F:F + 1])
+            mark("primal_interior")
             s.wait(h)
+            mark("q_halo_wait_exposed")
             self._primal(0, 1, self.qh_prev, q[1, self.ch_fwd], out[F + 1:F + 2])
             self._primal(nz - 1, nz, q[nz - 2, self.ch_back], self.qh_next, out[F + 2:F + 3])
+            mark("primal_edges")
         else:
             s.wait(h)
+            mark("q_halo_wait_exposed")
             self._primal(0, nz, self.qh_prev, self.qh_next, out[F:F + 1])
+            mark("primal")
         if ev:
             ev[2].record()
         self.it += 1
@@ -287,7 +343,7 @@ class ChambollePock(_SlabProblem):
         (global over all ranks), or None.  graph: None = capture the loop in a hipGraph when the problem is
         small enough to be launch-bound and not sharded; True / False force it."""
         hist = torch.zeros((n_iter, self.SLOTS), dtype=torch.float64, device=self.device)
-        use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS and not self.slab.sharded and self.timing is None) if graph is None else bool(graph)
+        use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS and not self.slab.sharded and self.timing is None and self.phase_timing is None) if graph is None else bool(graph)
         start = 0
         if use_graph and n_iter >= 2 + 2 * self.GRAPH_BLOCK and not self.slab.sharded:
             # two eager iterations (also the warm-up of the capture), then graph replays, then an eager tail

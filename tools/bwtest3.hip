@@ -132,6 +132,26 @@ __global__ __launch_bounds__(T) void k_lds(const f4* __restrict__ a, f4* __restr
     }
 }
 
+// NS read streams + NS write streams (the one-sweep CP kernel's shape: one vector from each of ~10 arrays per frame, then ~10
+// stores): stream k of block b is the region [k * sper + b * per, ...) of a / b.  LDM / STM: PLAIN or NT.
+template <int LDM, int STM, int NS, int T, int UU>
+__global__ __launch_bounds__(T) void k_streams(const f4* __restrict__ a, f4* __restrict__ b, long long per, long long sper) {
+    const long long c0 = (long long)blockIdx.x * per;
+    const int tid = threadIdx.x;
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0, 0x00020000);   // unused by PLAIN / NT
+    for (long long k = 0; k + UU * T <= per; k += UU * T) {
+        f4 v[NS][UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u)
+#pragma unroll
+            for (int sidx = 0; sidx < NS; ++sidx) v[sidx][u] = ld<LDM>(a + sidx * sper + c0, k + u * T + tid, r);
+#pragma unroll
+        for (int u = 0; u < UU; ++u)
+#pragma unroll
+            for (int sidx = 0; sidx < NS; ++sidx) st<STM>(b + sidx * sper + c0, k + u * T + tid, r, v[sidx][u] * 1.0001f);
+    }
+}
+
 static hipEvent_t e0, e1;
 template <typename F> static void run(const char* name, double bytes, F&& launch) {
     std::vector<float> ms;
@@ -172,6 +192,17 @@ static void ldsrun(const char* tag, const f4* a, f4* b, long long n, int bpc) {
     run(name, (double)per * blocks * 32, [&] { hipLaunchKernelGGL((k_lds<MODE, T, PHKB>), dim3(blocks), dim3(T), 0, 0, a, b, per); });
 }
 
+template <int LDM, int STM, int NS, int T, int UU>
+static void streams(const f4* a, f4* b, long long n, int bpc) {
+    const int blocks = 256 * bpc;
+    const long long sper = n / NS;
+    long long per = sper / blocks;
+    per -= per % ((long long)UU * T);
+    char name[128];
+    snprintf(name, sizeof name, "mix %d R + %d W streams, ld %s st %s, T=%-4d U=%d blocks/CU=%d", NS, NS, LDM == NT ? "nt" : "plain", STM == NT ? "nt" : "plain", T, UU, bpc);
+    run(name, (double)per * blocks * NS * 32, [&] { hipLaunchKernelGGL((k_streams<LDM, STM, NS, T, UU>), dim3(blocks), dim3(T), 0, 0, a, b, per, sper); });
+}
+
 int main(int argc, char** argv) {
     const long long gib = (argc > 1) ? atoll(argv[1]) : 4;
     const long long n = gib * (1ll << 30) / 16;       // vectors
@@ -185,6 +216,27 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     printf("# bwtest3: %lld GiB in + %lld GiB out, 256 CUs; GB/s = (bytes read + bytes written) / time\n", gib, gib);
+    if (argc > 2) {       // second study: load / store policy mix and the many-stream shape of the CP sweep
+        for (int bpc : {1, 2}) {
+            streams<PLAIN, PLAIN, 8, 512, 1>(a, b, n, bpc);
+            streams<NT, PLAIN, 8, 512, 1>(a, b, n, bpc);
+            streams<NT, NT, 8, 512, 1>(a, b, n, bpc);
+            streams<PLAIN, PLAIN, 8, 1024, 1>(a, b, n, bpc);
+            streams<NT, PLAIN, 8, 1024, 1>(a, b, n, bpc);
+            streams<NT, NT, 8, 1024, 1>(a, b, n, bpc);
+            streams<NT, PLAIN, 8, 512, 2>(a, b, n, bpc);
+            streams<NT, NT, 8, 512, 2>(a, b, n, bpc);
+            streams<NT, PLAIN, 8, 256, 2>(a, b, n, bpc);
+            streams<NT, PLAIN, 2, 1024, 4>(a, b, n, bpc);
+            streams<NT, NT, 2, 1024, 4>(a, b, n, bpc);
+            streams<NT, PLAIN, 1, 1024, 8>(a, b, n, bpc);
+            streams<PLAIN, NT, 1, 1024, 8>(a, b, n, bpc);
+        }
+        streams<NT, PLAIN, 8, 256, 1>(a, b, n, 4);
+        streams<PLAIN, PLAIN, 8, 256, 1>(a, b, n, 4);
+        streams<NT, NT, 8, 256, 1>(a, b, n, 4);
+        return 0;
+    }
     run("hipMemcpyAsync D2D", (double)n * 32, [&] { CK(hipMemcpyAsync(b, a, n * 16, hipMemcpyDeviceToDevice, 0)); });
     run("copy  grid-stride U=4 blocks=8192", (double)n * 32, [&] { hipLaunchKernelGGL((k_gs<4>), dim3(8192), dim3(256), 0, 0, a, b, n); });
     run("copy  grid-stride U=8 blocks=65536", (double)n * 32, [&] { hipLaunchKernelGGL((k_gs<8>), dim3(65536), dim3(256), 0, 0, a, b, n); });
