@@ -191,6 +191,15 @@ int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* 
                double thresh, double* tv, void* ws, void* stream);
 /* out = base + alpha * D^T (a - b)   (b and/or base may be NULL).  ab_prev / ab_next: halo planes
  * of (a - b) for the channels named in tv_DT. */
+int tv_DT_axpy2(const tv_geom* g, const void* a, const void* b, const void* ab_prev, const void* ab_next,
+                const void* base, const void* base2, double beta, double alpha, void* out, void* stream);
+/* ^ out = base + beta * base2 + alpha * D^T (a - b): the primal step of Chambolle-Pock with a data-fidelity operator A
+ *   (the CT use case, README.md:2,148), x - tau A^T p - tau D^T q in ONE pass: base = x, base2 = A^T p, beta = alpha = -tau.
+ * The two data-space updates of that iteration (vectors of ANY length n, the user's A decides):
+ *   tv_cpop_p        : p <- (p + sigma_A r) / (1 + sigma_A),  r = A x - b carried over from the previous iteration
+ *   tv_cpop_residual : r <- ax - b;  *fid (device fp64) = 1/2 |r|^2;  ws: >= 2048 doubles of device scratch */
+int tv_cpop_p(int32_t dtype, int64_t n, void* p, const void* r, double sigma_A, void* stream);
+int tv_cpop_residual(int32_t dtype, int64_t n, const void* ax, const void* b, void* r, double* fid, void* ws, void* stream);
 int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_prev, const void* ab_next,
                const void* base, double alpha, void* out, void* stream);
 /* out = x + rho * D^T D x, computed from x alone (radius-2 stencil); *dot (device fp64) = <x, out>

@@ -267,7 +267,7 @@ bool D_stream_ok(const tv_geom* g, const DG& d, bool vec);
 int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, float* dout);
 int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb, float* out);
 int DT_axpy(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
-            float* out, const float* base, float alpha);
+            float* out, const float* base, float alpha, const float* base2 = nullptr, float beta = 0.f);
 int DT_cp_primal(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
                  float* x, const float* x0, float* p, float tau, float sigma_a, float inv_1p_sigma_a, double* partials);
 }  // namespace tvm

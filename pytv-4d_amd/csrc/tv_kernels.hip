@@ -670,6 +670,25 @@ __global__ __launch_bounds__(256) void k_sub_dot(long long nv, const T* a, const
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
+// Chambolle-Pock with a data-fidelity operator (README.md:148 with A != I), data space, any length:
+//   k_cpop_p  : p <- (p + sigma r) / (1 + sigma)              (r = A x - b carried from the previous iteration)
+//   k_cpop_res: r <- Ax - b,  partial 1/2 |r|^2
+template <typename T, int V> __global__ __launch_bounds__(256) void k_cpop_p(long long nv, T* p, const T* r, T sigma, T inv) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x)
+        vstore<T, V>(p + i * V, inv * (vload<T, V>(p + i * V) + sigma * vload<T, V>(r + i * V)));
+}
+template <typename T, int V> __global__ __launch_bounds__(256) void k_cpop_res(long long nv, const T* ax, const T* b, T* r, double* partials) {
+    __shared__ double sm[16];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const Vec<T, V> o = vload<T, V>(ax + i * V) - vload<T, V>(b + i * V);
+        vstore<T, V>(r + i * V, o);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc += 0.5 * (double)o.v[k] * (double)o.v[k];
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
 // README.md:122-123: x <- x - step * ((x - x0) + lambda G); partial 1/2 |x - x0|^2
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_sgstep(long long nv, T* x, const T* x0, const T* G, T step, T lambda, double* partials) {
@@ -774,17 +793,22 @@ int tv_DT(const tv_geom* g, const void* y, const void* y_prev, const void* y_nex
 
 int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_prev, const void* ab_next,
                const void* base, double alpha, void* out, void* stream) {
+    return tv_DT_axpy2(g, a, b, ab_prev, ab_next, base, nullptr, 0.0, alpha, out, stream);
+}
+
+int tv_DT_axpy2(const tv_geom* g, const void* a, const void* b, const void* ab_prev, const void* ab_next,
+                const void* base, const void* base2, double beta, double alpha, void* out, void* stream) {
     DG d;
     if (int rc = make_dg(g, d)) return rc;
     if (a == nullptr || out == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_y_halos(g, d, ab_prev, ab_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({a, b, ab_prev, ab_next, base, out, d.wv});
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({a, b, ab_prev, ab_next, base, base2, out, d.wv});
     hipStream_t st = (hipStream_t)stream;
-    const bool plain_store = (base == nullptr && alpha == 1.0);
+    const bool plain_store = (base == nullptr && base2 == nullptr && alpha == 1.0);
     if (b == nullptr && march_ok(g, d, vec)) {
         long long nb;
         if (plain_store) return tvm::DT_store(g, d, a, ab_prev, ab_next, st, &nb, (float*)out);
-        return tvm::DT_axpy(g, d, a, ab_prev, ab_next, st, &nb, (float*)out, (const float*)base, (float)alpha);
+        return tvm::DT_axpy(g, d, a, ab_prev, ab_next, st, &nb, (float*)out, (const float*)base, (float)alpha, (const float*)base2, (float)beta);
     }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lc = launch_cfg(d, V, d.nz);
@@ -795,12 +819,12 @@ int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_pr
                 StoreDT<T, V> epi{(T*)out, nullptr};
                 hipLaunchKernelGGL((k_DT<S, T, V, SrcPlain<T, V>, StoreDT<T, V>>), lc.grid, lc.block, 0, st, d, w, src, epi);
             } else {
-                AxpyDT<T, V> epi{(T*)out, (const T*)base, (T)alpha, nullptr};
+                AxpyDT<T, V> epi{(T*)out, (const T*)base, (T)alpha, nullptr, (const T*)base2, (T)beta};
                 hipLaunchKernelGGL((k_DT<S, T, V, SrcPlain<T, V>, AxpyDT<T, V>>), lc.grid, lc.block, 0, st, d, w, src, epi);
             }
         } else {
             SrcDiff<T, V> src{(const T*)a, (const T*)b, (const T*)ab_prev, (const T*)ab_next};
-            AxpyDT<T, V> epi{(T*)out, (const T*)base, (T)alpha, nullptr};
+            AxpyDT<T, V> epi{(T*)out, (const T*)base, (T)alpha, nullptr, (const T*)base2, (T)beta};
             hipLaunchKernelGGL((k_DT<S, T, V, SrcDiff<T, V>, AxpyDT<T, V>>), lc.grid, lc.block, 0, st, d, w, src, epi);
         }
         HIP_TRY(hipGetLastError());
@@ -1075,6 +1099,32 @@ int tv_sub(int32_t dtype, int64_t n, const void* a, const void* b, void* out, vo
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return 0;
     TV_FLAT_LAUNCH(k_sub, dtype, n, ({a, b, out}), (const T*)a, (const T*)b, (T*)out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tv_cpop_p(int32_t dtype, int64_t n, void* p, const void* r, double sigma_A, void* stream) {
+    if (n < 0 || p == nullptr || r == nullptr) return fail(TV_E_ARG, "bad argument");
+    if (dtype != TV_F32 && dtype != TV_F64) return fail(TV_E_ARG, "unknown dtype");
+    if (!(sigma_A >= 0.0)) return fail(TV_E_ARG, "sigma_A must be non-negative");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return 0;
+    TV_FLAT_LAUNCH(k_cpop_p, dtype, n, ({p, r}), (T*)p, (const T*)r, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tv_cpop_residual(int32_t dtype, int64_t n, const void* ax, const void* b, void* r, double* fid, void* ws, void* stream) {
+    if (n < 0 || ax == nullptr || b == nullptr || r == nullptr || fid == nullptr || ws == nullptr) return fail(TV_E_ARG, "bad argument");
+    if (dtype != TV_F32 && dtype != TV_F64) return fail(TV_E_ARG, "unknown dtype");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(fid, 0, sizeof(double), st));
+        return 0;
+    }
+    TV_FLAT_LAUNCH(k_cpop_res, dtype, n, ({ax, b, r}), (const T*)ax, (const T*)b, (T*)r, (double*)ws);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, st, (const double*)ws, (long long)kFlatBlocks, fid);
     HIP_TRY(hipGetLastError());
     return 0;
 }

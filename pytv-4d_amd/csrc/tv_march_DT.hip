@@ -23,8 +23,8 @@ int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const
     return launch_DT_march<StoreDT>(g, d, q, qp, qn, st, nb, out, (double*)nullptr);
 }
 int DT_axpy(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
-            float* out, const float* base, float alpha) {
-    return launch_DT_march<AxpyDT>(g, d, q, qp, qn, st, nb, out, base, alpha, (double*)nullptr);
+            float* out, const float* base, float alpha, const float* base2, float beta) {
+    return launch_DT_march<AxpyDT>(g, d, q, qp, qn, st, nb, out, base, alpha, (double*)nullptr, base2, beta);
 }
 int DT_cp_primal(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
                  float* x, const float* x0, float* p, float tau, float sigma_a, float inv_1p_sigma_a, double* partials) {

@@ -373,14 +373,17 @@ template <typename T, int V> struct StoreDT {
         return 0.0;
     }
 };
-template <typename T, int V> struct AxpyDT {     // out = base + alpha * r
+template <typename T, int V> struct AxpyDT {     // out = base + beta * base2 + alpha * r
     static constexpr bool REDUCES = false;
     T* out;
     const T* base;
     T alpha;
     double* partials;
+    const T* base2 = nullptr;       // tv_DT_axpy2: the primal step of Chambolle-Pock with a data-fidelity operator,
+    T beta = T(0);                  // x - tau A^T p - tau D^T q in one pass (base = x, base2 = A^T p, beta = alpha = -tau)
     __device__ __forceinline__ double operator()(long long off, const Vec<T, V>& r) const {
         Vec<T, V> b = (base != nullptr) ? vload<T, V>(base + off) : vsplat<T, V>(T(0));
+        if (base2 != nullptr) b = b + beta * vload<T, V>(base2 + off);
         vstore<T, V>(out + off, b + alpha * r);
         return 0.0;
     }

@@ -274,6 +274,9 @@ struct SgCol {
 #pragma unroll
                 for (int d = 0; d < H; ++d) Nq[d] = Nh[HEADS ? d : 0];
             }
+            T xu_n = T(0), xd_n = T(0);
+            if (DN || CEN) xu_n = sh.xe[par][0][r_up][lane];
+            if (UP || CEN) xd_n = sh.xe[par][0][r_dn][lane];
             C pf_t_prev, f_t_prev, c_old_prev;      // time-axis carries: product / forward difference / x of frame t-1
 #pragma unroll
             for (int i = 0; i < R; ++i) pf_t_prev.v[i] = f_t_prev.v[i] = c_old_prev.v[i] = T(0);
@@ -282,9 +285,11 @@ struct SgCol {
                 const C c = Cc[t];
                 const C nx = Nq[t % SG2_D];          // x(zl+1, t)
                 // ---- row neighbours across the strip's ends -----------------------------------------------------------
-                T xu = T(0), xd = T(0);
-                if (DN || CEN) xu = sh.xe[par][t][r_up][lane];
-                if (UP || CEN) xd = sh.xe[par][t][r_dn][lane];
+                T xu = xu_n, xd = xd_n;              // read from LDS one frame ahead (two waves per SIMD do not hide an LDS round trip)
+                if (t + 1 < M) {
+                    if (DN || CEN) xu_n = sh.xe[par][(t + 1 < M) ? t + 1 : t][r_up][lane];
+                    if (UP || CEN) xd_n = sh.xe[par][(t + 1 < M) ? t + 1 : t][r_dn][lane];
+                }
                 if (HALO) {                          // first / last wave: LDS gave 0, the halo load the value; every other wave: the reverse
                     const T h = hq[t & 1];
                     if (t + 2 < M) hq[t & 1] = sg2_ld(frame(pc, t + 2), hoff, T(0));

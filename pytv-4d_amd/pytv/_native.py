@@ -86,6 +86,9 @@ _SIGNATURES = {
     "tv_cp_fixup": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double] + [ctypes.c_int64] * 2 + [_c_double_p, _c_void_p, _c_void_p]),
     "tv_admm_zu": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double, _c_double_p, _c_void_p, _c_void_p]),
     "tv_DT_axpy": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double, _c_void_p, _c_void_p]),
+    "tv_DT_axpy2": (ctypes.c_int, [_G] + [_c_void_p] * 6 + [ctypes.c_double, ctypes.c_double, _c_void_p, _c_void_p]),
+    "tv_cpop_p": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, _c_void_p, _c_void_p, ctypes.c_double, _c_void_p]),
+    "tv_cpop_residual": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, _c_void_p, _c_void_p, _c_void_p, _c_double_p, _c_void_p, _c_void_p]),
     "tv_normal_op": (ctypes.c_int, [_G] + [_c_void_p] * 3 + [ctypes.c_double, _c_void_p, _c_double_p, _c_void_p, _c_void_p]),
     "tv_normal_op2": (ctypes.c_int, [_G] + [_c_void_p] * 3 + [ctypes.c_double] + [_c_void_p] * 3 + [_c_double_p, _c_void_p, _c_void_p]),
     "tv_cg_update": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [_c_double_p, _c_void_p, _c_double_p, _c_void_p, _c_void_p]),

@@ -408,13 +408,13 @@ class ChambollePockOperator(_SlabProblem):
                  mask_static=False, factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None):
         super().__init__(x_init, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.A, self.AT = A, AT
-        self.b = b
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
         self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x_init.shape[1], reg_z_over_reg, reg_time,
                                                                     self.geo.time_weight_max)
         self.x = self.x0.clone()
-        self.p = torch.zeros_like(b)
+        self.b = b.to(self.dtype).contiguous()
+        self.p = torch.zeros_like(self.b)
         self.q = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
         self.ws = self.geo.workspace()
         self.x_new = torch.empty_like(self.x)
@@ -424,25 +424,50 @@ class ChambollePockOperator(_SlabProblem):
         self.xh_next = self.new_plane() if pl.x_need_next else None
         self.qh_prev = self.new_plane() if pl.g_need_prev else None
         self.qh_next = self.new_plane() if pl.g_need_next else None
+        # the residual r = A x - b is CARRIED from one iteration to the next (round 2 applied A twice per iteration: once
+        # for the dual update, once more for the loss of the new iterate -- the next iteration's first residual)
+        self.r = torch.empty_like(self.b)
+        self.n_A = self.n_AT = 0          # calls of the user's operators (tests assert one of each per iteration)
+        self._fid0 = torch.zeros((), dtype=torch.float64, device=self.device)
+        self._residual(self.x, self._fid0)
+
+    def _apply(self, op, v, shape, what):
+        out = op(v)
+        if tuple(out.shape) != tuple(shape) or out.dtype != self.dtype or not out.is_cuda:
+            raise ValueError("%s must return a device tensor of shape %s and dtype %s, got %s %s on %s"
+                             % (what, tuple(shape), self.dtype, tuple(out.shape), out.dtype, out.device))
+        return out if out.is_contiguous() else out.contiguous()
+
+    def _residual(self, x, fid_slot):
+        """r <- A x - b, fid_slot <- 1/2 |r|^2 (this rank's share): one call of A, one HIP kernel."""
+        ax = self._apply(self.A, x, self.b.shape, "A(x)")
+        self.n_A += 1
+        _nv.check(self.lib.tv_cpop_residual(_nv.dtype_code(self.dtype), self.b.numel(), _nv.ptr(ax), _nv.ptr(self.b), _nv.ptr(self.r),
+                                            fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
 
     def step(self, out):
-        """out: fp64 device tensor [tv, fid] (fid = 1/2 |A x_new - b|^2) of this rank."""
+        """out: fp64 device tensor [tv, fid] of this rank: tv = |D x|_{2,1} of the iterate the step started from, fid =
+        1/2 |A x_new - b|^2 of the one it produced (the mix the reference's loss line uses, README.md:157).
+        One call of A and one of A^T per iteration; every update of ours is a HIP kernel on preallocated buffers:
+            tv_cpop_p        p <- (p + sigma_A r) / (1 + sigma_A)
+            tv_cp_dual       q <- proj(q + sigma_D D x), TV
+            tv_DT_axpy2      x_new <- x - tau A^T p - tau D^T q          (one pass: q, x and A^T p read once)
+            tv_cpop_residual r <- A x_new - b, fidelity"""
         g, s = self.geo, self.slab
-        h = self.plan.exchange_image(self.x, self.xh_prev, self.xh_next)      # in flight while the user's operator runs
-        r = self.A(self.x) - self.b
-        self.p = (self.p + self.sigma_A * r) / (1.0 + self.sigma_A)
+        h = self.plan.exchange_image(self.x, self.xh_prev, self.xh_next)      # in flight while the data-space update runs
+        _nv.check(self.lib.tv_cpop_p(_nv.dtype_code(self.dtype), self.p.numel(), _nv.ptr(self.p), _nv.ptr(self.r), self.sigma_A, self.stream))
         s.wait(h)
         _nv.check(self.lib.tv_cp_dual(g.ref, _nv.ptr(self.x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.q),
                                       self.sigma_D, self.reg, out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
         h = self.plan.exchange_grad(self.q, self.qh_prev[0] if self.qh_prev is not None else None,
                                     self.qh_next[0] if self.qh_next is not None else None)
-        base = (self.x - self.tau * self.AT(self.p)).contiguous()
+        atp = self._apply(self.AT, self.p, self.x.shape, "AT(p)")             # the user's operator runs while the q halos travel
+        self.n_AT += 1
         s.wait(h)
-        _nv.check(self.lib.tv_DT_axpy(g.ref, _nv.ptr(self.q), None, _nv.ptr(self.qh_prev), _nv.ptr(self.qh_next), _nv.ptr(base),
-                                      -self.tau, _nv.ptr(self.x_new), self.stream))
+        _nv.check(self.lib.tv_DT_axpy2(g.ref, _nv.ptr(self.q), None, _nv.ptr(self.qh_prev), _nv.ptr(self.qh_next), _nv.ptr(self.x),
+                                       _nv.ptr(atp), -self.tau, -self.tau, _nv.ptr(self.x_new), self.stream))
         self.x, self.x_new = self.x_new, self.x
-        res = self.A(self.x) - self.b
-        out[1:2] = 0.5 * torch.sum(res.double() ** 2)
+        self._residual(self.x, out[1:2])
 
     def run(self, n_iter):
         hist = torch.zeros((n_iter, 2), dtype=torch.float64, device=self.device)

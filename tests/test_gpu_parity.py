@@ -541,6 +541,60 @@ def test_cp_with_fidelity_operator(pytv):
         np.testing.assert_allclose(cp.result().cpu().numpy(), x, rtol=1e-10, atol=1e-9)
 
 
+def test_cp_operator_applies_A_once_and_allocates_nothing(pytv):
+    """round-2 verdict item 6: one A and one A^T per iteration (the residual A x - b is carried), and no device
+    allocation by the solver's own updates (the user's operators here write into buffers they own)."""
+    import torch
+    rng = np.random.default_rng(62)
+    shape = (6, 4, 32, 256)               # 4 MiB planes are not needed: the point is the call pattern
+    x0 = torch.as_tensor((50.0 * rng.random(shape)).astype(np.float32)).cuda()
+    a = torch.as_tensor((0.2 + 0.8 * rng.random(shape)).astype(np.float32)).cuda()
+    b = (a * x0 + torch.randn(shape, device="cuda")).contiguous()
+    buf_a, buf_at = torch.empty_like(x0), torch.empty_like(x0)
+    calls = {"A": 0, "AT": 0}
+
+    def A(v):
+        calls["A"] += 1
+        return torch.mul(a, v, out=buf_a)
+
+    def AT(v):
+        calls["AT"] += 1
+        return torch.mul(a, v, out=buf_at)
+
+    cp = pytv.solvers.ChambollePockOperator(A, AT, b, x0, 5.0, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.7)
+    assert calls == {"A": 1, "AT": 0}                      # the residual of the starting point
+    hist = torch.zeros((12, 2), dtype=torch.float64, device="cuda")
+    cp.step(hist[0])
+    cp.step(hist[1])                                       # warm: every lazily created buffer exists now
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_stats()
+    n0 = dict(calls)
+    for it in range(2, 12):
+        cp.step(hist[it])
+    torch.cuda.synchronize()
+    after = torch.cuda.memory_stats()
+    assert calls["A"] - n0["A"] == 10 and calls["AT"] - n0["AT"] == 10 and cp.n_A == calls["A"] and cp.n_AT == calls["AT"]
+    for key in ("allocation.all.allocated", "allocated_bytes.all.allocated"):
+        assert after[key] == before[key], (key, before[key], after[key])
+    # and the iteration is still the oracle's
+    xs, ps, qs = x0.double().cpu().numpy(), np.zeros(shape), None
+    an, bn = a.double().cpu().numpy(), b.double().cpu().numpy()
+    kw = dict(reg_z_over_reg=1.0, reg_time=0.7)
+    tau = orc.cp_step_size("hybrid", shape[0], shape[1], 1.0, 0.7)
+    qs = np.zeros_like(orc.D(xs, "hybrid", **kw))
+    want = []
+    for _ in range(12):
+        ps = (ps + 1.0 * (an * xs - bn)) / 2.0
+        Dx = orc.D(xs, "hybrid", **kw)
+        v = qs + 0.5 * Dx
+        qs = v / np.maximum(1.0, np.sqrt(np.sum(v ** 2, axis=1, keepdims=True)) / 5.0)
+        xs = xs - tau * (an * ps) - tau * orc.D_T(qs, "hybrid", **kw)
+        want.append(0.5 * np.sum((an * xs - bn) ** 2) + 5.0 * orc.compute_L21_norm(Dx))
+    h = hist.cpu().numpy()
+    np.testing.assert_allclose(h[:, 1] + 5.0 * h[:, 0], want, rtol=2e-5)
+    np.testing.assert_allclose(cp.result().cpu().numpy(), xs, rtol=1e-4, atol=2e-3)
+
+
 # ------------------------------------------------------------------------------------------------
 # z-slab halos on ONE GPU: every slab call with halos == the unsharded call (slab edges are where
 # the bugs live; the multi-process exchange itself is covered on CPU with gloo in test_slab_gloo.py)
