@@ -180,7 +180,9 @@ __global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8
                 }
             }
             F4 o[8];
-            d_slots<S, float, 4>(g, w, n, mf, o);        // z slots come out as zero (h_nz = h_pz = false): filled below
+            F4 mft = mf;          // per-voxel weight on the time channels (tv_geom::time_weight_vol): one more streamed read
+            if (g.wv != nullptr && g.ta && in_chunk && ok) mft = mf * ldu(static_cast<const float*>(g.wv) + (long long)z * g.s_z + foff(t), voff);
+            d_slots<S, float, 4>(g, w, n, mft, o);       // z slots come out as zero (h_nz = h_pz = false): filled below
             // ---- next plane: requested before this frame's stores -----------------------------------------------------
             cold = c;
             if (CEN) P2[t] = P[t];

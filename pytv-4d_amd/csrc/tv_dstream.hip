@@ -6,7 +6,7 @@
 namespace tvm {
 
 bool D_stream_ok(const tv_geom* g, const DG& d, bool vec) {
-    if (g->dtype != TV_F32 || !vec || d.nx < 64 || d.wv != nullptr) return false;
+    if (g->dtype != TV_F32 || !vec || d.nx < 64) return false;        // a weight volume is one more read stream (round 3)
     if ((long long)d.ny * d.nx > (1ll << 30)) return false;           // 32-bit per-lane byte offsets inside a frame
     return true;
 }

@@ -146,6 +146,35 @@ __device__ __forceinline__ F4 ldu(const float* ubase, unsigned voff) {
 __device__ __forceinline__ float ldu1(const float* ubase, unsigned voff) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + voff);
 }
+// streamed-once data (the dual variable q, x0, p): non-temporal loads / stores (-DTV_FUSED_NT=1: A/B of round 3 -- a copy with
+// 8 read + 8 write streams and this kernel's 512-thread blocks gains 1.3 % from it, tools/bwtest3 "mix"; mixing non-temporal loads
+// with plain stores LOSES 7 %)
+#ifndef TV_FUSED_NT
+#define TV_FUSED_NT 1
+#endif
+__device__ __forceinline__ F4 ldu_s(const float* ubase, unsigned voff) {
+    const F4* p = reinterpret_cast<const F4*>(reinterpret_cast<const char*>(ubase) + voff);
+#if TV_FUSED_NT
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    F4 r;
+    r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
+    return r;
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stu_s(float* ubase, unsigned voff, const F4& v) {
+    F4* p = reinterpret_cast<F4*>(reinterpret_cast<char*>(ubase) + voff);
+#if TV_FUSED_NT
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    nt_f4 w;
+    w.x = v.v[0]; w.y = v.v[1]; w.z = v.v[2]; w.w = v.v[3];
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_f4*>(p));
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ void stu(float* ubase, unsigned voff, const F4& v) {
     *reinterpret_cast<F4*>(reinterpret_cast<char*>(ubase) + voff) = v;
 }
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             const float* qb0 = a.q + (long long)c.zs * g.s_dz;
             for_each_channel<S>(g, [&](auto slot, int ch) {
                 constexpr int k = decltype(slot)::value;
-                qpre[k & 3] = ldu(qb0 + (long long)ch * g.s_z, voff);
+                qpre[k & 3] = ldu_s(qb0 + (long long)ch * g.s_z, voff);
             });
         }
     }
@@ -294,7 +323,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             if (DN && c.lx == CP_TL - 1 && wave < CP_NW - 1) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
         }
         const long long foff = (long long)zf * g.s_z + (long long)(t0 + t) * g.s_t;      // uniform
-        const F4 x0v = ldu(a.x0 + foff, voff), pv = ldu(a.p + foff, voff);
+        const F4 x0v = ldu_s(a.x0 + foff, voff), pv = ldu_s(a.p + foff, voff);
         F4 pn, xo;
         double e2 = 0.0;
 #pragma unroll
@@ -304,8 +333,8 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             const double e = (double)xo.v[i] - (double)x0v.v[i];
             e2 += 0.5 * e * e;
         }
-        stu(a.p + foff, voff, pn);
-        stu(a.x_out + foff, voff, xo);
+        stu_s(a.p + foff, voff, pn);
+        stu_s(a.x_out + foff, voff, xo);
         if (!fused_needs_fixup<S, XW>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += e2;
     };
 
@@ -366,10 +395,15 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
                     const float* qbn = a.q + (long long)zn * g.s_dz + (long long)tn * g.s_t;
                     for_each_channel<S>(g, [&](auto slot, int ch) {
                         constexpr int k = decltype(slot)::value;
-                        qpre[k & 3] = ldu(qbn + (long long)ch * g.s_z, voff);
+                        qpre[k & 3] = ldu_s(qbn + (long long)ch * g.s_z, voff);
                     });
                 }
             }
+            // per-VOXEL weight on the time channels (tv_geom::time_weight_vol, the reference's to-do README.md:258): one more
+            // streamed read per frame.  D scales the time channels of a voxel by ITS factor, and so does the adjoint below
+            // (every q' sample is scaled by its own voxel's factor before the difference): round 3
+            F4 mft = mf;
+            if (g.wv != nullptr && g.ta && c.ok) mft = mf * ldu_s(static_cast<const float*>(g.wv) + (long long)z * g.s_z + toff, voff);
             // ------------------------------------------------ neighbourhood of x(z, t)
             XN<float, 4> n;
             n.c = C[t];
@@ -425,7 +459,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
                 else if (TWIN && g.ta && tg > 0) { n.h_pt = true; n.pt = c.ok ? ldu(pc + toff - g.s_t, voff) : zero; }        // across the seam
             }
             F4 o[8];
-            d_slots<S, float, 4>(g, w, n, mf, o);
+            d_slots<S, float, 4>(g, w, n, mft, o);
             // ------------------------------------------------ dual update (README.md:149-151)
             F4 v[8];
 #pragma unroll
@@ -435,7 +469,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             if (c.ok) {
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
-                    const F4 qv = PFQ ? qcur[k & 3] : ldu(qbase + (long long)ch * g.s_z, voff);
+                    const F4 qv = PFQ ? qcur[k & 3] : ldu_s(qbase + (long long)ch * g.s_z, voff);
                     v[k] = qv + a.sigma * o[k];
                     vs = vs + v[k] * v[k];
                 });
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
                     v[k] = v[k] * scale;
-                    stu(qbase + (long long)ch * g.s_z, voff, v[k]);
+                    stu_s(qbase + (long long)ch * g.s_z, voff, v[k]);
                 });
             }
             // slots: non-hybrid 0 rows, 1 cols, 2 z, 3 t ; hybrid 0 ru, 1 cu, 2 rd, 3 cd, 4 zu, 5 zd, 6 tu, 7 td
@@ -465,7 +499,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
                 for (int i = 0; i < 4; ++i)
                     qcu.v[i] = (c.ok && c.col0 + i < g.nx - 1 && (!CEN || c.col0 + i > 0)) ? v[k_cu].v[i] : 0.f;
                 if (g.za && c.ok && gz + 1 < g.nzg && (!CEN || z_fwd || gz > 0)) qzu = w.wz * v[k_zu];
-                if (g.ta && c.ok && tg + 1 < Mg && (!CEN || t_fwd || tg > 0)) qtu = (w.wt * v[k_tu]) * mf;
+                if (g.ta && c.ok && tg + 1 < Mg && (!CEN || t_fwd || tg > 0)) qtu = (w.wt * v[k_tu]) * mft;
             }
             if (DN) {
                 if (c.ok && c.y > 0 && (!CEN || c.y + 1 < g.ny)) qrd = v[k_rd];
@@ -473,7 +507,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
                 for (int i = 0; i < 4; ++i)
                     qcd.v[i] = (c.ok && c.col0 + i > 0 && (!CEN || c.col0 + i < g.nx - 1)) ? v[k_cd].v[i] : 0.f;
                 if (g.za && c.ok && gz > 0 && (!CEN || (!z_fwd && gz + 1 < g.nzg))) qzd = w.wz * v[k_zd];
-                if (g.ta && c.ok && tg > 0 && (!CEN || (!t_fwd && tg + 1 < Mg))) qtd = (w.wt * v[k_td]) * mf;
+                if (g.ta && c.ok && tg > 0 && (!CEN || (!t_fwd && tg + 1 < Mg))) qtd = (w.wt * v[k_td]) * mft;
             }
             // ------------------------------------------------ lagged primal update of plane z-1
             if (z > c.zs) {
@@ -591,9 +625,10 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, co
     if (g.ta && g.m > CP_TWN) {      // time-window seams: the neighbouring frame belongs to another window of the sweep
         const int c_tu = g.ch_t, c_td = (S == HYBRID) ? g.ch_t + 1 : g.ch_t;
         const int k = t % CP_TWN;
-        F4 mt = zero;
-        if (UP && k == 0 && t >= 1) mt = mt + vload<float, 4>(qb + (long long)c_tu * g.s_z - g.s_t);
-        if (DN && k == CP_TWN - 1 && t <= g.m - (CEN ? 3 : 2)) mt = mt - vload<float, 4>(qb + (long long)c_td * g.s_z + g.s_t);
+        F4 mt = zero;       // every sample with the per-voxel factor of ITS frame (1 without a weight volume)
+        if (UP && k == 0 && t >= 1) mt = mt + vload<float, 4>(qb + (long long)c_tu * g.s_z - g.s_t) * vol_factor<float, 4>(g, zl, t - 1, y, col0);
+        if (DN && k == CP_TWN - 1 && t <= g.m - (CEN ? 3 : 2))
+            mt = mt - vload<float, 4>(qb + (long long)c_td * g.s_z + g.s_t) * vol_factor<float, 4>(g, zl, t + 1, y, col0);
         m = m + (w.wt * mt) * mask_factor<float, 4>(g, w.sf, y, col0);
     }
     const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : (CEN ? 0.5f : 1.f);

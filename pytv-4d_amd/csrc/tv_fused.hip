@@ -74,7 +74,6 @@ int tv_cp_fused_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
     if (g->dtype != TV_F32 || d.nx % 4 != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;
-    if (d.wv != nullptr) return 0;                                  // weight volume: kernel pair on the one-site path
     if (d.m > CP_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_FUSED", 0)) return 0;
@@ -96,7 +95,7 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     if (x_in == x_out) return fail(TV_E_ARG, "x_in and x_out must be different buffers (ping-pong)");
     if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
-    if (!aligned16({x_in, x_prev, x_next, q, x0, p, x_out})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    if (!aligned16({x_in, x_prev, x_next, q, x0, p, x_out, d.wv})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     const int zc = fused_zchunk(d);

@@ -351,18 +351,39 @@ struct SgCol {
                 else if (TWIN) load_rows(sg2_rsrc<T>(pc + foff_t(t + 1), pc != nullptr && has_tn, fbytes), xtn);
                 else xtn = c;
                 if (TWIN && t == 0 && (CEN || DN)) load_rows(sg2_rsrc<T>(pc + foff_t(-1), pc != nullptr && has_tp, fbytes), xtp);
+                // per-VOXEL weight of the time channels (tv_geom::time_weight_vol; generic variant only -- with a weight volume no
+                // tile is FAST): the factor of THIS voxel scales its forward AND its backward channel, so the backward one is no
+                // longer the forward one of frame t-1 and the carry is the unweighted difference.  No volume: a descriptor with
+                // num_records = 0, the loads cost nothing and the factor is 1.
+                C wv_t;
+                if (!FAST) {
+                    const T* wpl = vol_plane<T>(g, zl, t0 + t);          // uniform: the weight frame of (zl, t), ghost planes included
+                    const Rsrc rw = sg2_rsrc<T>(wpl, wpl != nullptr, fbytes);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const T v = sg2_ld(rw, roff[i], T(0));
+                        wv_t.v[i] = (wpl != nullptr) ? v : T(1);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    const T wti = FAST ? wt_u : mft.v[i] * m_pl;
+                    const T wti = FAST ? wt_u : (mft.v[i] * m_pl) * wv_t.v[i];
                     if (CEN) {
                         f_t.v[i] = (has_tn && has_tp) ? wti * (xtn.v[i] - xtp.v[i]) : T(0);
                         b_t.v[i] = T(0);
-                    } else {
+                    } else if (FAST) {
                         f_t.v[i] = has_tn ? wti * (xtn.v[i] - c.v[i]) : T(0);
                         b_t.v[i] = f_t_prev.v[i];
                         if (TWIN && t == 0 && DN) b_t.v[i] = has_tp ? wti * (c.v[i] - xtp.v[i]) : T(0);   // backward difference of the window's first frame
+                    } else {
+                        const T dt = has_tn ? (xtn.v[i] - c.v[i]) : T(0);
+                        f_t.v[i] = wti * dt;
+                        b_t.v[i] = wti * f_t_prev.v[i];                   // f_t_prev carries the RAW difference here
+                        if (TWIN && t == 0 && DN) b_t.v[i] = has_tp ? wti * (c.v[i] - xtp.v[i]) : T(0);
+                        f_t_prev.v[i] = dt;
                     }
                 }
+                if (FAST || CEN)
                 f_t_prev = f_t;
                 c_old_prev = c;
                 // ---- 1 / |Dx| -------------------------------------------------------------------------------------------

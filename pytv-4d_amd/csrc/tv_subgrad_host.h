@@ -13,7 +13,6 @@ inline int sg_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
     if (g->dtype != TV_F32 || d.nx % 4 != 0 || !sg_m_ok(d.m)) return 0;
-    if (d.wv != nullptr) return 0;                                  // weight volume: two-pass kernels
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return 0;   // two-point axes: forward stencil
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (d.m > SG_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
@@ -69,7 +68,7 @@ inline int sg2_launch_f32(const tv_geom* g, const DG& d, const void* x, const vo
     SgTiles tm{};
     tm.tx = (int)tx; tm.ty = (int)ty;
     int ix0 = 1, ix1 = (int)((d.nx - 2 - 63 + RING) / UC), iy0 = 1, iy1 = (int)((d.ny - RB) / UR);
-    if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || ix1 < ix0 || iy1 < iy0) { ix0 = iy0 = 1; ix1 = iy1 = 0; }
+    if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || d.wv != nullptr || ix1 < ix0 || iy1 < iy0) { ix0 = iy0 = 1; ix1 = iy1 = 0; }
     tm.ix0 = ix0; tm.ix1 = ix1; tm.iy0 = iy0; tm.iy1 = iy1;
     tm.nfast = (long long)(ix1 - ix0 + 1) * (iy1 - iy0 + 1);
     tm.nborder = tx * ty - tm.nfast;
@@ -111,6 +110,7 @@ inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const 
     // take the round-1 kernel; frames must stay below 2^31 bytes for its buffer addressing
     if (env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * 4 < (1ll << 31) && (MODE != 1 || (double)sa.step * (double)sa.lambda >= 1e-6))
         return sg2_launch_f32<MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, sa);
+    if (d.wv != nullptr) return fail(TV_E_ARG, "a weight volume needs the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad");
     const long long nmax = max_partials(d);
     constexpr int NW = 4, UR = 4 * NW - 2, UC = 14;
     const long long tx = (d.nx / 4 + UC - 1) / UC, ty = (d.ny + UR - 1) / UR;

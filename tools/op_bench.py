@@ -33,6 +33,8 @@ print("shape %s  V = %.0f Mvox  dtype %s; GB/s = algorithmic bytes / time; frac 
 print("%-9s %-22s %8s %9s %7s  %s" % ("scheme", "op", "ms", "GB/s", "frac", "algorithmic words/voxel"))
 for scheme in schemes:
     kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
+    if os.environ.get("WEIGHT", "") == "vol":       # per-voxel weight on the time channels: sqrt(W) resident on the device
+        kw["weight_dev"] = (torch.sqrt(torch.rand(shape, device=dev, generator=gen) * 2.0).to(x.dtype), None, None)
     g = nv.Geometry(shape, scheme, x.dtype, dev, **kw)
     nd, st, ws = g.nd, nv.current_stream(dev), g.workspace()
     d = torch.empty(g.grad_shape, device=dev, dtype=x.dtype)
@@ -55,6 +57,17 @@ for scheme in schemes:
         ("tv_cp_dual", 1 + 2 * nd, lambda: nv.check(lib.tv_cp_dual(g.ref, nv.ptr(x), None, None, nv.ptr(d), 0.5, 25.0, nv.ptr(sc), nv.ptr(ws), st))),
         ("tv_cp_primal", nd + 5, lambda: nv.check(lib.tv_cp_primal(g.ref, nv.ptr(d), None, None, nv.ptr(o), nv.ptr(x), nv.ptr(o2), 0.05, 1.0, nv.ptr(sc), nv.ptr(ws), st))),
     ]
+    wvol = 1 if "weight_dev" in kw else 0          # one more word per voxel wherever the time channels are formed
+
+    def cp_sweep():
+        nv.check(lib.tv_cp_fused(g.ref, nv.ptr(x), None, None, nv.ptr(d), nv.ptr(x), nv.ptr(o2), nv.ptr(o), 0.5, 25.0, 1.0 / 17.0, 1.0, 0, -1,
+                                 nv.ptr(sc), nv.ptr(sc), nv.ptr(ws), st))
+        nv.check(lib.tv_cp_fixup(g.ref, nv.ptr(d), None, None, nv.ptr(o), nv.ptr(x), 1.0 / 17.0, 0, -1, nv.ptr(sc), nv.ptr(ws), st))
+
+    if lib.tv_cp_fused_supported(g.ref):
+        ops.append(("cp_sweep+fixup", 5 + 2 * nd + wvol, cp_sweep))
+    if wvol:
+        ops = [(n, wd + (1 if n in ("tv_D", "tv_subgrad_fused", "tv_subgrad_fused_norms", "tv_cp_dual", "tv_subgrad", "tv_admm_zu") else 0), f) for n, wd, f in ops]
     only = [o for o in os.environ.get("OPS", "").split(",") if o]
     for name, words, f in ops:
         if (only and name not in only) or f is None:
