@@ -8,7 +8,7 @@ int tv_subgrad_step_fused(const tv_geom* g, const void* x, const void* x_prev, c
                           double step, double lambda, double* tvout, double* fid, void* ws, void* stream) {
     if (x0 == nullptr || x_out == nullptr || fid == nullptr) return fail(TV_E_ARG, "NULL array");
     if (x == x_out) return fail(TV_E_ARG, "x and x_out must be different buffers (ping-pong)");
-    SgStepArgs sa{(const float*)x0, (float*)x_out, (float)step, (float)lambda, nullptr, nullptr};
+    SgHostArgs sa{x0, x_out, step, lambda, nullptr};
     return sg_launch<1>(g, x, x_prev, x_next, nullptr, tvout, fid, ws, stream, sa,
                         "tv_subgrad_step_fused on a slab needs two halo planes on each interior side");
 }

@@ -8,7 +8,7 @@ int tv_subgrad_fused_supported(const tv_geom* g) { return sg_supported(g); }
 int tv_subgrad_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
                      void* ws, void* stream) {
     if (G == nullptr) return fail(TV_E_ARG, "NULL array");
-    return sg_launch<0>(g, x, x_prev, x_next, G, tvout, nullptr, ws, stream, SgStepArgs{},
+    return sg_launch<0>(g, x, x_prev, x_next, G, tvout, nullptr, ws, stream, SgHostArgs{},
                         "tv_subgrad_fused on a slab needs two halo planes on each interior side");
 }
 
@@ -16,8 +16,8 @@ int tv_subgrad_fused_norms(const tv_geom* g, const void* x, const void* x_prev, 
                            double* tvout, void* ws, void* stream) {
     if (G == nullptr || norms == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!aligned16({norms})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
-    SgStepArgs sa{};
-    sa.norms = (float*)norms;
+    SgHostArgs sa{};
+    sa.norms = norms;
     return sg_launch<2>(g, x, x_prev, x_next, G, tvout, nullptr, ws, stream, sa,
                         "tv_subgrad_fused_norms on a slab needs two halo planes on each interior side");
 }

@@ -109,7 +109,10 @@ constexpr int SG2_D = TV_SG2_D;                        // depth of the x(z+1) lo
 
 // MODE 0: G stored.  MODE 1: the descent step x_out = x - step ((x - x0) + lambda G), 1/2 |x_out - x0|^2 reduced (README.md:118-124).
 // MODE 2: G and the per-voxel norms |Dx| (zeros -> +inf: the reference's grad_norms, pytv/tv_GPU.py:88,135-139).
-template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN>
+// XLD: the rows just above / below a wave's strip come from MEMORY (two more loads per frame, L1 / L2 hits: the neighbouring
+// wave requests the same lines) instead of the LDS hand-off xe -- half the LDS, which is what lets the fp64 instantiation
+// (R = 2 rows of doubles: the same registers as R = 4 floats) keep two blocks per CU.
+template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false>
 struct SgCol {
     static constexpr bool CEN = (S == CENTRAL);
     static constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
@@ -127,7 +130,7 @@ struct SgCol {
     struct Shared {
         // [parity][frame][row][lane]; row 2 w = first row of wave w's strip, 2 w + 1 = its last row, row ZR = zeros (what the
         // first / last wave of the block reads instead of a neighbour: no select, no multiplier)
-        T xe[2][M][ROWS][64];       // x of plane z (parity z & 1)
+        T xe[XLD ? 1 : 2][XLD ? 1 : M][XLD ? 1 : ROWS][64];       // x of plane z (parity z & 1); XLD: unused
         T ye[2][M][ROWS][64];       // row products of step z: [2 w] for the wave above, [2 w + 1] for the wave below
         double sm[16];
     };
@@ -185,15 +188,25 @@ struct SgCol {
         // the row just outside the tile (hybrid / central: the norm of a ring row needs it): read from memory by the first /
         // last wave; every other wave requests an out-of-range offset and gets 0
         unsigned hoff = SG2_OOB;
-        if (HALO && in_x) {
+        if (HALO && in_x && !XLD) {
             if (wv == 0 && yb > 0) hoff = (unsigned)(((long long)(yb - 1) * g.nx + cx) * (long long)sizeof(T));
             if (wv == NW - 1 && yb + R < g.ny) hoff = (unsigned)(((long long)(yb + R) * g.nx + cx) * (long long)sizeof(T));
+        }
+        // XLD: EVERY wave reads the row above / below its strip (where the scheme needs it and the row exists: the block's first /
+        // last wave only for the schemes whose ring norm looks outwards, exactly like the halo load above)
+        unsigned uoff = SG2_OOB, doff = SG2_OOB;
+        if (XLD && in_x) {
+            if ((DN || CEN) && yb > 0 && (wv > 0 || HALO)) uoff = (unsigned)(((long long)(yb - 1) * g.nx + cx) * (long long)sizeof(T));
+            if ((UP || CEN) && yb + R < g.ny && (wv < NW - 1 || HALO)) doff = (unsigned)(((long long)(yb + R) * g.nx + cx) * (long long)sizeof(T));
         }
         // LDS hand-off rows: own pair, the neighbour's row above / below (the zero row at the block's ends)
         const int r_own = 2 * wv, r_up = (wv > 0) ? 2 * (wv - 1) + 1 : ZR, r_dn = (wv < NW - 1) ? 2 * (wv + 1) : ZR;
         if (wv == 0) {
 #pragma unroll
-            for (int t = 0; t < M; ++t) sh.xe[0][t][ZR][lane] = sh.xe[1][t][ZR][lane] = sh.ye[0][t][ZR][lane] = sh.ye[1][t][ZR][lane] = T(0);
+            for (int t = 0; t < M; ++t) {
+                if (!XLD) sh.xe[0][t][ZR][lane] = sh.xe[1][t][ZR][lane] = T(0);
+                sh.ye[0][t][ZR][lane] = sh.ye[1][t][ZR][lane] = T(0);
+            }
         }
 #pragma unroll
         for (int t = 0; t < M; ++t)        // the first step reads the "previous step's" products for a store that is dropped: keep them finite
@@ -233,8 +246,10 @@ struct SgCol {
                 }
 #pragma unroll
                 for (int i = 0; i < R; ++i) Gp[t].v[i] = Gc[t].v[i] = T(0);
-                sh.xe[z_lo & 1][t][r_own][lane] = Cc[t].v[0];
-                sh.xe[z_lo & 1][t][r_own + 1][lane] = Cc[t].v[R - 1];
+                if (!XLD) {
+                    sh.xe[z_lo & 1][t][r_own][lane] = Cc[t].v[0];
+                    sh.xe[z_lo & 1][t][r_own + 1][lane] = Cc[t].v[R - 1];
+                }
             }
         }
         auto next_plane = [&](int zl) -> const T* {                 // plane zl+1 if this chunk needs it
@@ -247,22 +262,36 @@ struct SgCol {
             for (int d = 0; d < H; ++d) load_rows(frame(pn, d), HEADS ? Nh[HEADS ? d : 0] : Nq[d]);
         }
         __syncthreads();
+        // plane zl+1 exists in memory for this call iff it is a local plane or a supplied halo plane: same answer as zplane(),
+        // but for the CURRENT plane of the next step it was already computed as this step's "next" unless the chunk did not need it
+        auto zplane_cheap = [&](int zl) -> const T* { return zplane<T>(g, x, xp, xn, 2, zl); };
+        const T* pc_c = zplane<T>(g, x, xp, xn, 2, z_lo);
+        const T* pn_c = next_plane(z_lo);
 
         for (int zl = z_lo; zl <= ze; ++zl) {
             const int gz = g.z0 + zl, par = zl & 1;
             const bool plane_in = (gz >= 0) && (gz < g.nzg) && (zl < ze || g.za);
-            const T* pc = zplane<T>(g, x, xp, xn, 2, zl);
-            const T* pn = next_plane(zl);
+            const T* pc = pc_c;                                            // carried: one zplane() per step instead of three
+            const T* pn = pn_c;
             const T* pn2 = (zl + 1 <= ze) ? next_plane(zl + 1) : nullptr;
+            pc_c = zplane_cheap(zl + 1);
+            pn_c = pn2;
             const bool z_prev = plane_in && (gz > 0), z_next = plane_in && (gz + 1 < g.nzg);
             const T wzn = (CEN ? (z_prev && z_next) : z_next) ? wz_u : T(0), wzp = (CEN ? (z_prev && z_next) : z_prev) ? wz_u : T(0);
             const T m_pl = plane_in ? T(1) : T(0);
             const bool count = plane_in && (zl >= zs) && (zl < ze);
             const bool store = (zl - 1 >= zs) && (zl - 1 < ze);
-            T hq[2] = {T(0), T(0)};
-            if (HALO) {
+            T hq[2] = {T(0), T(0)}, hu[2] = {T(0), T(0)}, hd[2] = {T(0), T(0)};
+            if (HALO && !XLD) {
                 hq[0] = sg2_ld(frame(pc, 0), hoff, T(0));
                 if (M > 1) hq[1] = sg2_ld(frame(pc, 1), hoff, T(0));
+            }
+            if (XLD) {
+#pragma unroll
+                for (int k = 0; k < 2 && k < M; ++k) {
+                    if (DN || CEN) hu[k] = sg2_ld(frame(pc, k), uoff, T(0));
+                    if (UP || CEN) hd[k] = sg2_ld(frame(pc, k), doff, T(0));
+                }
             }
             C x0q;                                  // MODE 1: x0 of the frame about to be stored, requested a frame ahead
             if (MODE == 1 && TV_SG2_X0_AHEAD) {
@@ -274,9 +303,11 @@ struct SgCol {
 #pragma unroll
                 for (int d = 0; d < H; ++d) Nq[d] = Nh[HEADS ? d : 0];
             }
-            T xu_n = T(0), xd_n = T(0);
-            if (DN || CEN) xu_n = sh.xe[par][0][r_up][lane];
-            if (UP || CEN) xd_n = sh.xe[par][0][r_dn][lane];
+            T xu_n = T(0), xd_n = T(0), yu_n = T(0), yd_n = T(0);
+            if ((DN || CEN) && !XLD) xu_n = sh.xe[par][0][r_up][lane];
+            if ((UP || CEN) && !XLD) xd_n = sh.xe[par][0][r_dn][lane];
+            if (UP || CEN) yu_n = sh.ye[par ^ 1][0][r_up][lane];
+            if (DN || CEN) yd_n = sh.ye[par ^ 1][0][r_dn][lane];
             C pf_t_prev, f_t_prev, c_old_prev;      // time-axis carries: product / forward difference / x of frame t-1
 #pragma unroll
             for (int i = 0; i < R; ++i) pf_t_prev.v[i] = f_t_prev.v[i] = c_old_prev.v[i] = T(0);
@@ -286,11 +317,19 @@ struct SgCol {
                 const C nx = Nq[t % SG2_D];          // x(zl+1, t)
                 // ---- row neighbours across the strip's ends -----------------------------------------------------------
                 T xu = xu_n, xd = xd_n;              // read from LDS one frame ahead (two waves per SIMD do not hide an LDS round trip)
-                if (t + 1 < M) {
+                if (t + 1 < M && !XLD) {
                     if (DN || CEN) xu_n = sh.xe[par][(t + 1 < M) ? t + 1 : t][r_up][lane];
                     if (UP || CEN) xd_n = sh.xe[par][(t + 1 < M) ? t + 1 : t][r_dn][lane];
                 }
-                if (HALO) {                          // first / last wave: LDS gave 0, the halo load the value; every other wave: the reverse
+                if (XLD) {                           // from memory, requested two frames ahead
+                    xu = hu[t & 1];
+                    xd = hd[t & 1];
+                    if (t + 2 < M) {
+                        if (DN || CEN) hu[t & 1] = sg2_ld(frame(pc, t + 2), uoff, T(0));
+                        if (UP || CEN) hd[t & 1] = sg2_ld(frame(pc, t + 2), doff, T(0));
+                    }
+                }
+                if (HALO && !XLD) {                          // first / last wave: LDS gave 0, the halo load the value; every other wave: the reverse
                     const T h = hq[t & 1];
                     if (t + 2 < M) hq[t & 1] = sg2_ld(frame(pc, t + 2), hoff, T(0));
                     xu += h * m_hu;
@@ -303,8 +342,10 @@ struct SgCol {
                     for (int i = 0; i < R; ++i) x0n.v[i] = sg2_ld(r0, soff[i], T(0));
                 }
                 // publish the strip ends of plane zl+1 for the next step
-                sh.xe[par ^ 1][t][r_own][lane] = nx.v[0];
-                sh.xe[par ^ 1][t][r_own + 1][lane] = nx.v[R - 1];
+                if (!XLD) {
+                    sh.xe[par ^ 1][t][r_own][lane] = nx.v[0];
+                    sh.xe[par ^ 1][t][r_own + 1][lane] = nx.v[R - 1];
+                }
                 // ---- raw differences --------------------------------------------------------------------------------------
                 // dr[i] = x(row i+1) - x(row i) for i = -1 .. R-1 (index shifted by one): the forward row differences of the
                 // strip and of the row above it
@@ -502,8 +543,12 @@ struct SgCol {
                     const bool st = store && fstore(t);
                     const long long foff = (long long)(zl - 1) * g.s_z + foff_t(t);      // uniform
                     // the row products the neighbouring waves published in the previous step (zero row at the block's ends)
-                    if (UP || CEN) Gp[t].v[0] += sh.ye[par ^ 1][t][r_up][lane];
-                    if (DN || CEN) Gp[t].v[R - 1] -= sh.ye[par ^ 1][t][r_dn][lane];
+                    if (UP || CEN) Gp[t].v[0] += yu_n;
+                    if (DN || CEN) Gp[t].v[R - 1] -= yd_n;
+                    if (t + 1 < M) {                 // next frame's, a frame ahead
+                        if (UP || CEN) yu_n = sh.ye[par ^ 1][(t + 1 < M) ? t + 1 : t][r_up][lane];
+                        if (DN || CEN) yd_n = sh.ye[par ^ 1][(t + 1 < M) ? t + 1 : t][r_dn][lane];
+                    }
                     if (MODE != 1) {
                         const Rsrc rg = sg2_rsrc<T>(G + foff, st, fbytes);
 #pragma unroll
@@ -544,7 +589,9 @@ struct SgCol {
                 __builtin_amdgcn_sched_barrier(0);   // keep the frames apart: interleaving them costs registers (scratch) for nothing
 #endif
             }
-            __syncthreads();
+            // LDS-only barrier: the hand-off rows must be visible, nothing else.  __syncthreads() would also drain vmcnt -- the
+            // stores of this plane and the look-ahead loads of the next one, one exposed memory round trip per plane
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         acc = block_sum(acc, sh.sm);
         if (threadIdx.x == 0 && threadIdx.y == 0) partials[lid] = acc;
@@ -591,11 +638,11 @@ __device__ __forceinline__ void sg2_tile(const SgTiles& tm, bool fast, long long
     }
 }
 
-template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN>
+template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false>
 __global__ __launch_bounds__(64 * NW, (NW <= 4) ? 2 : 1) void k_subgrad_col(DG g, WT<T> w, const T* __restrict__ x, const T* __restrict__ xp,
                                                                             const T* __restrict__ xn, T* __restrict__ G, int zchunk, int nchunks,
                                                                             double* __restrict__ partials, SgArgs2<T> sa, SgTiles tm) {
-    using K = SgCol<S, T, M, R, NW, MODE, TWIN>;
+    using K = SgCol<S, T, M, R, NW, MODE, TWIN, XLD>;
     __shared__ typename K::Shared sh;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + SG2_TWU - 1) / SG2_TWU : 1;

@@ -12,7 +12,9 @@ inline bool sg_m_ok(int m) { return m >= 1; }
 inline int sg_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
-    if (g->dtype != TV_F32 || d.nx % 4 != 0 || !sg_m_ok(d.m)) return 0;
+    if (!sg_m_ok(d.m)) return 0;
+    if (g->dtype == TV_F32 ? (d.nx % 4 != 0) : (d.nx % 2 != 0 || env_int("TV_SG_KERNEL", 2) == 1)) return 0;   // fp64: round-3 kernel only
+    if (g->dtype == TV_F64 && d.s_t * 8 >= (1ll << 31)) return 0;
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return 0;   // two-point axes: forward stencil
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (d.m > SG_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
@@ -40,13 +42,24 @@ template <typename F> inline int dispatch_sg(int scheme, int m, F&& f) {
     return fail(TV_E_ARG, "unsupported (scheme, M) for the one-pass sub-gradient");
 }
 
+// what the C entry points hand to the launcher (dtype-neutral)
+struct SgHostArgs {
+    const void* x0 = nullptr;
+    void* x_out = nullptr;
+    double step = 0.0, lambda = 0.0;
+    void* norms = nullptr;
+};
+
 // ---- round-3 kernel (tv_subgrad2.h): a lane = R rows x 1 column -----------------------------------------------------------
-// fp32: R = 4, 4 waves per block (tile 16 rows x 64 columns, 14 x 60 / 62 stored).  TV_SG_KERNEL=1 selects the round-1 kernel
-// (k_subgrad_one) for A/B.
-template <int MODE>
-inline int sg2_launch_f32(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
-                          double* fidout, void* ws, hipStream_t st, const SgStepArgs& so) {
-    constexpr int R = 4, NW = 4;
+// fp32: R = 4 rows per lane, 4 waves per block (tile 16 rows x 64 columns, 14 x 60 / 62 stored), row hand-off through LDS.
+// fp64: R = 2 (the same registers), tile 8 x 64 (6 x 60 / 62 stored), neighbour rows from memory (XLD) so that two blocks still
+// fit a CU's LDS.  TV_SG_KERNEL=1 selects the round-1 kernel (k_subgrad_one, fp32 only) for A/B.
+template <typename T, int MODE>
+inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
+                      double* fidout, void* ws, hipStream_t st, const SgHostArgs& so) {
+    constexpr bool F64 = sizeof(T) == 8;
+    constexpr int R = F64 ? 2 : 4, NW = 4;
+    constexpr bool XLD = F64;
     const long long nmax = max_partials(d);
     const bool halo = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL);
     const int UR = R * NW - 2, UC = halo ? 60 : 62;
@@ -79,12 +92,12 @@ inline int sg2_launch_f32(const tv_geom* g, const DG& d, const void* x, const vo
     const dim3 block(64, NW, 1);
     double* w0 = (double*)ws;
     double* w1 = w0 + nmax + kStage + 16;
-    SgArgs2<float> sa{so.x0, so.x_out, so.step, so.lambda, w1, so.norms};
+    SgArgs2<T> sa{(const T*)so.x0, (T*)so.x_out, (T)so.step, (T)so.lambda, w1, (T*)so.norms};
     int rc = dispatch_sg(g->scheme, d.m > SG2_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
         constexpr int MM = (M == 0) ? SG2_TWN : M;
         constexpr bool TW = (M == 0);
-        hipLaunchKernelGGL((k_subgrad_col<S, float, MM, R, NW, MODE, TW>), dim3((unsigned)ngrid), block, 0, st, d, make_w<float>(g),
-                           (const float*)x, (const float*)x_prev, (const float*)x_next, (float*)G, zc, (int)nch, w0, sa, tm);
+        hipLaunchKernelGGL((k_subgrad_col<S, T, MM, R, NW, MODE, TW, XLD>), dim3((unsigned)ngrid), block, 0, st, d, make_w<T>(g),
+                           (const T*)x, (const T*)x_prev, (const T*)x_next, (T*)G, zc, (int)nch, w0, sa, tm);
         HIP_TRY(hipGetLastError());
         return 0;
     });
@@ -97,20 +110,26 @@ inline int sg2_launch_f32(const tv_geom* g, const DG& d, const void* x, const vo
 // common argument checks + launch geometry; MODE 1 passes the step arguments, MODE 0 an empty struct
 template <int MODE>
 inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout, double* fidout,
-                     void* ws, void* stream, SgStepArgs sa, const char* who) {
+                     void* ws, void* stream, const SgHostArgs& ha, const char* who) {
     DG d;
     if (int rc = make_dg(g, d)) return rc;
     if (x == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!sg_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-pass sub-gradient");
-    if (!aligned16({x, x_prev, x_next, G, sa.x0, sa.x_out})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    if (!aligned16({x, x_prev, x_next, G, ha.x0, ha.x_out})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
     if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr))) return fail(TV_E_HALO, who);
     hipStream_t st = (hipStream_t)stream;
     // round-3 kernel unless switched off; its descent step divides by step * lambda (tv_subgrad2.h): tiny or zero products
     // take the round-1 kernel; frames must stay below 2^31 bytes for its buffer addressing
-    if (env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * 4 < (1ll << 31) && (MODE != 1 || (double)sa.step * (double)sa.lambda >= 1e-6))
-        return sg2_launch_f32<MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, sa);
+    const bool step_ok = (MODE != 1 || ha.step * ha.lambda >= 1e-6);
+    if (g->dtype == TV_F64) {
+        if (!step_ok) return fail(TV_E_ARG, "the fp64 one-pass descent step needs step * lambda >= 1e-6: use tv_subgrad + tv_subgrad_step");
+        return sg2_launch<double, MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
+    }
+    if (env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * 4 < (1ll << 31) && step_ok)
+        return sg2_launch<float, MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
     if (d.wv != nullptr) return fail(TV_E_ARG, "a weight volume needs the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad");
+    SgStepArgs sa{(const float*)ha.x0, (float*)ha.x_out, (float)ha.step, (float)ha.lambda, nullptr, (float*)ha.norms};
     const long long nmax = max_partials(d);
     constexpr int NW = 4, UR = 4 * NW - 2, UC = 14;
     const long long tx = (d.nx / 4 + UC - 1) / UC, ty = (d.ny + UR - 1) / UR;

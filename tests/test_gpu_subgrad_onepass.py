@@ -168,7 +168,7 @@ def test_one_pass_rejects_what_it_does_not_support(pytv):
     lib = nv.lib()
     for shape, scheme, dt, kw in (((2, 1, 8, 64), "central", torch.float32, {}),                       # two-point z axis
                                   ((3, 2, 8, 64), "central", torch.float32, dict(reg_time=1.0)),       # two-point time axis
-                                  ((2, 1, 8, 64), "hybrid", torch.float64, {}), ((2, 1, 8, 66), "hybrid", torch.float32, {}),
+                                  ((2, 1, 8, 65), "hybrid", torch.float64, {}), ((2, 1, 8, 66), "hybrid", torch.float32, {}),
                                   ((2, 1, 8, 7), "downwind", torch.float32, {}),
                                   ((2, 16, 8, 66), "upwind", torch.float32, {})):
         g = nv.Geometry(shape, scheme, dt, torch.device("cuda", 0), **kw)
@@ -178,6 +178,9 @@ def test_one_pass_rejects_what_it_does_not_support(pytv):
         rc = lib.tv_subgrad_fused(g.ref, nv.ptr(x), None, None, nv.ptr(G), nv.ptr(g.scalar()), nv.ptr(g.workspace()),
                                   nv.current_stream(x.device))
         assert rc < 0
+    # round 3: fp64 has a one-pass kernel of its own (even Nx)
+    g = nv.Geometry((2, 1, 8, 64), "hybrid", torch.float64, torch.device("cuda", 0))
+    assert lib.tv_subgrad_fused_supported(g.ref) == 1
     # central with a two-point axis that is switched off is fine
     g = nv.Geometry((3, 2, 8, 64), "central", torch.float32, torch.device("cuda", 0), reg_time=0.0)
     assert lib.tv_subgrad_fused_supported(g.ref) == 1
