@@ -29,6 +29,38 @@ __device__ __forceinline__ float dpp_from_left(float v) {      // lane-1 inside 
 __device__ __forceinline__ float dpp_from_right(float v) {     // lane+1 inside the 16-lane row (lane 15 of a row: 0)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
 }
+__device__ __forceinline__ double dpp_from_left(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x111, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double dpp_from_right(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x101, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// dtype-generic forms of ldu / ldu1 / stu (tv_fused.h) and of the 16-lane row shuffles: a lane holds V = 16 / sizeof(T) columns
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> ldu_t(const T* ubase, unsigned voff) {
+    return *reinterpret_cast<const Vec<T, V>*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+template <typename T> __device__ __forceinline__ T ldu1_t(const T* ubase, unsigned voff) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+template <typename T, int V> __device__ __forceinline__ void stu_t(T* ubase, unsigned voff, const Vec<T, V>& v) {
+    *reinterpret_cast<Vec<T, V>*>(reinterpret_cast<char*>(ubase) + voff) = v;
+}
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> shfl_up16_t(const Vec<T, V>& v) {
+    Vec<T, V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = __shfl_up(v.v[i], 16, 64);
+    return r;
+}
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> shfl_down16_t(const Vec<T, V>& v) {
+    Vec<T, V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = __shfl_down(v.v[i], 16, 64);
+    return r;
+}
 
 constexpr int DS_TWN = 8;      // frames per time window (M > 8)
 
@@ -56,15 +88,17 @@ constexpr int ST_BR = 4 * ST_NWY;        // rows per block tile
 // block (64, 4): wave w covers columns [64 w, 64 w + 64) of a 4-row x 256-column block tile; grid.x = XCD-ordered
 // (tile, chunk, window) ids.  TWIN: the block works on frames [t0, t0 + M) of a volume with more than 8 frames and reads
 // the x frame on either side of its window for the time differences (M == DS_TWN).
-template <int S, int M, bool TWIN>
-__global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 : 3) void k_D_stream(DG g, WT<float> w, const float* __restrict__ x,
-                                                                       const float* __restrict__ xp, const float* __restrict__ xn,
-                                                                       float* __restrict__ d, int zchunk, int nchunks) {
+template <int S, int M, bool TWIN, typename T = float>
+__global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 : 3) void k_D_stream(DG g, WT<T> w, const T* __restrict__ x,
+                                                                       const T* __restrict__ xp, const T* __restrict__ xn,
+                                                                       T* __restrict__ d, int zchunk, int nchunks) {
+    constexpr int V = 16 / (int)sizeof(T);          // columns per lane (16-byte lanes): 4 floats / 2 doubles
+    using VT = Vec<T, V>;
     constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID), CEN = (S == CENTRAL);
     constexpr bool NEXT = (S != DOWNWIND), PREV = (S != UPWIND);
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
-    const int nxv = g.nx / 4;
+    const int nxv = g.nx / V;
     const int tiles_x = (nxv + ST_BCV - 1) / ST_BCV, tiles_y = (g.ny + ST_BR - 1) / ST_BR;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + DS_TWN - 1) / DS_TWN : 1;
@@ -77,14 +111,14 @@ __global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8
     const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
     const int t0 = TWIN ? win * DS_TWN : 0;
     const int bx = tile % tiles_x, by = tile / tiles_x;
-    const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * 4, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
+    const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * V, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
     const bool ok = (col0 < g.nx) && (y < g.ny);
-    const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * 4) : 0u;      // byte offset inside a frame
-    const unsigned row_bytes = (unsigned)g.nx * 4u;
+    const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * (long long)sizeof(T)) : 0u;      // byte offset inside a frame
+    const unsigned row_bytes = (unsigned)g.nx * (unsigned)sizeof(T);
     const int zs = chunk * zchunk;
     const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
-    const F4 zero = vsplat<float, 4>(0.f);
-    const F4 mf = g.ta ? mask_factor<float, 4>(g, w.sf, ok ? y : 0, ok ? col0 : 0) : vsplat<float, 4>(1.f);
+    const VT zero = vsplat<T, V>(T(0));
+    const VT mf = g.ta ? mask_factor<T, V>(g, w.sf, ok ? y : 0, ok ? col0 : 0) : vsplat<T, V>(T(1));
     const bool z_fwd = CEN && g.z_two;
     // halo row / edge element of this lane (one predicated load each per frame)
     const bool want_up = PREV && (row == 0) && ok && (y > 0);
@@ -92,28 +126,28 @@ __global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8
     const bool want_halo = want_up || want_dn;
     const unsigned hoff = want_up ? voff - row_bytes : voff + row_bytes;
     const bool want_le = PREV && (lx == 0) && ok && (col0 > 0);
-    const bool want_re = NEXT && (lx == 15) && ok && (col0 + 4 < g.nx);
+    const bool want_re = NEXT && (lx == 15) && ok && (col0 + V < g.nx);
     const bool want_edge = want_le || want_re;
-    const unsigned eoff = want_le ? voff - 4u : voff + 16u;
+    const unsigned eoff = want_le ? voff - (unsigned)sizeof(T) : voff + 16u;
 
     auto fvalid = [&](int t) { return !TWIN || (t0 + t < Mg); };
     auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };             // uniform
     // state: plane z (C), plane z-1 (P), central: plane z-2 (P2); halo rows and edge elements of plane z
-    F4 C[M], P[M], P2[CEN ? M : 1], H[M];
-    float E[M];
-    auto load_plane = [&](const float* pl, int t, bool with_halo, F4& c, F4& h, float& e) {
+    VT C[M], P[M], P2[CEN ? M : 1], H[M];
+    T E[M];
+    auto load_plane = [&](const T* pl, int t, bool with_halo, VT& c, VT& h, T& e) {
         const bool v = (pl != nullptr) && fvalid(t);
-        c = (v && ok) ? ldu(pl + foff(t), voff) : zero;
-        h = (v && with_halo && want_halo) ? ldu(pl + foff(t), hoff) : zero;
-        e = (v && with_halo && want_edge) ? ldu1(pl + foff(t), eoff) : 0.f;
+        c = (v && ok) ? ldu_t<T, V>(pl + foff(t), voff) : zero;
+        h = (v && with_halo && want_halo) ? ldu_t<T, V>(pl + foff(t), hoff) : zero;
+        e = (v && with_halo && want_edge) ? ldu1_t<T>(pl + foff(t), eoff) : T(0);
     };
     {
-        const float* pc = zplane<float>(g, x, xp, xn, 1, zs);
-        const float* pp = (g.za && (PREV || UP)) ? zplane<float>(g, x, xp, xn, 1, zs - 1) : nullptr;
+        const T* pc = zplane<T>(g, x, xp, xn, 1, zs);
+        const T* pp = (g.za && (PREV || UP)) ? zplane<T>(g, x, xp, xn, 1, zs - 1) : nullptr;
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             load_plane(pc, t, true, C[t], H[t], E[t]);
-            P[t] = (pp != nullptr && ok && fvalid(t)) ? ldu(pp + foff(t), voff) : zero;
+            P[t] = (pp != nullptr && ok && fvalid(t)) ? ldu_t<T, V>(pp + foff(t), voff) : zero;
             if (CEN) P2[t] = zero;       // x(zs - 2) is never needed: the z channel of plane zs - 1 is the previous chunk's
         }
     }
@@ -128,61 +162,61 @@ __global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8
         const bool plane_prev = (gz > 0);
         // plane to request now (consumed at step z + 1)
         const bool need_next = (z + 1 <= z_last);
-        const float* pn = need_next ? zplane<float>(g, x, xp, xn, 1, z + 1) : nullptr;
-        float* dz_cur = d + (long long)z * g.s_dz;                             // gradient plane z (uniform)
-        float* dz_prv = d + (long long)(z - 1) * g.s_dz;
-        F4 cold = zero;          // x(z, t-1)
+        const T* pn = need_next ? zplane<T>(g, x, xp, xn, 1, z + 1) : nullptr;
+        T* dz_cur = d + (long long)z * g.s_dz;                             // gradient plane z (uniform)
+        T* dz_prv = d + (long long)(z - 1) * g.s_dz;
+        VT cold = zero;          // x(z, t-1)
         if (TWIN && in_chunk && g.ta && t0 > 0 && PREV) {                     // frame left of the window (backward / central in t)
-            const float* pc = zplane<float>(g, x, xp, xn, 1, z);
-            cold = ok ? ldu(pc + foff(-1), voff) : zero;
+            const T* pc = zplane<T>(g, x, xp, xn, 1, z);
+            cold = ok ? ldu_t<T, V>(pc + foff(-1), voff) : zero;
         }
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             if (TWIN && !fvalid(t)) break;                                    // ragged last window (block-uniform)
             st_sync_frame();
             const int tg = t0 + t;
-            const F4 c = C[t];
+            const VT c = C[t];
             // ---- z differences of this step ---------------------------------------------------------------------
             // radius-1 schemes: dzv = wz (x(z) - x(z-1)) is D_down(z) and D_up(z-1); central: wz (x(z) - x(z-2)) is 2 D(z-1)
-            F4 dzv = zero;
+            VT dzv = zero;
             if (g.za) {
                 if (!CEN || z_fwd) { if (plane_here && plane_prev) dzv = w.wz * (c - P[t]); }
                 else if (plane_here && gz >= 2) dzv = w.wz * (c - P2[t]);
             }
             // ---- in-plane and time channels of plane z -------------------------------------------------------------
-            XN<float, 4> n;
+            XN<T, V> n;
             n.c = c;
             n.col0 = col0;
             n.nr = n.pr = n.nc = n.pc = n.nz = n.pz = n.nt = n.pt = zero;
             n.h_nr = n.h_pr = n.h_nz = n.h_pz = n.h_nt = n.h_pt = false;
             if (in_chunk) {
-                const F4 h = H[t];
+                const VT h = H[t];
                 if (NEXT) {
                     n.h_nr = ok && (y + 1 < g.ny);
-                    const F4 sdn = shfl_down16(c);
+                    const VT sdn = shfl_down16_t<T, V>(c);
                     n.nr = (row == 3) ? h : sdn;
-                    const float sh = dpp_from_right(c.v[0]);
-                    n.nc = shift_left<float, 4>(c, (lx == 15) ? E[t] : sh);
+                    const T sh = dpp_from_right(c.v[0]);
+                    n.nc = shift_left<T, V>(c, (lx == 15) ? E[t] : sh);
                     if (t + 1 < M) { n.h_nt = (g.ta != 0) && (tg + 1 < Mg); n.nt = C[(t + 1 < M) ? t + 1 : t]; }
                     else if (TWIN && g.ta && tg + 1 < Mg) {                    // frame right of the window
-                        const float* pc = zplane<float>(g, x, xp, xn, 1, z);
+                        const T* pc = zplane<T>(g, x, xp, xn, 1, z);
                         n.h_nt = true;
-                        n.nt = ok ? ldu(pc + foff(t + 1), voff) : zero;
+                        n.nt = ok ? ldu_t<T, V>(pc + foff(t + 1), voff) : zero;
                     }
                 }
                 if (PREV) {
                     n.h_pr = ok && (y > 0);
-                    const F4 sup = shfl_up16(c);
+                    const VT sup = shfl_up16_t<T, V>(c);
                     n.pr = (row == 0) ? h : sup;
-                    const float sh = dpp_from_left(c.v[3]);
-                    n.pc = shift_right<float, 4>(c, (lx == 0) ? E[t] : sh);
+                    const T sh = dpp_from_left(c.v[V - 1]);
+                    n.pc = shift_right<T, V>(c, (lx == 0) ? E[t] : sh);
                     if (tg > 0) { n.h_pt = (g.ta != 0); n.pt = cold; }
                 }
             }
-            F4 o[8];
-            F4 mft = mf;          // per-voxel weight on the time channels (tv_geom::time_weight_vol): one more streamed read
-            if (g.wv != nullptr && g.ta && in_chunk && ok) mft = mf * ldu(static_cast<const float*>(g.wv) + (long long)z * g.s_z + foff(t), voff);
-            d_slots<S, float, 4>(g, w, n, mft, o);       // z slots come out as zero (h_nz = h_pz = false): filled below
+            VT o[8];
+            VT mft = mf;          // per-voxel weight on the time channels (tv_geom::time_weight_vol): one more streamed read
+            if (g.wv != nullptr && g.ta && in_chunk && ok) mft = mf * ldu_t<T, V>(static_cast<const T*>(g.wv) + (long long)z * g.s_z + foff(t), voff);
+            d_slots<S, T, V>(g, w, n, mft, o);       // z slots come out as zero (h_nz = h_pz = false): filled below
             // ---- next plane: requested before this frame's stores -----------------------------------------------------
             cold = c;
             if (CEN) P2[t] = P[t];
@@ -192,37 +226,37 @@ __global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8
             if (!ok) continue;
             const long long fo = foff(t);
             if (S == HYBRID) {
-                const F4 dzs = Consts<float>::inv_sqrt2() * dzv;
+                const VT dzs = Consts<T>::inv_sqrt2() * dzv;
                 if (in_chunk) {
-                    stu(dz_cur + fo, voff, o[0]);
-                    stu(dz_cur + 1 * g.s_z + fo, voff, o[1]);
-                    stu(dz_cur + 2 * g.s_z + fo, voff, o[2]);
-                    stu(dz_cur + 3 * g.s_z + fo, voff, o[3]);
-                    if (g.za) stu(dz_cur + (long long)(g.ch_z + 1) * g.s_z + fo, voff, dzs);
+                    stu_t<T, V>(dz_cur + fo, voff, o[0]);
+                    stu_t<T, V>(dz_cur + 1 * g.s_z + fo, voff, o[1]);
+                    stu_t<T, V>(dz_cur + 2 * g.s_z + fo, voff, o[2]);
+                    stu_t<T, V>(dz_cur + 3 * g.s_z + fo, voff, o[3]);
+                    if (g.za) stu_t<T, V>(dz_cur + (long long)(g.ch_z + 1) * g.s_z + fo, voff, dzs);
                     if (g.ta) {
-                        stu(dz_cur + (long long)g.ch_t * g.s_z + fo, voff, o[6]);
-                        stu(dz_cur + (long long)(g.ch_t + 1) * g.s_z + fo, voff, o[7]);
+                        stu_t<T, V>(dz_cur + (long long)g.ch_t * g.s_z + fo, voff, o[6]);
+                        stu_t<T, V>(dz_cur + (long long)(g.ch_t + 1) * g.s_z + fo, voff, o[7]);
                     }
                 }
-                if (g.za && z > zs) stu(dz_prv + (long long)g.ch_z * g.s_z + fo, voff, dzs);
+                if (g.za && z > zs) stu_t<T, V>(dz_prv + (long long)g.ch_z * g.s_z + fo, voff, dzs);
             } else {
                 if (in_chunk) {
-                    stu(dz_cur + fo, voff, o[0]);
-                    stu(dz_cur + 1 * g.s_z + fo, voff, o[1]);
-                    if (g.ta) stu(dz_cur + (long long)g.ch_t * g.s_z + fo, voff, o[3]);
-                    if (S == DOWNWIND && g.za) stu(dz_cur + (long long)g.ch_z * g.s_z + fo, voff, dzv);
+                    stu_t<T, V>(dz_cur + fo, voff, o[0]);
+                    stu_t<T, V>(dz_cur + 1 * g.s_z + fo, voff, o[1]);
+                    if (g.ta) stu_t<T, V>(dz_cur + (long long)g.ch_t * g.s_z + fo, voff, o[3]);
+                    if (S == DOWNWIND && g.za) stu_t<T, V>(dz_cur + (long long)g.ch_z * g.s_z + fo, voff, dzv);
                     if (CEN && z_fwd && g.za) {
                         // two-plane volume: forward stencil, D(0) = 1/2 wz (x(1) - x(0)), D(1) = 0
-                        if (gz == g.nzg - 1) stu(dz_cur + (long long)g.ch_z * g.s_z + fo, voff, zero);
+                        if (gz == g.nzg - 1) stu_t<T, V>(dz_cur + (long long)g.ch_z * g.s_z + fo, voff, zero);
                     }
                 }
                 if (g.za && z > zs) {
-                    if (S == UPWIND) stu(dz_prv + (long long)g.ch_z * g.s_z + fo, voff, dzv);
+                    if (S == UPWIND) stu_t<T, V>(dz_prv + (long long)g.ch_z * g.s_z + fo, voff, dzv);
                     if (CEN) {
                         // z channel of plane z-1: central 1/2 wz (x(z) - x(z-2)) on interior planes, 0 on the first / last one
-                        F4 cz = 0.5f * dzv;
+                        VT cz = T(0.5) * dzv;
                         if (!z_fwd && !(plane_here && gz >= 2)) cz = zero;
-                        stu(dz_prv + (long long)g.ch_z * g.s_z + fo, voff, cz);
+                        stu_t<T, V>(dz_prv + (long long)g.ch_z * g.s_z + fo, voff, cz);
                     }
                 }
             }

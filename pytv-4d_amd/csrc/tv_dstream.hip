@@ -6,13 +6,14 @@
 namespace tvm {
 
 bool D_stream_ok(const tv_geom* g, const DG& d, bool vec) {
-    if (g->dtype != TV_F32 || !vec || d.nx < 64) return false;        // a weight volume is one more read stream (round 3)
-    if ((long long)d.ny * d.nx > (1ll << 30)) return false;           // 32-bit per-lane byte offsets inside a frame
+    if (!vec || d.nx < 64) return false;        // fp32 and (round 3) fp64; a weight volume is one more read stream (round 3)
+    if ((long long)d.ny * d.nx * (g->dtype == TV_F32 ? 4 : 8) > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
     return true;
 }
 
-int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, float* dout) {
-    const long long tx = (d.nx / 4 + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
+int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, void* dout) {
+    const int V = (g->dtype == TV_F32) ? 4 : 2;
+    const long long tx = (d.nx / V + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
     // planes per z-chunk: a chunk re-reads one plane (its trailing step), so chunks are long; >= ~4096 blocks in flight
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
@@ -26,10 +27,15 @@ int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
     const long long nwin = (d.m > DS_TWN) ? (d.m + DS_TWN - 1) / DS_TWN : 1;
     const long long nb = tx * ty * nch * nwin, per_xcd = (nb + 7) / 8;
     const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, ST_NWX * ST_NWY, 1);
-    const WT<float> w = make_w<float>(g);
 #define TV_DS_LAUNCH(SC, MM, TW)                                                                                              \
-    hipLaunchKernelGGL((k_D_stream<SC, MM, TW>), grid, block, 0, st, d, w, (const float*)x, (const float*)xp, (const float*)xn, \
-                       dout, zc, (int)nch)
+    do {                                                                                                                      \
+        if (g->dtype == TV_F32)                                                                                               \
+            hipLaunchKernelGGL((k_D_stream<SC, MM, TW, float>), grid, block, 0, st, d, make_w<float>(g), (const float*)x, (const float*)xp, \
+                               (const float*)xn, (float*)dout, zc, (int)nch);                                                 \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_D_stream<SC, MM, TW, double>), grid, block, 0, st, d, make_w<double>(g), (const double*)x, (const double*)xp, \
+                               (const double*)xn, (double*)dout, zc, (int)nch);                                               \
+    } while (0)
 #define TV_DS_CASE(SC)                                              \
     case SC:                                                        \
         switch (d.m > DS_TWN ? 0 : d.m) {                           \

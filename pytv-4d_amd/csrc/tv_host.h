@@ -260,11 +260,11 @@ int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, cons
               float* z, float* u, float thresh, double* partials, int tform);
 // streaming normal operator (tv_nstream.h): radius-1 schemes, fp32; two dot products
 bool N_stream_ok(const tv_geom* g, const DG& d, bool vec);
-int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, float* out, float* out2,
-             float rho, hipStream_t st, long long* nb, double* part0, double* part1);
+int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, void* out, void* out2,
+             double rho, hipStream_t st, long long* nb, double* part0, double* part1);
 // streaming forward kernel (tv_dstream.h): d = D x without LDS tile or barrier, every load one plane ahead of its use
 bool D_stream_ok(const tv_geom* g, const DG& d, bool vec);
-int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, float* dout);
+int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, void* dout);
 int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb, float* out);
 int DT_axpy(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
             float* out, const float* base, float alpha, const float* base2 = nullptr, float beta = 0.f);

@@ -769,10 +769,10 @@ int tv_D(const tv_geom* g, const void* x, const void* x_prev, const void* x_next
     // (64x8x1024x1024, ms hybrid / upwind / downwind / central: k_D 4.90 / 2.39 / 2.37 / 3.04, k_D_march 5.76 / 2.71 /
     // 2.47 / 2.99, k_D_stream 4.31 / 2.16 / 2.17 / 2.31); on small planes the z / t neighbours of the one-site kernel
     // stay in L2 and it wins (256x1x512x512: 0.39 / 0.19 ms against 0.40 / 0.23) -- profiles/r2_d_kernels.txt
-    const bool big_plane = (long long)d.s_z * 4 >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;
+    const bool big_plane = (long long)d.s_z * (g->dtype == TV_F32 ? 4 : 8) >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;
     const int kern = env_int("TV_D_KERNEL", env_int("TV_MARCH_D", 0) ? 1 : (big_plane ? 2 : 0));
     if (kern == 2 && tvm::D_stream_ok(g, d, vec) && !env_int("TV_NO_MARCH", 0))
-        return tvm::D_stream(g, d, x, x_prev, x_next, st, (float*)dout);
+        return tvm::D_stream(g, d, x, x_prev, x_next, st, dout);
     if (kern == 1 && march_ok(g, d, vec)) {
         long long nb;
         return tvm::D_store(g, d, x, x_prev, x_next, st, &nb, (float*)dout);
@@ -958,7 +958,7 @@ int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void
         long long nb;
         double* w0 = (double*)ws;
         double* w1 = w0 + nmax + kStage + 16;
-        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, nullptr, (float*)out, nullptr, (float)rho, st, &nb, w0, w1)) return rc;
+        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, nullptr, out, nullptr, rho, st, &nb, w0, w1)) return rc;
         return reduce_partials(w0, nb, nmax, dot, st);
     }
     if (nkern >= 1 && g->scheme != TV_CENTRAL && d.m <= 8 && march_ok(g, d, vec) && !env_int("TV_NO_MARCH_NORMAL", 0)) {
@@ -1189,7 +1189,7 @@ int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const voi
         long long nb;
         double* w0 = (double*)ws;
         double* w1 = w0 + nmax + kStage + 16;
-        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, b, (float*)out, (float*)out2, (float)rho, st, &nb, w0, w1)) return rc;
+        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, b, out, out2, rho, st, &nb, w0, w1)) return rc;
         if (int rc = reduce_partials(w0, nb, nmax, dots, st)) return rc;
         return reduce_partials(w1, nb, nmax, dots + 1, st);
     }

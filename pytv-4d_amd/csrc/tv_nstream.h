@@ -17,17 +17,18 @@
 
 namespace tv {
 
-struct NormalArgs {
-    const float* x;
-    const float* xp;       // TWO planes z0-2, z0-1 (or nullptr)
-    const float* xn;       // TWO planes z0+nz, z0+nz+1 (or nullptr)
-    const float* b;        // or nullptr
-    float* out;
-    float* out2;           // or nullptr
-    float rho;
+template <typename T> struct NormalArgsT {
+    const T* x;
+    const T* xp;           // TWO planes z0-2, z0-1 (or nullptr)
+    const T* xn;           // TWO planes z0+nz, z0+nz+1 (or nullptr)
+    const T* b;            // or nullptr
+    T* out;
+    T* out2;               // or nullptr
+    T rho;
     double* part0;         // per-block partials of the first / second dot product
     double* part1;
 };
+using NormalArgs = NormalArgsT<float>;
 
 constexpr int NS_TWN = 8;
 
@@ -40,31 +41,36 @@ constexpr int NS_TWN = 8;
 __device__ __forceinline__ float ns_vmul(float a, float b) { float r; asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float ns_vadd(float a, float b) { float r; asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float ns_vsub(float a, float b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ F4 ns_mul(float m, const F4& a, const F4& b) {
-    F4 r;
+__device__ __forceinline__ double ns_vmul(double a, double b) { double r; asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double ns_vadd(double a, double b) { double r; asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double ns_vsub(double a, double b) { double r; asm("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> ns_mul(T m, const Vec<T, V>& a, const Vec<T, V>& b) {
+    Vec<T, V> r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = ns_vmul(m, ns_vsub(a.v[i], b.v[i]));
+    for (int i = 0; i < V; ++i) r.v[i] = ns_vmul(m, ns_vsub(a.v[i], b.v[i]));
     return r;
 }
-__device__ __forceinline__ F4 ns_add(const F4& a, const F4& b) {
-    F4 r;
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> ns_add(const Vec<T, V>& a, const Vec<T, V>& b) {
+    Vec<T, V> r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = ns_vadd(a.v[i], b.v[i]);
+    for (int i = 0; i < V; ++i) r.v[i] = ns_vadd(a.v[i], b.v[i]);
     return r;
 }
-__device__ __forceinline__ F4 ns_sub(const F4& a, const F4& b) {
-    F4 r;
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> ns_sub(const Vec<T, V>& a, const Vec<T, V>& b) {
+    Vec<T, V> r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = ns_vsub(a.v[i], b.v[i]);
+    for (int i = 0; i < V; ++i) r.v[i] = ns_vsub(a.v[i], b.v[i]);
     return r;
 }
 
-template <int M, bool TWIN>
-__global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
+template <int M, bool TWIN, typename T = float>
+__global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
+    constexpr int V = 16 / (int)sizeof(T);          // columns per 16-byte lane: 4 floats / 2 doubles (round 3)
+    using VT = Vec<T, V>;
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
-    const int nxv = g.nx / 4;
+    const int nxv = g.nx / V;
     const int tiles_x = (nxv + ST_BCV - 1) / ST_BCV, tiles_y = (g.ny + ST_BR - 1) / ST_BR;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + NS_TWN - 1) / NS_TWN : 1;
@@ -76,28 +82,28 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG
         const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
         const int t0 = TWIN ? win * NS_TWN : 0;
         const int bx = tile % tiles_x, by = tile / tiles_x;
-        const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * 4, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
+        const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * V, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
         const bool ok = (col0 < g.nx) && (y < g.ny);
-        const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * 4) : 0u;
-        const unsigned row_bytes = (unsigned)g.nx * 4u;
+        const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * (long long)sizeof(T)) : 0u;
+        const unsigned row_bytes = (unsigned)g.nx * (unsigned)sizeof(T);
         const int zs = chunk * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
-        const F4 zero = vsplat<float, 4>(0.f);
-        F4 mf2 = vsplat<float, 4>(1.f);
+        const VT zero = vsplat<T, V>(T(0));
+        VT mf2 = vsplat<T, V>(T(1));
         if (g.ta) {
-            const F4 mf = mask_factor<float, 4>(g, w.sf, ok ? y : 0, ok ? col0 : 0);
+            const VT mf = mask_factor<T, V>(g, w.sf, ok ? y : 0, ok ? col0 : 0);
             mf2 = (w.wt * w.wt) * (mf * mf);
         }
-        const float wz2 = g.za ? w.wz * w.wz : 0.f;
+        const T wz2 = g.za ? w.wz * w.wz : T(0);
         // existence of the in-plane neighbours as multipliers (no branches around vectors in the frame loop)
-        const float m_pr = (ok && y > 0) ? 1.f : 0.f, m_nr = (ok && y + 1 < g.ny) ? 1.f : 0.f;
-        const float m_c0 = (ok && col0 > 0) ? 1.f : 0.f, m_c3 = (ok && col0 + 4 < g.nx) ? 1.f : 0.f;
+        const T m_pr = (ok && y > 0) ? T(1) : T(0), m_nr = (ok && y + 1 < g.ny) ? T(1) : T(0);
+        const T m_c0 = (ok && col0 > 0) ? T(1) : T(0), m_c3 = (ok && col0 + V < g.nx) ? T(1) : T(0);
         const bool want_up = (row == 0) && ok && (y > 0), want_dn = (row == 3) && ok && (y + 1 < g.ny);
         const unsigned hoff = want_up ? voff - row_bytes : voff + row_bytes;
         // a tile row needs BOTH halo rows when the wave tile is a single row high at the frame border: rows 0 and 3 differ,
         // so one predicated load per lane is enough (row 0 reads y-1, row 3 reads y+1)
-        const bool want_le = (lx == 0) && ok && (col0 > 0), want_re = (lx == 15) && ok && (col0 + 4 < g.nx);
-        const unsigned eoff = want_le ? voff - 4u : voff + 16u;
+        const bool want_le = (lx == 0) && ok && (col0 > 0), want_re = (lx == 15) && ok && (col0 + V < g.nx);
+        const unsigned eoff = want_le ? voff - (unsigned)sizeof(T) : voff + 16u;
         auto fvalid = [&](int t) { return !TWIN || (t0 + t < Mg); };
         auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };
         // State: plane z (C), plane z-1 (P), the result of plane z-1 still waiting for its forward z term (R), the halo rows /
@@ -106,95 +112,97 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG
         // the step.  That lets the centre vectors, halo rows and border elements of plane z+1 all be requested in the same
         // frame of step z -- the moment the owners of those lines request them (round 2: requested one step apart they cost
         // a second trip to memory, 17 GB read for an 8.6 GB image).
-        F4 C[M], P[M], R[M], H[M];
-        float E[M];
-        auto plane = [&](int zl) { return g.za ? zplane<float>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
-        auto load_c = [&](const float* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu(pl + foff(t), voff) : zero; };
+        VT C[M], P[M], R[M], H[M];
+        T E[M];
+        auto plane = [&](int zl) { return g.za ? zplane<T>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
+        auto load_c = [&](const T* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu_t<T, V>(pl + foff(t), voff) : zero; };
         {
-            const float* pp = g.za ? plane(zs - 1) : nullptr;
-            const float* pc = plane(zs);
+            const T* pp = g.za ? plane(zs - 1) : nullptr;
+            const T* pc = plane(zs);
 #pragma unroll
             for (int t = 0; t < M; ++t) {
                 P[t] = load_c(pp, t);
                 C[t] = load_c(pc, t);
                 R[t] = zero;
-                H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu(pc + foff(t), hoff) : zero;
-                E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu1(pc + foff(t), eoff) : 0.f;
+                H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pc + foff(t), hoff) : zero;
+                E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu1_t<T>(pc + foff(t), eoff) : T(0);
             }
         }
         for (int z = zs; z <= ze; ++z) {              // step ze only finishes plane ze - 1
             st_sync_plane();
             const bool in_chunk = (z < ze), next_in = (z + 1 < ze);
             const int gz = g.z0 + z;
-            const float mz = (g.za && gz > 0 && gz < g.nzg) ? wz2 : 0.f;
-            const float* pc = in_chunk ? plane(z) : nullptr;
+            const T mz = (g.za && gz > 0 && gz < g.nzg) ? wz2 : T(0);
+            const T* pc = in_chunk ? plane(z) : nullptr;
             // plane requested now (consumed at step z + 1); the step behind the chunk needs the centre vectors only
-            const float* pn = (next_in || (g.za && z + 1 == ze)) ? plane(z + 1) : nullptr;
-            F4 cold = zero;
-            if (TWIN && g.ta && t0 > 0 && in_chunk) cold = ok ? ldu(pc + foff(-1), voff) : zero;
+            const T* pn = (next_in || (g.za && z + 1 == ze)) ? plane(z + 1) : nullptr;
+            VT cold = zero;
+            if (TWIN && g.ta && t0 > 0 && in_chunk) cold = ok ? ldu_t<T, V>(pc + foff(-1), voff) : zero;
 #pragma unroll
             for (int t = 0; t < M; ++t) {
                 if (TWIN && !fvalid(t)) break;
                 st_sync_frame();
                 const int tg = t0 + t;
-                const F4 c = C[t], h = H[t], xm = P[t];
-                const F4 dz = ns_mul(mz, c, xm);
-                const F4 rfin = ns_sub(R[t], dz);            // plane z-1 is complete
+                const VT c = C[t], h = H[t], xm = P[t];
+                const VT dz = ns_mul<T, V>(mz, c, xm);
+                const VT rfin = ns_sub<T, V>(R[t], dz);            // plane z-1 is complete
                 if (in_chunk) {
                     // ---- - Laplacian-like sum: (c - prev) - (next - c) per axis, missing neighbours drop their term ------
-                    const F4 sdn = shfl_down16(c), sup = shfl_up16(c);
-                    const F4 nr = (row == 3) ? h : sdn, pr = (row == 0) ? h : sup;
-                    F4 r = m_pr * (c - pr) - m_nr * (nr - c);
+                    const VT sdn = shfl_down16_t<T, V>(c), sup = shfl_up16_t<T, V>(c);
+                    const VT nr = (row == 3) ? h : sdn, pr = (row == 0) ? h : sup;
+                    VT r = m_pr * (c - pr) - m_nr * (nr - c);
                     {
                         // the cross-lane moves are executed by EVERY lane (a DPP read from a lane that a branch has switched
                         // off returns 0), the select comes afterwards
-                        const float from_l = dpp_from_left(c.v[3]), from_r = dpp_from_right(c.v[0]);
-                        const float left = (lx == 0) ? E[t] : from_l;
-                        const float right = (lx == 15) ? E[t] : from_r;
-                        const float e0 = c.v[1] - c.v[0], e1 = c.v[2] - c.v[1], e2 = c.v[3] - c.v[2];
-                        // interior elements of the vector always have both column neighbours inside the frame (nx % 4 == 0)
-                        r.v[0] += m_c0 * (c.v[0] - left) - e0;
-                        r.v[1] += e0 - e1;
-                        r.v[2] += e1 - e2;
-                        r.v[3] += e2 - m_c3 * (right - c.v[3]);
+                        const T from_l = dpp_from_left(c.v[V - 1]), from_r = dpp_from_right(c.v[0]);
+                        const T left = (lx == 0) ? E[t] : from_l;
+                        const T right = (lx == 15) ? E[t] : from_r;
+                        // interior elements of the vector always have both column neighbours inside the frame (nx % V == 0)
+                        T e[V];         // e[i] = c[i] - c[i-1] (e[0]: against the left neighbour), one more for the right neighbour
+#pragma unroll
+                        for (int i = 1; i < V; ++i) e[i] = c.v[i] - c.v[i - 1];
+                        r.v[0] += m_c0 * (c.v[0] - left) - e[1];
+#pragma unroll
+                        for (int i = 1; i + 1 < V; ++i) r.v[i] += e[i] - e[i + 1];
+                        r.v[V - 1] += e[V - 1] - m_c3 * (right - c.v[V - 1]);
                     }
                     if (g.ta) {
-                        F4 tt = zero;
+                        VT tt = zero;
                         if (tg > 0) tt = tt + (c - cold);
                         if (t + 1 < M) { if (tg + 1 < Mg) tt = tt - (C[(t + 1 < M) ? t + 1 : t] - c); }
-                        else if (TWIN && tg + 1 < Mg) tt = tt - ((ok ? ldu(pc + foff(t + 1), voff) : zero) - c);
+                        else if (TWIN && tg + 1 < Mg) tt = tt - ((ok ? ldu_t<T, V>(pc + foff(t + 1), voff) : zero) - c);
                         r = r + mf2 * tt;
                     }
-                    R[t] = ns_add(r, dz);
+                    R[t] = ns_add<T, V>(r, dz);
                 }
                 // ---- rotate the planes, request the next one (before the stores of this frame) ---------------------------
                 cold = c;
                 P[t] = c;
                 C[t] = load_c(pn, t);
-                H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu(pn + foff(t), hoff) : zero;
-                E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu1(pn + foff(t), eoff) : 0.f;
+                H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pn + foff(t), hoff) : zero;
+                E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu1_t<T>(pn + foff(t), eoff) : T(0);
                 // ---- epilogue of plane z-1 --------------------------------------------------------------------------------
                 if (!ok || z == zs) continue;
                 const long long fo = (long long)(z - 1) * g.s_z + foff(t);
-                F4 o;
+                VT o;
                 if (a.b == nullptr) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < V; ++i) {
                         o.v[i] = xm.v[i] + a.rho * rfin.v[i];
                         acc0 += (double)xm.v[i] * (double)o.v[i];
                         acc1 += (double)xm.v[i] * (double)xm.v[i];
                     }
                 } else {
-                    const F4 bv = ldu(a.b + fo, voff);
+                    const VT bv = ldu_t<T, V>(a.b + fo, voff);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < V; ++i) {
                         o.v[i] = bv.v[i] - (xm.v[i] + a.rho * rfin.v[i]);
                         acc0 += (double)o.v[i] * (double)o.v[i];
                         acc1 += (double)xm.v[i] * (double)xm.v[i];
                     }
-                    if (a.out2 != nullptr) stu(a.out2 + fo, voff, o);
+                    if (a.out2 != nullptr) stu_t<T, V>(a.out2 + fo, voff, o);
                 }
-                stu(a.out + fo, voff, o);
+                stu_t<T, V>(a.out + fo, voff, o);
             }
         }
     }

@@ -9,17 +9,20 @@
 namespace tvm {
 
 bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
-    if (g->dtype != TV_F32 || !vec || d.nx < 64 || d.wv != nullptr) return false;
+    if (!vec || d.nx < 64 || d.wv != nullptr) return false;
+    if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL) return false;                          // fp64 (round 3): the radius-1 kernel only
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return false;   // two-point axes: forward stencil
-    if ((long long)d.ny * d.nx > (1ll << 30)) return false;           // 32-bit per-lane byte offsets inside a frame
+    const long long eb = (g->dtype == TV_F32) ? 4 : 8;
+    if ((long long)d.ny * d.nx * eb > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_MARCH", 0) || env_int("TV_NO_MARCH_NORMAL", 0)) return false;
     // small planes: the z / t neighbours of the one-site kernel stay in L2 (same threshold as the other streaming kernels)
-    return (long long)d.s_z * 4 >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;
+    return (long long)d.s_z * eb >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;
 }
 
-int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, float* out, float* out2,
-             float rho, hipStream_t st, long long* nblocks, double* part0, double* part1) {
-    const long long tx = (d.nx / 4 + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
+int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, void* out, void* out2,
+             double rho, hipStream_t st, long long* nblocks, double* part0, double* part1) {
+    const int V = (g->dtype == TV_F32) ? 4 : 2;
+    const long long tx = (d.nx / V + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
         const long long want = (4096 + tx * ty - 1) / (tx * ty);
@@ -35,11 +38,13 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
     *nblocks = 8 * per_xcd;
     if (*nblocks > max_partials(d)) return fail(TV_E_ARG, "internal: normal-operator partials exceed the workspace");
     const WT<float> w = make_w<float>(g);
-    NormalArgs a{(const float*)x, (const float*)xp, (const float*)xn, (const float*)b, out, out2, rho, part0, part1};
+    NormalArgs a{(const float*)x, (const float*)xp, (const float*)xn, (const float*)b, (float*)out, (float*)out2, (float)rho, part0, part1};
+    NormalArgsT<double> ad{(const double*)x, (const double*)xp, (const double*)xn, (const double*)b, (double*)out, (double*)out2, rho, part0, part1};
 #define TV_NS_LAUNCH(MM, TW)                                                                                            \
     do {                                                                                                               \
-        if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW>), grid, block, 0, st, d, w, a, zc, (int)nch); \
-        else hipLaunchKernelGGL((k_normal_stream<MM, TW>), grid, block, 0, st, d, w, a, zc, (int)nch);                  \
+        if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
+        else if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW>), grid, block, 0, st, d, w, a, zc, (int)nch); \
+        else hipLaunchKernelGGL((k_normal_stream<MM, TW, float>), grid, block, 0, st, d, w, a, zc, (int)nch);           \
     } while (0)
     switch (d.m > NS_TWN ? 0 : d.m) {
         case 0: TV_NS_LAUNCH(NS_TWN, true); break;

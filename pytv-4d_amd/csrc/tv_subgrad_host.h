@@ -59,7 +59,10 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
                       double* fidout, void* ws, hipStream_t st, const SgHostArgs& so) {
     constexpr bool F64 = sizeof(T) == 8;
     constexpr int R = F64 ? 2 : 4, NW = 4;
-    constexpr bool XLD = F64;
+#ifndef TV_SG2_XLD32
+#define TV_SG2_XLD32 0
+#endif
+    constexpr bool XLD = F64 || TV_SG2_XLD32;
     const long long nmax = max_partials(d);
     const bool halo = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL);
     const int UR = R * NW - 2, UC = halo ? 60 : 62;

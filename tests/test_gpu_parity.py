@@ -910,3 +910,66 @@ def test_partials_workspace_covers_narrow_frames_with_short_chunks(pytv, shape, 
     if not a.fused:
         pytest.skip("one-sweep path not available for this geometry")
     np.testing.assert_allclose(a.run(3), b.run(3), rtol=2e-6)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape", [(5, 3, 20, 128), (4, 9, 12, 66), (3, 1, 40, 256)])
+def test_fp64_streaming_D_equals_the_one_site_kernel_and_the_oracle(pytv, scheme, shape):
+    """round 3: tv_D has a streaming instantiation for double (k_D_stream<..., double>, 2 columns per 16-byte lane).  Same
+    d_slots arithmetic as the one-site kernel: bit for bit; and the oracle to 1e-11."""
+    import torch
+    from pytv import _native as nv
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal(shape) * 10
+    kw = dict(reg_z_over_reg=1.7, reg_time=0.6)
+    if scheme == "central" and (shape[0] == 2 or shape[1] == 2):
+        pytest.skip("two-point axis")
+    ops = pytv.tv_operators_GPU
+    xt = torch.as_tensor(x).cuda()
+    nv.set_option("TV_D_KERNEL", 2)
+    try:
+        d_fast = getattr(ops, "D_" + scheme)(xt, **kw)
+        nv.set_option("TV_D_KERNEL", 0)
+        d_slow = getattr(ops, "D_" + scheme)(xt, **kw)
+    finally:
+        nv.set_option("TV_D_KERNEL", None)
+    assert d_fast.dtype == torch.float64 and torch.equal(d_fast, d_slow)
+    np.testing.assert_allclose(d_fast.cpu().numpy(), orc.D(x, scheme, **kw), rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("scheme", ["upwind", "downwind", "hybrid"])
+@pytest.mark.parametrize("shape", [(6, 3, 20, 128), (5, 9, 12, 66), (4, 1, 40, 256)])
+def test_fp64_streaming_normal_operator_equals_the_one_site_kernel_and_the_oracle(pytv, scheme, shape):
+    """round 3: tv_normal_op / tv_normal_op2 stream in double as well (k_normal_stream<..., double>, radius-1 schemes)."""
+    import torch
+    from pytv import _native as nv
+    rng = np.random.default_rng(73)
+    x = rng.standard_normal(shape) * 10
+    b = rng.standard_normal(shape)
+    kw = dict(reg_z_over_reg=1.7, reg_time=0.6)
+    xt, bt = torch.as_tensor(x).cuda(), torch.as_tensor(b).cuda()
+    g = nv.Geometry(shape, scheme, torch.float64, "cuda", **kw)
+    lib, st, ws = nv.lib(), nv.current_stream(xt.device), g.workspace()
+    res = {}
+    for kern in (2, 0):
+        nv.set_option("TV_NORMAL_KERNEL", kern)
+        try:
+            out, out2 = torch.empty_like(xt), torch.empty_like(xt)
+            dots = torch.zeros(2, dtype=torch.float64, device="cuda")
+            nv.check(lib.tv_normal_op(g.ref, nv.ptr(xt), None, None, 0.37, nv.ptr(out), dots[0:1].data_ptr(), nv.ptr(ws), st))
+            r = torch.empty_like(xt)
+            d2 = torch.zeros(2, dtype=torch.float64, device="cuda")
+            nv.check(lib.tv_normal_op2(g.ref, nv.ptr(xt), None, None, 0.37, nv.ptr(bt), nv.ptr(r), nv.ptr(out2), d2.data_ptr(), nv.ptr(ws), st))
+            res[kern] = (out.cpu().numpy(), float(dots[0]), r.cpu().numpy(), out2.cpu().numpy(), d2.cpu().numpy())
+        finally:
+            nv.set_option("TV_NORMAL_KERNEL", None)
+    want = x + 0.37 * orc.D_T(orc.D(x, scheme, **kw), scheme, **kw)
+    for kern in (2, 0):
+        out, dot, r, out2, d2 = res[kern]
+        np.testing.assert_allclose(out, want, rtol=1e-11, atol=1e-10)
+        assert abs(dot - float(np.sum(x * want))) <= 1e-11 * abs(float(np.sum(x * want)))
+        np.testing.assert_allclose(r, b - want, rtol=1e-11, atol=1e-10)
+        np.testing.assert_array_equal(r, out2)
+        assert abs(d2[0] - float(np.sum((b - want) ** 2))) <= 1e-11 * float(np.sum((b - want) ** 2))
+        assert abs(d2[1] - float(np.sum(x * x))) <= 1e-12 * float(np.sum(x * x))
+    np.testing.assert_allclose(res[2][0], res[0][0], rtol=1e-13, atol=1e-12)

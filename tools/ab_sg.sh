@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT
-for r in 1 2; do for v in base d4; do
+for r in 1 2; do for v in base ${VARIANT:-xld}; do
   if [ $v != base ]; then export PYTV4D_LIB=$R/pytv-4d_amd/pytv/libpytv4d_hip_$v.so; else unset PYTV4D_LIB; fi
-  echo "== $v"; python3 $R/tools/sg_bench.py 256x8x1024x1024 hybrid upwind central 2>&1 | grep one-pass
+  echo "== $v"; python3 $R/tools/sg_bench.py 256x8x1024x1024 ${SCHEMES:-hybrid upwind central} 2>&1 | grep one-pass
 done; done
