@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto (1 GPU only): measure roofline.traffic live with two rocprofv3 --pmc child passes after the timed run; "
                          "off: copy the committed numbers of profiles/traffic.json and label them STATIC")
+    ap.add_argument("--prewarm-gb", type=float, default=float(os.environ.get("TV_BENCH_PREWARM_GB", "0")),
+                    help="touch and release this many GB of device memory before the volume is allocated (placement experiment)")
     ap.add_argument("--phases", action="store_true", help="per-phase HIP-event times of the schedule in the JSON line (always on at N > 1)")
     args = ap.parse_args()
     # must be in the environment BEFORE the HIP runtime starts (the pool's driver only supports dmabuf IPC; RCCL's
@@ -223,6 +225,12 @@ def main():
     device = torch.device("cuda", local_rank)
     wl = WORKLOADS[args.workload]
     shape = wl["shape"]
+    if args.prewarm_gb > 0:
+        junk = torch.empty(int(args.prewarm_gb * (1 << 30)), dtype=torch.uint8, device=device)
+        junk.fill_(1)
+        torch.cuda.synchronize()
+        del junk
+        torch.cuda.empty_cache()
     native = None
     comm_name = "none (one process, no process group)"
     try:
