@@ -99,6 +99,12 @@ constexpr int SG2_TWN = 8, SG2_TWU = SG2_TWN - 2;      // time windows for M > 8
 #ifndef TV_SG2_D
 #define TV_SG2_D 2
 #endif
+#ifndef TV_SG2_COPYONLY
+#define TV_SG2_COPYONLY 0      // 1: EXPERIMENT -- store x instead of G and drop the arithmetic: what the memory pattern alone costs
+#endif
+#ifndef TV_SG2_WIDE
+#define TV_SG2_WIDE 0          // 1: EXPERIMENT (with COPYONLY) -- the waves of a block side by side: 4 rows x 256 columns, no ring
+#endif
 #ifndef TV_SG2_X0_AHEAD
 #define TV_SG2_X0_AHEAD 1
 #endif
@@ -112,7 +118,11 @@ constexpr int SG2_D = TV_SG2_D;                        // depth of the x(z+1) lo
 // XLD: the rows just above / below a wave's strip come from MEMORY (two more loads per frame, L1 / L2 hits: the neighbouring
 // wave requests the same lines) instead of the LDS hand-off xe -- half the LDS, which is what lets the fp64 instantiation
 // (R = 2 rows of doubles: the same registers as R = 4 floats) keep two blocks per CU.
-template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false>
+// NWX: wave columns per block.  The memory pattern, not the arithmetic, bounds this kernel (a build that stores x instead of G and
+// drops all the mathematics takes the same 1.55 ms at 64x8x1024x1024, profiles/r3_subgrad_col_pattern.txt): 256-byte row
+// segments at a 4 KiB stride are what HBM likes least.  NWX = 2 puts two 64-column wave tiles side by side in ONE block (8 waves,
+// one block per CU: the same two waves per SIMD): their rows are 496 contiguous bytes, requested within a frame of each other.
+template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false, int NWX = 1>
 struct SgCol {
     static constexpr bool CEN = (S == CENTRAL);
     static constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
@@ -130,8 +140,8 @@ struct SgCol {
     struct Shared {
         // [parity][frame][row][lane]; row 2 w = first row of wave w's strip, 2 w + 1 = its last row, row ZR = zeros (what the
         // first / last wave of the block reads instead of a neighbour: no select, no multiplier)
-        T xe[XLD ? 1 : 2][XLD ? 1 : M][XLD ? 1 : ROWS][64];       // x of plane z (parity z & 1); XLD: unused
-        T ye[2][M][ROWS][64];       // row products of step z: [2 w] for the wave above, [2 w + 1] for the wave below
+        T xe[NWX][XLD ? 1 : 2][XLD ? 1 : M][XLD ? 1 : ROWS][64];       // [wave column] x of plane z (parity z & 1); XLD: unused
+        T ye[NWX][2][M][ROWS][64];  // row products of step z: [2 w] for the wave above, [2 w + 1] for the wave below
         double sm[16];
     };
 
@@ -141,27 +151,36 @@ struct SgCol {
     static __device__ __forceinline__ void run(const DG& g, const WT<T>& w, const T* __restrict__ x, const T* __restrict__ xp,
                                                const T* __restrict__ xn, T* __restrict__ G, int zchunk, int chunk, int tile_x, int tile_y,
                                                int win, long long lid, double* __restrict__ partials, const SgArgs2<T>& sa, Shared& sh) {
-        const int lane = (int)threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);     // the wave index is uniform: keep it scalar
+        const int lane = (int)threadIdx.x, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.y);    // the wave index is uniform: keep it scalar
+        const int wv = wid % NW, wx = wid / NW;                 // position in the block: row strip, wave column
+        tile_x = tile_x * NWX + wx;
+        auto& xe = sh.xe[wx];
+        auto& ye = sh.ye[wx];
         const int Mg = TWIN ? g.m : M;
         const int t0 = TWIN ? win * SG2_TWU - 1 : 0;
         auto fvalid = [&](int t) { return !TWIN || (t0 + t >= 0 && t0 + t < Mg); };
         auto fstore = [&](int t) { return !TWIN || (t0 + t >= win * SG2_TWU && t0 + t < win * SG2_TWU + SG2_TWU && t0 + t < Mg); };
         auto foff_t = [&](int t) { return (long long)(t0 + t) * g.s_t; };     // uniform
         const int fbytes = (int)(g.s_t * (long long)sizeof(T));
+#if TV_SG2_WIDE
+        const int cx = (tile_x * NW + wv) * 64 + lane;
+        const int yb = tile_y * R;
+#else
         const int cx = tile_x * UC - RING + lane;
         const int yb = tile_y * UR - 1 + wv * R;               // first row of this wave's strip
+#endif
         const bool in_x = FAST || (cx >= 0 && cx < g.nx);
         // per-lane byte offsets inside a frame: roff = where this thread's sites are (out of range if outside the frame: loads
         // give 0), soff = where it STORES (only sites the tile owns: not the ring, not outside the frame)
         unsigned roff[R], soff[R];
         C mi, mfr, mbr, mfc, mbc, mft, cm;
-        const bool lane_ok = in_x && lane >= RING && lane <= 63 - RING;
+        const bool lane_ok = in_x && (TV_SG2_WIDE || (lane >= RING && lane <= 63 - RING));
 
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int y = yb + i;
             const bool in = in_x && (FAST || (y >= 0 && y < g.ny));
-            const bool own = in && lane_ok && !(wv == 0 && i == 0) && !(wv == NW - 1 && i == R - 1);
+            const bool own = in && lane_ok && (TV_SG2_WIDE || (!(wv == 0 && i == 0) && !(wv == NW - 1 && i == R - 1)));
             const unsigned off = (unsigned)(((long long)y * g.nx + cx) * (long long)sizeof(T));
             roff[i] = in ? off : SG2_OOB;
             soff[i] = own ? off : SG2_OOB;
@@ -204,13 +223,13 @@ struct SgCol {
         if (wv == 0) {
 #pragma unroll
             for (int t = 0; t < M; ++t) {
-                if (!XLD) sh.xe[0][t][ZR][lane] = sh.xe[1][t][ZR][lane] = T(0);
-                sh.ye[0][t][ZR][lane] = sh.ye[1][t][ZR][lane] = T(0);
+                if (!XLD) xe[0][t][ZR][lane] = xe[1][t][ZR][lane] = T(0);
+                ye[0][t][ZR][lane] = ye[1][t][ZR][lane] = T(0);
             }
         }
 #pragma unroll
         for (int t = 0; t < M; ++t)        // the first step reads the "previous step's" products for a store that is dropped: keep them finite
-            sh.ye[0][t][r_own][lane] = sh.ye[0][t][r_own + 1][lane] = sh.ye[1][t][r_own][lane] = sh.ye[1][t][r_own + 1][lane] = T(0);
+            ye[0][t][r_own][lane] = ye[0][t][r_own + 1][lane] = ye[1][t][r_own][lane] = ye[1][t][r_own + 1][lane] = T(0);
         static_assert(NW >= 2, "one halo load per thread serves the first OR the last wave");
         const T m_hu = (wv == 0) ? T(1) : T(0), m_hd = (wv == NW - 1) ? T(1) : T(0);
         double acc = 0.0, acc_fid = 0.0;
@@ -247,8 +266,8 @@ struct SgCol {
 #pragma unroll
                 for (int i = 0; i < R; ++i) Gp[t].v[i] = Gc[t].v[i] = T(0);
                 if (!XLD) {
-                    sh.xe[z_lo & 1][t][r_own][lane] = Cc[t].v[0];
-                    sh.xe[z_lo & 1][t][r_own + 1][lane] = Cc[t].v[R - 1];
+                    xe[z_lo & 1][t][r_own][lane] = Cc[t].v[0];
+                    xe[z_lo & 1][t][r_own + 1][lane] = Cc[t].v[R - 1];
                 }
             }
         }
@@ -304,10 +323,10 @@ struct SgCol {
                 for (int d = 0; d < H; ++d) Nq[d] = Nh[HEADS ? d : 0];
             }
             T xu_n = T(0), xd_n = T(0), yu_n = T(0), yd_n = T(0);
-            if ((DN || CEN) && !XLD) xu_n = sh.xe[par][0][r_up][lane];
-            if ((UP || CEN) && !XLD) xd_n = sh.xe[par][0][r_dn][lane];
-            if (UP || CEN) yu_n = sh.ye[par ^ 1][0][r_up][lane];
-            if (DN || CEN) yd_n = sh.ye[par ^ 1][0][r_dn][lane];
+            if ((DN || CEN) && !XLD) xu_n = xe[par][0][r_up][lane];
+            if ((UP || CEN) && !XLD) xd_n = xe[par][0][r_dn][lane];
+            if (UP || CEN) yu_n = ye[par ^ 1][0][r_up][lane];
+            if (DN || CEN) yd_n = ye[par ^ 1][0][r_dn][lane];
             C pf_t_prev, f_t_prev, c_old_prev;      // time-axis carries: product / forward difference / x of frame t-1
 #pragma unroll
             for (int i = 0; i < R; ++i) pf_t_prev.v[i] = f_t_prev.v[i] = c_old_prev.v[i] = T(0);
@@ -318,8 +337,8 @@ struct SgCol {
                 // ---- row neighbours across the strip's ends -----------------------------------------------------------
                 T xu = xu_n, xd = xd_n;              // read from LDS one frame ahead (two waves per SIMD do not hide an LDS round trip)
                 if (t + 1 < M && !XLD) {
-                    if (DN || CEN) xu_n = sh.xe[par][(t + 1 < M) ? t + 1 : t][r_up][lane];
-                    if (UP || CEN) xd_n = sh.xe[par][(t + 1 < M) ? t + 1 : t][r_dn][lane];
+                    if (DN || CEN) xu_n = xe[par][(t + 1 < M) ? t + 1 : t][r_up][lane];
+                    if (UP || CEN) xd_n = xe[par][(t + 1 < M) ? t + 1 : t][r_dn][lane];
                 }
                 if (XLD) {                           // from memory, requested two frames ahead
                     xu = hu[t & 1];
@@ -343,8 +362,8 @@ struct SgCol {
                 }
                 // publish the strip ends of plane zl+1 for the next step
                 if (!XLD) {
-                    sh.xe[par ^ 1][t][r_own][lane] = nx.v[0];
-                    sh.xe[par ^ 1][t][r_own + 1][lane] = nx.v[R - 1];
+                    xe[par ^ 1][t][r_own][lane] = nx.v[0];
+                    xe[par ^ 1][t][r_own + 1][lane] = nx.v[R - 1];
                 }
                 // ---- raw differences --------------------------------------------------------------------------------------
                 // dr[i] = x(row i+1) - x(row i) for i = -1 .. R-1 (index shifted by one): the forward row differences of the
@@ -445,7 +464,7 @@ struct SgCol {
                 {
                     T mn = ss.v[0];
 #pragma unroll
-                    for (int i = 1; i < R; ++i) mn = mn < ss.v[i] ? mn : ss.v[i];
+                    for (int i = 1; i < R; ++i) mn = (sizeof(T) == 4) ? (T)__builtin_fminf((float)mn, (float)ss.v[i]) : (T)__builtin_fmin((double)mn, (double)ss.v[i]);   // v_min: one instruction, not compare + select
                     // a wave that holds no vanishing gradient (the usual case) skips the selects
                     if (__builtin_expect(__any(!(mn >= thr)), 0)) {
 #pragma unroll
@@ -467,7 +486,7 @@ struct SgCol {
                         sum += rn * cm.v[i];
                         if (MODE == 2) sg2_st(rn_rs, soff[i], (n.v[i] > T(0)) ? s * rn : (T)__builtin_inff());
                     }
-                    acc += (double)(sum * (cnt ? s : T(0)));
+                    if (!TV_SG2_COPYONLY) acc += (double)(sum * (cnt ? s : T(0)));
                     pin1<double>(acc);        // or LLVM sinks the sums of all M frames below the frame loop and keeps their operands alive
                 }
                 // ---- scatter the products -------------------------------------------------------------------------------
@@ -493,6 +512,46 @@ struct SgCol {
                 } else {
 #pragma unroll
                     for (int i = 0; i < R; ++i) gn.v[i] = T(0);
+                    if constexpr (S == HYBRID) {
+                        // hybrid, FLUX form.  The backward channel of a site IS the forward channel of its predecessor, so an
+                        // edge (v, v + e) with difference d hands d n(v) + d n(v + e) = d (n(v) + n(v + e)) to v + e and takes the
+                        // same from v: one product per edge instead of two, and half the accumulations.  Used where both ends
+                        // of the edge are at hand in the same frame step: the rows inside the strip, the columns (1 / |Dx| of the
+                        // right neighbour: one DPP move) and -- FAST variant, where the time factor is the same for both ends --
+                        // the frames (the edge t-1 -> t closes at frame t).  The strip's end rows and the planes stay scatters.
+#pragma unroll
+                        for (int i = 0; i + 1 < R; ++i) {
+                            const T ph = f_r.v[i] * (n.v[i] + n.v[(i + 1 < R) ? i + 1 : i]);
+                            gc.v[i] -= ph;
+                            gc.v[(i + 1 < R) ? i + 1 : i] += ph;
+                        }
+                        to_up = b_r.v[0] * n.v[0];
+                        gc.v[0] += to_up;
+                        to_dn = f_r.v[R - 1] * n.v[R - 1];
+                        gc.v[R - 1] -= to_dn;
+#pragma unroll
+                        for (int i = 0; i < R; ++i) {
+                            const T pc_ = f_c.v[i] * (n.v[i] + from_right(n.v[i]));
+                            gc.v[i] += from_left(pc_) - pc_;
+                            const T pz_f = f_z.v[i] * n.v[i], pz_b = b_z.v[i] * n.v[i];
+                            gc.v[i] += pz_b - pz_f;
+                            gn.v[i] = pz_f;
+                            Gp[t].v[i] -= pz_b;
+                            if (FAST) {
+                                T pt_;
+                                if (TWIN && t == 0) pt_ = b_t.v[i] * n.v[i];          // the edge into the window: its other end is not ours
+                                else pt_ = b_t.v[i] * (pf_t_prev.v[i] + n.v[i]);      // pf_t_prev carries 1 / |Dx| of frame t-1 here
+                                gc.v[i] += pt_;
+                                if (t > 0) { Gp[(t > 0) ? t - 1 : 0].v[i] -= pt_; pin1<T>(Gp[(t > 0) ? t - 1 : 0].v[i]); }
+                                pf_t_prev.v[i] = n.v[i];
+                            } else {
+                                const T p_t = f_t.v[i] * n.v[i], q_t = b_t.v[i] * n.v[i];
+                                gc.v[i] += (pf_t_prev.v[i] - p_t) + q_t;
+                                pf_t_prev.v[i] = p_t;
+                                if (t > 0) { Gp[(t > 0) ? t - 1 : 0].v[i] -= q_t; pin1<T>(Gp[(t > 0) ? t - 1 : 0].v[i]); }
+                            }
+                        }
+                    } else
                     if (UP) {       // forward channels: - to the site itself, + to the next site
 #pragma unroll
                         for (int i = 0; i < R; ++i) {
@@ -509,7 +568,7 @@ struct SgCol {
                             pf_t_prev.v[i] = p_t;
                         }
                     }
-                    if (DN) {       // backward channels: + to the site itself, - to the previous site
+                    if (DN && S != HYBRID) {       // backward channels: + to the site itself, - to the previous site
 #pragma unroll
                         for (int i = 0; i < R; ++i) {
                             const T p_r = b_r.v[i] * n.v[i];
@@ -526,8 +585,8 @@ struct SgCol {
                         }
                     }
                 }
-                if (DN || CEN) sh.ye[par][t][r_own][lane] = to_up;
-                if (UP || CEN) sh.ye[par][t][r_own + 1][lane] = to_dn;
+                if (DN || CEN) ye[par][t][r_own][lane] = to_up;
+                if (UP || CEN) ye[par][t][r_own + 1][lane] = to_dn;
 #pragma unroll
                 for (int i = 0; i < R; ++i) pin1<T>(gc.v[i]);
                 if (MODE == 1) {
@@ -546,13 +605,13 @@ struct SgCol {
                     if (UP || CEN) Gp[t].v[0] += yu_n;
                     if (DN || CEN) Gp[t].v[R - 1] -= yd_n;
                     if (t + 1 < M) {                 // next frame's, a frame ahead
-                        if (UP || CEN) yu_n = sh.ye[par ^ 1][(t + 1 < M) ? t + 1 : t][r_up][lane];
-                        if (DN || CEN) yd_n = sh.ye[par ^ 1][(t + 1 < M) ? t + 1 : t][r_dn][lane];
+                        if (UP || CEN) yu_n = ye[par ^ 1][(t + 1 < M) ? t + 1 : t][r_up][lane];
+                        if (DN || CEN) yd_n = ye[par ^ 1][(t + 1 < M) ? t + 1 : t][r_dn][lane];
                     }
                     if (MODE != 1) {
                         const Rsrc rg = sg2_rsrc<T>(G + foff, st, fbytes);
 #pragma unroll
-                        for (int i = 0; i < R; ++i) sg2_st(rg, soff[i], s * Gp[t].v[i]);
+                        for (int i = 0; i < R; ++i) sg2_st(rg, soff[i], TV_SG2_COPYONLY ? c.v[i] : s * Gp[t].v[i]);
                     } else {
                         const Rsrc ro = sg2_rsrc<T>(sa.x_out + foff, st, fbytes);
                         if (!TV_SG2_X0_AHEAD) {
@@ -638,11 +697,11 @@ __device__ __forceinline__ void sg2_tile(const SgTiles& tm, bool fast, long long
     }
 }
 
-template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false>
-__global__ __launch_bounds__(64 * NW, (NW <= 4) ? 2 : 1) void k_subgrad_col(DG g, WT<T> w, const T* __restrict__ x, const T* __restrict__ xp,
+template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false, int NWX = 1>
+__global__ __launch_bounds__(64 * NW * NWX, 2) void k_subgrad_col(DG g, WT<T> w, const T* __restrict__ x, const T* __restrict__ xp,
                                                                             const T* __restrict__ xn, T* __restrict__ G, int zchunk, int nchunks,
                                                                             double* __restrict__ partials, SgArgs2<T> sa, SgTiles tm) {
-    using K = SgCol<S, T, M, R, NW, MODE, TWIN, XLD>;
+    using K = SgCol<S, T, M, R, NW, MODE, TWIN, XLD, NWX>;
     __shared__ typename K::Shared sh;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + SG2_TWU - 1) / SG2_TWU : 1;

@@ -59,13 +59,21 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
                       double* fidout, void* ws, hipStream_t st, const SgHostArgs& so) {
     constexpr bool F64 = sizeof(T) == 8;
     constexpr int R = F64 ? 2 : 4, NW = 4;
+#ifndef TV_SG2_NWX
+#define TV_SG2_NWX 2
+#endif
+    constexpr int NWX = F64 ? 1 : TV_SG2_NWX;         // fp32: two wave tiles side by side per block (8 waves, one block per CU)
 #ifndef TV_SG2_XLD32
 #define TV_SG2_XLD32 0
 #endif
     constexpr bool XLD = F64 || TV_SG2_XLD32;
     const long long nmax = max_partials(d);
     const bool halo = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL);
+#if TV_SG2_WIDE
+    const int UR = R, UC = 64 * NW;
+#else
     const int UR = R * NW - 2, UC = halo ? 60 : 62;
+#endif
     const long long tx = (d.nx + UC - 1) / UC, ty = (d.ny + UR - 1) / UR;
     const long long nwin = (d.m > SG2_TWN) ? (d.m + SG2_TWU - 1) / SG2_TWU : 1;
     // planes per z-chunk (TV_ZCHUNK overrides): 16.  A chunk computes two extra planes of norms, so longer chunks waste less
@@ -75,31 +83,40 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
         zc = 16;
-        while (zc > 8 && tx * ty * nwin * ((d.nz + zc - 1) / zc) < 2048) zc -= 4;
+        while (zc > 8 && ((tx + NWX - 1) / NWX) * ty * nwin * ((d.nz + zc - 1) / zc) < 1024 * (3 - NWX)) zc -= 4;
     }
     if (zc > d.nz) zc = d.nz;
     const long long nch = (d.nz + zc - 1) / zc;
     // interior rectangle of the tile grid (tv_subgrad2.h, SgTiles): tiles with every site, ring included, strictly inside the frame
     const int RING = halo ? 2 : 1, RB = R * NW;
+    // tiles of the launch = BLOCK tiles: NWX wave tiles side by side (the last block of a row may hold a wave tile beyond the frame:
+    // all its lanes are out of range).  A block runs the variant without border multipliers iff all its wave tiles are interior.
+    const long long txb = (tx + NWX - 1) / NWX;
     SgTiles tm{};
-    tm.tx = (int)tx; tm.ty = (int)ty;
+    tm.tx = (int)txb; tm.ty = (int)ty;
     int ix0 = 1, ix1 = (int)((d.nx - 2 - 63 + RING) / UC), iy0 = 1, iy1 = (int)((d.ny - RB) / UR);
-    if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || d.wv != nullptr || ix1 < ix0 || iy1 < iy0) { ix0 = iy0 = 1; ix1 = iy1 = 0; }
+    if (TV_SG2_WIDE) { ix1 = (int)tx - 1; ix0 = 0; iy0 = 0; iy1 = (int)ty - 1; }
+    else if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || d.wv != nullptr || ix1 < ix0 || iy1 < iy0) { ix0 = iy0 = 1; ix1 = iy1 = 0; }
+    if (ix1 >= ix0) {            // wave-tile columns [ix0, ix1] -> block-tile columns whose NWX wave tiles all lie inside
+        const int b0 = (ix0 + NWX - 1) / NWX, b1 = (ix1 + 1) / NWX - 1;
+        ix0 = b0; ix1 = b1;
+        if (ix1 < ix0) { ix0 = iy0 = 1; ix1 = iy1 = 0; }
+    }
     tm.ix0 = ix0; tm.ix1 = ix1; tm.iy0 = iy0; tm.iy1 = iy1;
     tm.nfast = (long long)(ix1 - ix0 + 1) * (iy1 - iy0 + 1);
-    tm.nborder = tx * ty - tm.nfast;
+    tm.nborder = txb * ty - tm.nfast;
     const long long nbf = tm.nfast * nch * nwin, nbb = tm.nborder * nch * nwin, nb = nbf + nbb;
     if (nb > nmax) return fail(TV_E_ARG, "internal: partials exceed the workspace");
     const long long ngrid = (nbb + 7) / 8 * 8 + (nbf + 7) / 8 * 8;
     if (ngrid > 0x7fffffffll) return fail(TV_E_ARG, "volume too large for the one-pass sub-gradient grid");
-    const dim3 block(64, NW, 1);
+    const dim3 block(64, NW * NWX, 1);
     double* w0 = (double*)ws;
     double* w1 = w0 + nmax + kStage + 16;
     SgArgs2<T> sa{(const T*)so.x0, (T*)so.x_out, (T)so.step, (T)so.lambda, w1, (T*)so.norms};
     int rc = dispatch_sg(g->scheme, d.m > SG2_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
         constexpr int MM = (M == 0) ? SG2_TWN : M;
         constexpr bool TW = (M == 0);
-        hipLaunchKernelGGL((k_subgrad_col<S, T, MM, R, NW, MODE, TW, XLD>), dim3((unsigned)ngrid), block, 0, st, d, make_w<T>(g),
+        hipLaunchKernelGGL((k_subgrad_col<S, T, MM, R, NW, MODE, TW, XLD, NWX>), dim3((unsigned)ngrid), block, 0, st, d, make_w<T>(g),
                            (const T*)x, (const T*)x_prev, (const T*)x_next, (T*)G, zc, (int)nch, w0, sa, tm);
         HIP_TRY(hipGetLastError());
         return 0;
