@@ -20,6 +20,7 @@ struct DG {
     int nd;                // gradient channels
     int za, ta;            // z / time axis active
     int z_two, t_two;      // central scheme: axis has exactly two points -> forward stencil
+    int vl;                // columns per 16-byte lane of the image dtype: 4 (fp32) / 2 (fp64)
     int ch_z, ch_t;        // first channel of the z / time axis
     long long s_t;         // frame stride            ny*nx
     long long s_z;         // image plane stride      m*ny*nx   (== gradient channel stride)

@@ -39,16 +39,7 @@ __device__ __forceinline__ double dpp_from_right(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x101, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x101, 0xF, 0xF, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-// dtype-generic forms of ldu / ldu1 / stu (tv_fused.h) and of the 16-lane row shuffles: a lane holds V = 16 / sizeof(T) columns
-template <typename T, int V> __device__ __forceinline__ Vec<T, V> ldu_t(const T* ubase, unsigned voff) {
-    return *reinterpret_cast<const Vec<T, V>*>(reinterpret_cast<const char*>(ubase) + voff);
-}
-template <typename T> __device__ __forceinline__ T ldu1_t(const T* ubase, unsigned voff) {
-    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(ubase) + voff);
-}
-template <typename T, int V> __device__ __forceinline__ void stu_t(T* ubase, unsigned voff, const Vec<T, V>& v) {
-    *reinterpret_cast<Vec<T, V>*>(reinterpret_cast<char*>(ubase) + voff) = v;
-}
+// the 16-lane row shuffles for lanes of V = 16 / sizeof(T) columns (ldu_t / ldu1_t / stu_t: tv_fused.h)
 template <typename T, int V> __device__ __forceinline__ Vec<T, V> shfl_up16_t(const Vec<T, V>& v) {
     Vec<T, V> r;
 #pragma unroll

@@ -54,6 +54,8 @@ constexpr int CP_NW = TV_FUSED_NW;
 constexpr int CP_TR = TV_FUSED_TR, CP_TL = 64 / CP_TR, CP_WC = 4 * CP_TL, CP_BC = CP_NW * CP_WC;
 constexpr int CP_LSH = (CP_TL == 16) ? 4 : 3;
 static_assert(CP_TR == 4 || CP_TR == 8, "wave tile: 4 x 16 or 8 x 8");
+// the same for lanes of V columns (V = 4 floats, 2 doubles: round 3)
+template <int V> struct CPG { static constexpr int WC = V * CP_TL, BC = CP_NW * V * CP_TL; };
 
 struct FusedCoord {
     int lane, row, lx, col0, y, zs, ze;
@@ -82,15 +84,15 @@ __device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk, int c
 
 // coordinates of the one-sweep CP kernel: block (64, 4), wave = threadIdx.y covers columns [CP_WC w, CP_WC (w + 1))
 // of a CP_TR-row x CP_BC-column block tile
-__device__ __forceinline__ FusedCoord cp_coord(const DG& g, int zchunk, int chunk0) {
+template <int V = 4> __device__ __forceinline__ FusedCoord cp_coord(const DG& g, int zchunk, int chunk0) {
     FusedCoord c;
     c.lane = (int)threadIdx.x;
     c.row = c.lane >> CP_LSH;
     c.lx = c.lane & (CP_TL - 1);
-    const int nxv = g.nx / 4;
+    const int nxv = g.nx / V;
     const int tiles_x = (nxv + CP_NW * CP_TL - 1) / (CP_NW * CP_TL);
     const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
-    c.col0 = (bx * CP_NW * CP_TL + (int)threadIdx.y * CP_TL + c.lx) * 4;
+    c.col0 = (bx * CP_NW * CP_TL + (int)threadIdx.y * CP_TL + c.lx) * V;
     c.y = by * CP_TR + c.row;
     c.ok = (c.col0 < g.nx) && (c.y < g.ny);
     c.zs = ((int)blockIdx.y + chunk0) * zchunk;
@@ -112,15 +114,15 @@ template <int S> __device__ __forceinline__ bool is_seam_frame(const DG& g, int 
     return (UP && k == 0 && t >= 1) || (DN && k == CP_TWN - 1 && t <= g.m - (CEN ? 3 : 2));
 }
 
-template <int S, bool XW>
+template <int S, bool XW, int V = 4>
 __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, int col0, int zchunk) {
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND);
-    constexpr int CM = XW ? CP_BC - 1 : CP_WC - 1;   // column period of the tiles whose edges are left to the fix-up
+    constexpr int CM = XW ? CPG<V>::BC - 1 : CPG<V>::WC - 1;   // column period of the tiles whose edges are left to the fix-up
     bool f = false;
     // rows: every wave tile (CP_TR rows); columns: only the BLOCK tile edges (CP_BC columns) -- the CP_NW waves
     // of a block hand their edge columns to each other through LDS inside the sweep
     if (UP) f = f || ((y & (CP_TR - 1)) == 0 && y >= 1) || ((col0 & CM) == 0 && col0 >= 1);
-    if (DN) f = f || ((y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - 2) || ((col0 & CM) == CM - 3 && col0 + 4 <= g.nx - 1);
+    if (DN) f = f || ((y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - 2) || ((col0 & CM) == CM - (V - 1) && col0 + V <= g.nx - 1);
     if (g.za) {
         const int gz = g.z0 + zl;
         const int zs = (zl / zchunk) * zchunk;
@@ -131,10 +133,10 @@ __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, in
     return f;
 }
 // ... including the time-window seams
-template <int S, bool XW>
+template <int S, bool XW, int V = 4>
 __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, int col0, int zchunk, int t) {
     if (is_seam_frame<S>(g, t)) return true;
-    return fused_needs_fixup<S, XW>(g, zl, y, col0, zchunk);
+    return fused_needs_fixup<S, XW, V>(g, zl, y, col0, zchunk);
 }
 
 
@@ -145,6 +147,16 @@ __device__ __forceinline__ F4 ldu(const float* ubase, unsigned voff) {
 }
 __device__ __forceinline__ float ldu1(const float* ubase, unsigned voff) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+// dtype-generic forms (round 3: the one-sweep kernel, the streaming kernels): a lane holds V = 16 / sizeof(T) columns
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> ldu_t(const T* ubase, unsigned voff) {
+    return *reinterpret_cast<const Vec<T, V>*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+template <typename T> __device__ __forceinline__ T ldu1_t(const T* ubase, unsigned voff) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(ubase) + voff);
+}
+template <typename T, int V> __device__ __forceinline__ void stu_t(T* ubase, unsigned voff, const Vec<T, V>& v) {
+    *reinterpret_cast<Vec<T, V>*>(reinterpret_cast<char*>(ubase) + voff) = v;
 }
 // streamed-once data (the dual variable q, x0, p): non-temporal loads / stores (-DTV_FUSED_NT=1: A/B of round 3 -- a copy with
 // 8 read + 8 write streams and this kernel's 512-thread blocks gains 1.3 % from it, tools/bwtest3 "mix"; mixing non-temporal loads
@@ -175,6 +187,31 @@ __device__ __forceinline__ void stu_s(float* ubase, unsigned voff, const F4& v) 
     *p = v;
 #endif
 }
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> ldu_s_t(const T* ubase, unsigned voff) {
+    const Vec<T, V>* p = reinterpret_cast<const Vec<T, V>*>(reinterpret_cast<const char*>(ubase) + voff);
+#if TV_FUSED_NT
+    typedef T nt_v __attribute__((ext_vector_type(V)));
+    const nt_v v = __builtin_nontemporal_load(reinterpret_cast<const nt_v*>(p));
+    Vec<T, V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = v[i];
+    return r;
+#else
+    return *p;
+#endif
+}
+template <typename T, int V> __device__ __forceinline__ void stu_s_t(T* ubase, unsigned voff, const Vec<T, V>& v) {
+    Vec<T, V>* p = reinterpret_cast<Vec<T, V>*>(reinterpret_cast<char*>(ubase) + voff);
+#if TV_FUSED_NT
+    typedef T nt_v __attribute__((ext_vector_type(V)));
+    nt_v w;
+#pragma unroll
+    for (int i = 0; i < V; ++i) w[i] = v.v[i];
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_v*>(p));
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ void stu(float* ubase, unsigned voff, const F4& v) {
     *reinterpret_cast<F4*>(reinterpret_cast<char*>(ubase) + voff) = v;
 }
@@ -193,64 +230,68 @@ __device__ __forceinline__ F4 shfl_down16(const F4& v) {
 }
 
 // the same one row of the CP wave tile up / down (CP_TL lanes)
-__device__ __forceinline__ F4 cp_shfl_up(const F4& v) {
-    F4 r;
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> cp_shfl_up(const Vec<T, V>& v) {
+    Vec<T, V> r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_up(v.v[i], CP_TL, 64);
+    for (int i = 0; i < V; ++i) r.v[i] = __shfl_up(v.v[i], CP_TL, 64);
     return r;
 }
-__device__ __forceinline__ F4 cp_shfl_down(const F4& v) {
-    F4 r;
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> cp_shfl_down(const Vec<T, V>& v) {
+    Vec<T, V> r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_down(v.v[i], CP_TL, 64);
+    for (int i = 0; i < V; ++i) r.v[i] = __shfl_down(v.v[i], CP_TL, 64);
     return r;
 }
 
-struct FusedArgs {
-    const float* x_in;
-    const float* xp;      // plane z0-1 of x_in (or nullptr)
-    const float* xn;      // plane z0+nz of x_in (or nullptr)
-    float* q;
-    const float* x0;
-    float* p;
-    float* x_out;
-    float sigma, inv_lambda, tau, sigma_a, inv_1p_sigma_a;
+template <typename T> struct FusedArgsT {
+    const T* x_in;
+    const T* xp;          // plane z0-1 of x_in (or nullptr)
+    const T* xn;          // plane z0+nz of x_in (or nullptr)
+    T* q;
+    const T* x0;
+    T* p;
+    T* x_out;
+    T sigma, inv_lambda, tau, sigma_a, inv_1p_sigma_a;
     double* part_tv;
     double* part_fid;
 };
+using FusedArgs = FusedArgsT<float>;
 
 // XW: the CP_NW waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
 // TWIN: time windows for volumes with more than CP_TWN frames -- grid z = window, the block works on the frames
 // [t0, t0 + M) of the volume (M = CP_TWN), reads x of the frame on either side of its window for the time differences
 // and leaves the adjoint terms that cross a window seam to the fix-up (exactly like the z-chunk edges)
-template <int S, int M, bool XW, bool TWIN = false>
-__global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, FusedArgs a, int zchunk, int chunk0) {
+// T: float (4 columns per 16-byte lane) or double (2 columns, round 3): the same tile in lanes, half as wide in columns.
+template <int S, int M, bool XW, bool TWIN = false, typename T = float>
+__global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, FusedArgsT<T> a, int zchunk, int chunk0) {
+    constexpr int V = 16 / (int)sizeof(T);
+    using VT = Vec<T, V>;
     __shared__ double sm[16];
-    const FusedCoord c = cp_coord(g, zchunk, chunk0);
+    const FusedCoord c = cp_coord<V>(g, zchunk, chunk0);
     const int t0 = TWIN ? (int)blockIdx.z * CP_TWN : 0;       // first frame of this block's window
     const int Mg = TWIN ? g.m : M;                             // frames of the volume
-    const unsigned voff = (unsigned)c.inpl * 4u;          // byte offset of this lane's vector inside a frame (frames <= 2^30 px)
-    const unsigned row_bytes = (unsigned)g.nx * 4u;
+    const unsigned voff = (unsigned)c.inpl * (unsigned)sizeof(T);          // byte offset of this lane's vector inside a frame (frames <= 2^30 px)
+    const unsigned row_bytes = (unsigned)g.nx * (unsigned)sizeof(T);
     // UP: some channel's adjoint takes y^(p-e) (forward differences; central: every channel); DN: ... y^(p+e).
     // CEN: central -- ONE channel per axis plays both roles, has no own-site term and is defined on interior
     // points only; its two-point z / t axes (z_fwd / t_fwd) behave like upwind axes.
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
     constexpr bool NEXT = UP, PREV = DN;       // forward differences need x(+e), backward x(-e)
     const bool z_fwd = CEN && g.z_two, t_fwd = CEN && g.t_two;
-    const F4 zero = vsplat<float, 4>(0.f);
-    const F4 mf = g.ta ? mask_factor<float, 4>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<float, 4>(1.f);
-    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : (CEN ? 0.5f : 1.f);
+    const VT zero = vsplat<T, V>(T(0));
+    const VT mf = g.ta ? mask_factor<T, V>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<T, V>(T(1));
+    const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : (CEN ? T(0.5) : T(1));
     double acc_tv = 0.0, acc_fid = 0.0;
     // x planes z (C) and z-1 (P) live in registers; the adjoint accumulators R (plane z-1 waiting
     // for its z+1 term) and the carried z-up terms U live in LDS, private per thread ([frame][thread]:
     // conflict-free 16-byte lanes, no barrier needed) -- 4 M vectors of state do not fit the VGPR file
-    __shared__ F4 lds_R[M][64 * CP_NW];
-    __shared__ F4 lds_U[M][64 * CP_NW];
+    __shared__ VT lds_R[M][64 * CP_NW];
+    __shared__ VT lds_U[M][64 * CP_NW];
     // column terms that cross the 64-column wave tiles INSIDE the block: each wave publishes, per plane and
     // frame, the col-up value of its last column and the col-down value of its first column (per row);
     // the neighbouring wave adds them one plane later (after the per-plane barrier), double-buffered
-    __shared__ float edge_cu[XW ? 2 : 1][XW ? M : 1][CP_NW][CP_TR];
-    __shared__ float edge_cd[XW ? 2 : 1][XW ? M : 1][CP_NW][CP_TR];
+    __shared__ T edge_cu[XW ? 2 : 1][XW ? M : 1][CP_NW][CP_TR];
+    __shared__ T edge_cd[XW ? 2 : 1][XW ? M : 1][CP_NW][CP_TR];
     // edge_flag[w] = number of planes of this chunk whose edge columns wave w has published.  A wave starts
     // plane z only after both neighbours published plane z-1, so neighbouring waves stay within one plane of
     // each other (that is what makes two buffers enough) -- a pairwise hand-off, not a block-wide barrier.
@@ -261,12 +302,12 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
     // hybrid 36.4 / 36.4 vs 35.9 / 37.4 ms, upwind 26.7 / 25.4 vs 23.7 / 25.8, central equal (profiles/r2_ab_xe.txt) --
     // the edge loads are not what the sweep's ~14 GB of over-read consist of.
     constexpr bool XE = XW && (TV_FUSED_XE != 0);
-    __shared__ float edge_xl[XE ? 2 : 1][XE ? M : 1][CP_NW][CP_TR];
-    __shared__ float edge_xr[XE ? 2 : 1][XE ? M : 1][CP_NW][CP_TR];
+    __shared__ T edge_xl[XE ? 2 : 1][XE ? M : 1][CP_NW][CP_TR];
+    __shared__ T edge_xr[XE ? 2 : 1][XE ? M : 1][CP_NW][CP_TR];
     const int wave = (int)threadIdx.y;
     if (XW && c.lane == 0) edge_flag[wave] = 0;
     const int tid = (int)threadIdx.y * 64 + (int)threadIdx.x;
-    F4 C[M], P[M];
+    VT C[M], P[M];
     // EA (round 2): the 4-byte column neighbours across the wave-tile border (first / last lane of a row segment) are requested
     // ONE PLANE AHEAD, in the same frame as the wide load of that plane -- i.e. while the neighbouring wave fetches the very
     // line they live in.  Requested a plane later (as before) the line had left the L2 again (a CU streams ~0.7 MB per plane
@@ -274,68 +315,68 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
     // the north-star volume on the read counter (tools/pmc_calib.sh shows the same +14 % on a kernel with exactly known bytes).
     constexpr bool EA = (TV_FUSED_EA != 0) && !(XW && (TV_FUSED_XE != 0));
     const bool e_le = PREV && (c.lx == 0) && c.ok && (c.col0 > 0);
-    const bool e_re = NEXT && (c.lx == CP_TL - 1) && c.ok && (c.col0 + 4 < g.nx);
-    const unsigned eoff = e_le ? voff - 4u : voff + 16u;
-    float E[EA ? M : 1];
+    const bool e_re = NEXT && (c.lx == CP_TL - 1) && c.ok && (c.col0 + V < g.nx);
+    const unsigned eoff = e_le ? voff - (unsigned)sizeof(T) : voff + 16u;
+    T E[EA ? M : 1];
     // PFQ (round 2, central): the four dual channels of the NEXT frame are requested at the top of the current one.  Central
     // has 1 + 4 streams per frame (hybrid: 1 + 8) but hybrid's per-site arithmetic (every channel plays both adjoint roles),
     // so its waves waited ~77 % of the time with too few bytes in flight: sweep 26.6 - 27.4 -> 21.2 - 23.0 ms on the
     // north-star volume (0.52 -> 0.63 of peak; profiles/r2_ab_pfq.txt).  Measured for upwind / downwind too: 3 - 7 % SLOWER
     // there (they already request plane z+1 of x a step ahead), so it stays off; hybrid has no registers for it.
     constexpr bool PFQ = (TV_FUSED_PFQ != 0) && (S == CENTRAL) && !TWIN;
-    F4 qpre[PFQ ? 4 : 1];
+    VT qpre[PFQ ? 4 : 1];
     if (PFQ) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) qpre[k] = zero;
         if (c.ok) {
-            const float* qb0 = a.q + (long long)c.zs * g.s_dz;
+            const T* qb0 = a.q + (long long)c.zs * g.s_dz;
             for_each_channel<S>(g, [&](auto slot, int ch) {
                 constexpr int k = decltype(slot)::value;
-                qpre[k & 3] = ldu_s(qb0 + (long long)ch * g.s_z, voff);
+                qpre[k & 3] = ldu_s_t<T, V>(qb0 + (long long)ch * g.s_z, voff);
             });
         }
     }
     {
-        const float* pc = zplane<float>(g, a.x_in, a.xp, a.xn, 1, c.zs);
-        const float* pp = (PREV && g.za) ? zplane<float>(g, a.x_in, a.xp, a.xn, 1, c.zs - 1) : nullptr;
+        const T* pc = zplane<T>(g, a.x_in, a.xp, a.xn, 1, c.zs);
+        const T* pp = (PREV && g.za) ? zplane<T>(g, a.x_in, a.xp, a.xn, 1, c.zs - 1) : nullptr;
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const bool fok = c.ok && (t0 + t < Mg);
-            C[t] = fok ? ldu(pc + (long long)(t0 + t) * g.s_t, voff) : zero;
-            P[t] = (fok && pp != nullptr) ? ldu(pp + (long long)(t0 + t) * g.s_t, voff) : zero;
-            if (EA) E[t] = (fok && (e_le || e_re)) ? ldu1(pc + (long long)(t0 + t) * g.s_t, eoff) : 0.f;
+            C[t] = fok ? ldu_t<T, V>(pc + (long long)(t0 + t) * g.s_t, voff) : zero;
+            P[t] = (fok && pp != nullptr) ? ldu_t<T, V>(pp + (long long)(t0 + t) * g.s_t, voff) : zero;
+            if (EA) E[t] = (fok && (e_le || e_re)) ? ldu1_t<T>(pc + (long long)(t0 + t) * g.s_t, eoff) : T(0);
             lds_R[t][tid] = zero;
             lds_U[t][tid] = zero;
             if (XE) {
                 if (c.lx == 0) edge_xl[0][t][wave][c.row] = C[t].v[0];
-                if (c.lx == CP_TL - 1) edge_xr[0][t][wave][c.row] = C[t].v[3];
+                if (c.lx == CP_TL - 1) edge_xr[0][t][wave][c.row] = C[t].v[V - 1];
             }
         }
     }
     if (XW) __syncthreads();      // counters zeroed, the first plane's x edges published
 
     // finalise plane zf (its x values are in `xv`), adjoint accumulator `racc` (un-scaled)
-    auto finalize = [&](int zf, int t, const F4& xv, F4 racc) {
+    auto finalize = [&](int zf, int t, const VT& xv, VT racc) {
         if (!c.ok || t0 + t >= Mg) return;
         const int eb = (zf - c.zs) & 1;
         if (XW) {
             if (UP && c.lx == 0 && wave > 0) racc.v[0] += edge_cu[eb][t][wave - 1][c.row];
-            if (DN && c.lx == CP_TL - 1 && wave < CP_NW - 1) racc.v[3] -= edge_cd[eb][t][wave + 1][c.row];
+            if (DN && c.lx == CP_TL - 1 && wave < CP_NW - 1) racc.v[V - 1] -= edge_cd[eb][t][wave + 1][c.row];
         }
         const long long foff = (long long)zf * g.s_z + (long long)(t0 + t) * g.s_t;      // uniform
-        const F4 x0v = ldu_s(a.x0 + foff, voff), pv = ldu_s(a.p + foff, voff);
-        F4 pn, xo;
+        const VT x0v = ldu_s_t<T, V>(a.x0 + foff, voff), pv = ldu_s_t<T, V>(a.p + foff, voff);
+        VT pn, xo;
         double e2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < V; ++i) {
             pn.v[i] = (pv.v[i] + a.sigma_a * (xv.v[i] - x0v.v[i])) * a.inv_1p_sigma_a;
             xo.v[i] = (xv.v[i] - a.tau * pn.v[i]) - a.tau * (s * racc.v[i]);
             const double e = (double)xo.v[i] - (double)x0v.v[i];
             e2 += 0.5 * e * e;
         }
-        stu_s(a.p + foff, voff, pn);
-        stu_s(a.x_out + foff, voff, xo);
-        if (!fused_needs_fixup<S, XW>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += e2;
+        stu_s_t<T, V>(a.p + foff, voff, pn);
+        stu_s_t<T, V>(a.x_out + foff, voff, xo);
+        if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += e2;
     };
 
     // wait until the neighbouring waves have published `planes` planes (all waves of a block are resident and
@@ -348,8 +389,8 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
     for (int z = c.zs; z < c.ze; ++z) {
         if (XW && z > c.zs) wait_neighbours(z - c.zs);
         const int gz = g.z0 + z;
-        const float* pc = zplane<float>(g, a.x_in, a.xp, a.xn, 1, z);
-        const float* pn = zplane<float>(g, a.x_in, a.xp, a.xn, 1, z + 1);
+        const T* pc = zplane<T>(g, a.x_in, a.xp, a.xn, 1, z);
+        const T* pn = zplane<T>(g, a.x_in, a.xp, a.xn, 1, z + 1);
         const bool has_pz = PREV && g.za && (gz > 0);
         const bool has_nz = NEXT && g.za && (pn != nullptr);
         const bool load_next = (pn != nullptr) && c.ok && (has_nz || (z + 1 < c.ze));
@@ -358,54 +399,54 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
         // frames of plane z+1 here instead (these two schemes have the registers for it; hybrid has 1 + 8 streams
         // per frame and no registers left; downwind needs x(z+1) only one plane later)
         constexpr bool PFN = (S == UPWIND || S == CENTRAL);
-        F4 Nn[PFN ? M : 1];
+        VT Nn[PFN ? M : 1];
         if (PFN) {
 #pragma unroll
-            for (int t = 0; t < M; ++t) Nn[t] = (load_next && t0 + t < Mg) ? ldu(pn + (long long)(t0 + t) * g.s_t, voff) : zero;
+            for (int t = 0; t < M; ++t) Nn[t] = (load_next && t0 + t < Mg) ? ldu_t<T, V>(pn + (long long)(t0 + t) * g.s_t, voff) : zero;
         }
-        float En[(PFN && EA) ? M : 1];      // the border elements of plane z+1 travel with its wide loads
+        T En[(PFN && EA) ? M : 1];      // the border elements of plane z+1 travel with its wide loads
         if (PFN && EA) {
 #pragma unroll
             for (int t = 0; t < M; ++t)
-                En[t] = (load_next && (e_le || e_re) && t0 + t < Mg) ? ldu1(pn + (long long)(t0 + t) * g.s_t, eoff) : 0.f;
+                En[t] = (load_next && (e_le || e_re) && t0 + t < Mg) ? ldu1_t<T>(pn + (long long)(t0 + t) * g.s_t, eoff) : T(0);
         }
-        F4 cold = zero;        // x(z, t-1)
-        F4 ut_prev = zero;     // wt * q'_tup(z, t-1) * mf, already valid-masked
-        F4 r_prev = zero;      // accumulator of frame t-1 of THIS plane, still missing its time-down term
+        VT cold = zero;        // x(z, t-1)
+        VT ut_prev = zero;     // wt * q'_tup(z, t-1) * mf, already valid-masked
+        VT r_prev = zero;      // accumulator of frame t-1 of THIS plane, still missing its time-down term
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const int tg = t0 + t;                                                // frame of the volume
             if (TWIN && tg >= Mg) break;                                          // ragged last window (block-uniform)
             const long long toff = (long long)tg * g.s_t;                         // uniform
-            F4 N;
+            VT N;
             if constexpr (PFN) N = Nn[t];
-            else N = load_next ? ldu(pn + toff, voff) : zero;
-            float e_cur = 0.f;
+            else N = load_next ? ldu_t<T, V>(pn + toff, voff) : zero;
+            T e_cur = T(0);
             if (EA) {
                 e_cur = E[t];
                 if constexpr (PFN) E[t] = En[t];
-                else E[t] = (load_next && (e_le || e_re)) ? ldu1(pn + toff, eoff) : 0.f;
+                else E[t] = (load_next && (e_le || e_re)) ? ldu1_t<T>(pn + toff, eoff) : T(0);
             }
-            F4 qcur[PFQ ? 4 : 1];
+            VT qcur[PFQ ? 4 : 1];
             if (PFQ) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) qcur[k] = qpre[k];
                 const int tn = (t + 1 < M) ? t + 1 : 0, zn = (t + 1 < M) ? z : z + 1;
                 if (c.ok && zn < c.ze) {
-                    const float* qbn = a.q + (long long)zn * g.s_dz + (long long)tn * g.s_t;
+                    const T* qbn = a.q + (long long)zn * g.s_dz + (long long)tn * g.s_t;
                     for_each_channel<S>(g, [&](auto slot, int ch) {
                         constexpr int k = decltype(slot)::value;
-                        qpre[k & 3] = ldu_s(qbn + (long long)ch * g.s_z, voff);
+                        qpre[k & 3] = ldu_s_t<T, V>(qbn + (long long)ch * g.s_z, voff);
                     });
                 }
             }
             // per-VOXEL weight on the time channels (tv_geom::time_weight_vol, the reference's to-do README.md:258): one more
             // streamed read per frame.  D scales the time channels of a voxel by ITS factor, and so does the adjoint below
             // (every q' sample is scaled by its own voxel's factor before the difference): round 3
-            F4 mft = mf;
-            if (g.wv != nullptr && g.ta && c.ok) mft = mf * ldu_s(static_cast<const float*>(g.wv) + (long long)z * g.s_z + toff, voff);
+            VT mft = mf;
+            if (g.wv != nullptr && g.ta && c.ok) mft = mf * ldu_s_t<T, V>(static_cast<const T*>(g.wv) + (long long)z * g.s_z + toff, voff);
             // ------------------------------------------------ neighbourhood of x(z, t)
-            XN<float, 4> n;
+            XN<T, V> n;
             n.c = C[t];
             n.col0 = c.col0;
             n.nr = n.pr = n.nc = n.pc = n.nz = n.pz = n.nt = n.pt = zero;
@@ -413,77 +454,77 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             {   // halo rows of the wave tile: one predicated load (row 0 lanes read y-1, row 3 lanes y+1)
                 const bool want_up = PREV && (c.row == 0) && c.ok && (c.y > 0);
                 const bool want_dn = NEXT && (c.row == CP_TR - 1) && c.ok && (c.y + 1 < g.ny);
-                F4 halo = zero;
-                if (want_up || want_dn) halo = ldu(pc + toff, want_up ? voff - row_bytes : voff + row_bytes);
+                VT halo = zero;
+                if (want_up || want_dn) halo = ldu_t<T, V>(pc + toff, want_up ? voff - row_bytes : voff + row_bytes);
                 if (NEXT) {
                     n.h_nr = c.ok && (c.y + 1 < g.ny);
-                    const F4 sdn = cp_shfl_down(C[t]);
+                    const VT sdn = cp_shfl_down<T, V>(C[t]);
                     n.nr = (c.row == CP_TR - 1) ? halo : sdn;
                 }
                 if (PREV) {
                     n.h_pr = c.ok && (c.y > 0);
-                    const F4 sup = cp_shfl_up(C[t]);
+                    const VT sup = cp_shfl_up<T, V>(C[t]);
                     n.pr = (c.row == 0) ? halo : sup;
                 }
             }
             {   // columns: adjacent lane inside the 16-lane row segment, one scalar at the segment edges
                 const bool le = PREV && (c.lx == 0) && c.ok && (c.col0 > 0);
-                const bool re = NEXT && (c.lx == CP_TL - 1) && c.ok && (c.col0 + 4 < g.nx);
+                const bool re = NEXT && (c.lx == CP_TL - 1) && c.ok && (c.col0 + V < g.nx);
                 // inside the block the neighbouring wave published these elements (XE); the block's own edges are loaded
                 const bool le_lds = XE && le && (wave > 0), re_lds = XE && re && (wave < CP_NW - 1);
-                float edge = 0.f;
+                T edge = T(0);
                 if (EA) edge = e_cur;
-                else if ((le && !le_lds) || (re && !re_lds)) edge = ldu1(pc + toff, le ? voff - 4u : voff + 16u);
+                else if ((le && !le_lds) || (re && !re_lds)) edge = ldu1_t<T>(pc + toff, le ? voff - (unsigned)sizeof(T) : voff + 16u);
                 if (XE) {
                     const int xb = (z - c.zs) & 1;
                     if (le_lds) edge = edge_xr[xb][t][wave - 1][c.row];
                     if (re_lds) edge = edge_xl[xb][t][wave + 1][c.row];
                 }
                 if (NEXT) {
-                    const float sh = __shfl_down(C[t].v[0], 1, 64);
-                    n.nc = shift_left<float, 4>(C[t], (c.lx == CP_TL - 1) ? edge : sh);
+                    const T sh = __shfl_down(C[t].v[0], 1, 64);
+                    n.nc = shift_left<T, V>(C[t], (c.lx == CP_TL - 1) ? edge : sh);
                 }
                 if (PREV) {
-                    const float sh = __shfl_up(C[t].v[3], 1, 64);
-                    n.pc = shift_right<float, 4>(C[t], (c.lx == 0) ? edge : sh);
+                    const T sh = __shfl_up(C[t].v[V - 1], 1, 64);
+                    n.pc = shift_right<T, V>(C[t], (c.lx == 0) ? edge : sh);
                 }
             }
             if (NEXT) {
                 n.h_nz = has_nz; n.nz = N;
                 if (t + 1 < M) { n.h_nt = (g.ta != 0) && (tg + 1 < Mg); n.nt = C[(t + 1 < M) ? t + 1 : t]; }
-                else if (TWIN && g.ta && tg + 1 < Mg) { n.h_nt = true; n.nt = c.ok ? ldu(pc + toff + g.s_t, voff) : zero; }   // across the seam
+                else if (TWIN && g.ta && tg + 1 < Mg) { n.h_nt = true; n.nt = c.ok ? ldu_t<T, V>(pc + toff + g.s_t, voff) : zero; }   // across the seam
             }
             if (PREV) {
                 n.h_pz = has_pz; n.pz = P[t];
                 if (t > 0) { n.h_pt = (g.ta != 0); n.pt = cold; }
-                else if (TWIN && g.ta && tg > 0) { n.h_pt = true; n.pt = c.ok ? ldu(pc + toff - g.s_t, voff) : zero; }        // across the seam
+                else if (TWIN && g.ta && tg > 0) { n.h_pt = true; n.pt = c.ok ? ldu_t<T, V>(pc + toff - g.s_t, voff) : zero; }        // across the seam
             }
-            F4 o[8];
-            d_slots<S, float, 4>(g, w, n, mft, o);
+            VT o[8];
+            d_slots<S, T, V>(g, w, n, mft, o);
             // ------------------------------------------------ dual update (README.md:149-151)
-            F4 v[8];
+            VT v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = zero;
-            float* qbase = a.q + (long long)z * g.s_dz + toff;                    // uniform
-            F4 vs = zero;
+            T* qbase = a.q + (long long)z * g.s_dz + toff;                    // uniform
+            VT vs = zero;
             if (c.ok) {
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
-                    const F4 qv = PFQ ? qcur[k & 3] : ldu_s(qbase + (long long)ch * g.s_z, voff);
+                    const VT qv = PFQ ? qcur[k & 3] : ldu_s_t<T, V>(qbase + (long long)ch * g.s_z, voff);
                     v[k] = qv + a.sigma * o[k];
                     vs = vs + v[k] * v[k];
                 });
-                const F4 ds = sumsq_slots<float, 4>(o);
-                F4 scale;
+                const VT ds = sumsq_slots<T, V>(o);
+                VT scale;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < V; ++i) {
                     acc_tv += (double)tsqrt(ds.v[i]);
-                    scale.v[i] = 1.f / tmax(1.f, tsqrt(vs.v[i]) * a.inv_lambda);
+                    scale.v[i] = T(1) / tmax(T(1), tsqrt(vs.v[i]) * a.inv_lambda);
                 }
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
                     v[k] = v[k] * scale;
-                    stu_s(qbase + (long long)ch * g.s_z, voff, v[k]);
+                    stu_s_t<T, V>(qbase + (long long)ch * g.s_z, voff, v[k]);
                 });
             }
             // slots: non-hybrid 0 rows, 1 cols, 2 z, 3 t ; hybrid 0 ru, 1 cu, 2 rd, 3 cd, 4 zu, 5 zd, 6 tu, 7 td
@@ -492,41 +533,41 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             constexpr int k_tu = (S == HYBRID) ? 6 : 3, k_td = (S == HYBRID) ? 7 : 3;
             // y^ validity: an up channel is defined where the site has a next neighbour, a down
             // channel where it has a previous one; everything else counts as zero
-            F4 qru = zero, qrd = zero, qcu = zero, qcd = zero, qzu = zero, qzd = zero, qtu = zero, qtd = zero;
+            VT qru = zero, qrd = zero, qcu = zero, qcd = zero, qzu = zero, qzd = zero, qtu = zero, qtd = zero;
             if (UP) {
                 if (c.ok && c.y + 1 < g.ny && (!CEN || c.y > 0)) qru = v[k_ru];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    qcu.v[i] = (c.ok && c.col0 + i < g.nx - 1 && (!CEN || c.col0 + i > 0)) ? v[k_cu].v[i] : 0.f;
+                for (int i = 0; i < V; ++i)
+                    qcu.v[i] = (c.ok && c.col0 + i < g.nx - 1 && (!CEN || c.col0 + i > 0)) ? v[k_cu].v[i] : T(0);
                 if (g.za && c.ok && gz + 1 < g.nzg && (!CEN || z_fwd || gz > 0)) qzu = w.wz * v[k_zu];
                 if (g.ta && c.ok && tg + 1 < Mg && (!CEN || t_fwd || tg > 0)) qtu = (w.wt * v[k_tu]) * mft;
             }
             if (DN) {
                 if (c.ok && c.y > 0 && (!CEN || c.y + 1 < g.ny)) qrd = v[k_rd];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    qcd.v[i] = (c.ok && c.col0 + i > 0 && (!CEN || c.col0 + i < g.nx - 1)) ? v[k_cd].v[i] : 0.f;
+                for (int i = 0; i < V; ++i)
+                    qcd.v[i] = (c.ok && c.col0 + i > 0 && (!CEN || c.col0 + i < g.nx - 1)) ? v[k_cd].v[i] : T(0);
                 if (g.za && c.ok && gz > 0 && (!CEN || (!z_fwd && gz + 1 < g.nzg))) qzd = w.wz * v[k_zd];
                 if (g.ta && c.ok && tg > 0 && (!CEN || (!t_fwd && tg + 1 < Mg))) qtd = (w.wt * v[k_td]) * mft;
             }
             // ------------------------------------------------ lagged primal update of plane z-1
             if (z > c.zs) {
-                F4 rf = lds_R[t][tid];
+                VT rf = lds_R[t][tid];
                 if (DN) rf = rf - qzd;
                 finalize(z - 1, t, P[t], rf);
             }
             // ------------------------------------------------ adjoint accumulator of plane z
-            F4 r = zero;
+            VT r = zero;
             if (UP) {
                 if (!CEN) r = r - qru - qcu - qzu - qtu;              // own-site terms (central has none ...
                 else {
                     if (z_fwd) r = r - qzu;                           // ... except on its two-point axes)
                     if (t_fwd) r = r - qtu;
                 }
-                const F4 above = cp_shfl_up(qru);                      // q'_rowup of the row above
+                const VT above = cp_shfl_up<T, V>(qru);                      // q'_rowup of the row above
                 if (c.row > 0) r = r + above;
-                const float lft = __shfl_up(qcu.v[3], 1, 64);         // q'_colup one column to the left
-                r = r + shift_right<float, 4>(qcu, (c.lx == 0) ? 0.f : lft);
+                const T lft = __shfl_up(qcu.v[V - 1], 1, 64);         // q'_colup one column to the left
+                r = r + shift_right<T, V>(qcu, (c.lx == 0) ? T(0) : lft);
                 if (g.za) {
                     r = r + lds_U[t][tid];                            // wz q'_zup(z-1, t)
                     lds_U[t][tid] = qzu;
@@ -536,15 +577,15 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             }
             if (DN) {
                 if (!CEN) r = r + qrd + qcd + qzd + qtd;
-                const F4 below = cp_shfl_down(qrd);                    // q'_rowdown of the row below
+                const VT below = cp_shfl_down<T, V>(qrd);                    // q'_rowdown of the row below
                 if (c.row < CP_TR - 1) r = r - below;
-                const float rgt = __shfl_down(qcd.v[0], 1, 64);       // q'_coldown one column to the right
-                r = r - shift_left<float, 4>(qcd, (c.lx == CP_TL - 1) ? 0.f : rgt);
+                const T rgt = __shfl_down(qcd.v[0], 1, 64);       // q'_coldown one column to the right
+                r = r - shift_left<T, V>(qcd, (c.lx == CP_TL - 1) ? T(0) : rgt);
                 r_prev = r_prev - qtd;                                // time-down term of frame t-1
             }
             if (XW) {
                 const int eb = (z - c.zs) & 1;
-                if (UP && c.lx == CP_TL - 1) edge_cu[eb][t][wave][c.row] = qcu.v[3];
+                if (UP && c.lx == CP_TL - 1) edge_cu[eb][t][wave][c.row] = qcu.v[V - 1];
                 if (DN && c.lx == 0) edge_cd[eb][t][wave][c.row] = qcd.v[0];
             }
             if (t > 0) lds_R[(t > 0) ? t - 1 : 0][tid] = r_prev;     // frame t-1 is complete up to its z+1 term
@@ -556,7 +597,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
             if (XE) {                 // x edges of the plane the block works on next
                 const int nb = (z + 1 - c.zs) & 1;
                 if (c.lx == 0) edge_xl[nb][t][wave][c.row] = N.v[0];
-                if (c.lx == CP_TL - 1) edge_xr[nb][t][wave][c.row] = N.v[3];
+                if (c.lx == CP_TL - 1) edge_xr[nb][t][wave][c.row] = N.v[V - 1];
             }
         }
         if (XW) {                     // publish: edge columns of plane z are visible before the counter moves
@@ -580,69 +621,72 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<float> w, F
 // ranks) to x_out and account the fidelity of those sites.  One site-vector per thread; vectors
 // with nothing missing return at once.
 // ---------------------------------------------------------------------------------------------
-struct FixupArgs {
-    const float* q;
-    const float* qp;      // plane z0-1 of the z-up channel (previous rank) or nullptr
-    const float* qn;      // plane z0+nz of the z-down channel (next rank) or nullptr
-    float* x_out;
-    const float* x0;
-    float tau;
+template <typename T> struct FixupArgsT {
+    const T* q;
+    const T* qp;          // plane z0-1 of the z-up channel (previous rank) or nullptr
+    const T* qn;          // plane z0+nz of the z-down channel (next rank) or nullptr
+    T* x_out;
+    const T* x0;
+    T tau;
     int chunk0;           // class 1: first chunk whose edge planes are visited
 };
+using FixupArgs = FixupArgsT<float>;
 
 // all missing terms of one site-vector; returns its fidelity 1/2 |x_out - x0|^2 (0 if nothing was missing)
-template <int S, bool XW>
-__device__ __forceinline__ double fixup_site(const DG& g, const WT<float>& w, const FixupArgs& a, int zchunk, int zl, int t, int y,
+template <int S, bool XW, typename T = float>
+__device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const FixupArgsT<T>& a, int zchunk, int zl, int t, int y,
                                              int col0) {
+    constexpr int V = 16 / (int)sizeof(T);
+    using VT = Vec<T, V>;
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
-    if (!fused_needs_fixup<S, XW>(g, zl, y, col0, zchunk, t)) return 0.0;
-    constexpr int CM = XW ? CP_BC - 1 : CP_WC - 1;
+    if (!fused_needs_fixup<S, XW, V>(g, zl, y, col0, zchunk, t)) return 0.0;
+    constexpr int CM = XW ? CPG<V>::BC - 1 : CPG<V>::WC - 1;
     const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
     const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
     const bool z_fwd = CEN && g.z_two;
     const long long inpl = (long long)t * g.s_t + (long long)y * g.nx + col0;
-    const float* qb = a.q + (long long)zl * g.s_dz + inpl;
-    const F4 zero = vsplat<float, 4>(0.f);
-    F4 m = zero;
+    const T* qb = a.q + (long long)zl * g.s_dz + inpl;
+    const VT zero = vsplat<T, V>(T(0));
+    VT m = zero;
     // a missing term counts only where the neighbour's channel is defined (central: interior points of the axis)
-    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + vload<float, 4>(qb + (long long)c_ru * g.s_z - g.nx);
-    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - vload<float, 4>(qb + (long long)c_rd * g.s_z + g.nx);
+    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + vload<T, V>(qb + (long long)c_ru * g.s_z - g.nx);
+    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - vload<T, V>(qb + (long long)c_rd * g.s_z + g.nx);
     if (UP && (col0 & CM) == 0 && col0 >= (CEN ? 2 : 1)) m.v[0] += qb[(long long)c_cu * g.s_z - 1];
-    if (DN && (col0 & CM) == CM - 3 && col0 + 4 <= g.nx - (CEN ? 2 : 1)) m.v[3] -= qb[(long long)c_cd * g.s_z + 4];
+    if (DN && (col0 & CM) == CM - (V - 1) && col0 + V <= g.nx - (CEN ? 2 : 1)) m.v[V - 1] -= qb[(long long)c_cd * g.s_z + V];
     if (g.za) {
         const int gz = g.z0 + zl;
         const int zs = (zl / zchunk) * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
         if (UP && zl == zs && gz >= ((CEN && !z_fwd) ? 2 : 1)) {
-            const F4 u = (zl >= 1) ? vload<float, 4>(qb + (long long)c_zu * g.s_z - g.s_dz) : vload<float, 4>(a.qp + inpl);
+            const VT u = (zl >= 1) ? vload<T, V>(qb + (long long)c_zu * g.s_z - g.s_dz) : vload<T, V>(a.qp + inpl);
             m = m + w.wz * u;
         }
         if (DN && !z_fwd && zl == ze - 1 && gz <= g.nzg - (CEN ? 3 : 2)) {
-            const F4 d = (zl + 1 < g.nz) ? vload<float, 4>(qb + (long long)c_zd * g.s_z + g.s_dz) : vload<float, 4>(a.qn + inpl);
+            const VT d = (zl + 1 < g.nz) ? vload<T, V>(qb + (long long)c_zd * g.s_z + g.s_dz) : vload<T, V>(a.qn + inpl);
             m = m - w.wz * d;
         }
     }
     if (g.ta && g.m > CP_TWN) {      // time-window seams: the neighbouring frame belongs to another window of the sweep
         const int c_tu = g.ch_t, c_td = (S == HYBRID) ? g.ch_t + 1 : g.ch_t;
         const int k = t % CP_TWN;
-        F4 mt = zero;       // every sample with the per-voxel factor of ITS frame (1 without a weight volume)
-        if (UP && k == 0 && t >= 1) mt = mt + vload<float, 4>(qb + (long long)c_tu * g.s_z - g.s_t) * vol_factor<float, 4>(g, zl, t - 1, y, col0);
+        VT mt = zero;       // every sample with the per-voxel factor of ITS frame (1 without a weight volume)
+        if (UP && k == 0 && t >= 1) mt = mt + vload<T, V>(qb + (long long)c_tu * g.s_z - g.s_t) * vol_factor<T, V>(g, zl, t - 1, y, col0);
         if (DN && k == CP_TWN - 1 && t <= g.m - (CEN ? 3 : 2))
-            mt = mt - vload<float, 4>(qb + (long long)c_td * g.s_z + g.s_t) * vol_factor<float, 4>(g, zl, t + 1, y, col0);
-        m = m + (w.wt * mt) * mask_factor<float, 4>(g, w.sf, y, col0);
+            mt = mt - vload<T, V>(qb + (long long)c_td * g.s_z + g.s_t) * vol_factor<T, V>(g, zl, t + 1, y, col0);
+        m = m + (w.wt * mt) * mask_factor<T, V>(g, w.sf, y, col0);
     }
-    const float s = (S == HYBRID) ? Consts<float>::inv_sqrt2() : (CEN ? 0.5f : 1.f);
+    const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : (CEN ? T(0.5) : T(1));
     const long long off = (long long)zl * g.s_z + inpl;
-    const F4 xv = vload<float, 4>(a.x_out + off), x0v = vload<float, 4>(a.x0 + off);
-    F4 xo;
+    const VT xv = vload<T, V>(a.x_out + off), x0v = vload<T, V>(a.x0 + off);
+    VT xo;
     double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < V; ++i) {
         xo.v[i] = xv.v[i] - a.tau * (s * m.v[i]);
         const double e = (double)xo.v[i] - (double)x0v.v[i];
         acc += 0.5 * e * e;
     }
-    vstore<float, 4>(a.x_out + off, xo);
+    vstore<T, V>(a.x_out + off, xo);
     return acc;
 }
 
@@ -666,13 +710,14 @@ template <int S> __device__ __forceinline__ bool is_fix_plane(const DG& g, int z
 //   CLS 1  chunk-edge planes, the remaining rows: generic (tiles, m, plane-list) mapping
 //   CLS 2  the sparse column-edge vectors of the remaining rows on the remaining planes: one per thread
 // grid: CLS 0 (tiles_x * row groups, m, nz); CLS 1 (tiles_x * tiles_y, m, 2 * nchunks); CLS 2 (ceil(cands/256), m, nz)
-template <int S, int CLS, bool XW>
-__global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a, int zchunk, int zb, int zn, double* partials) {
+template <int S, int CLS, bool XW, typename T = float>
+__global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<T> w, FixupArgsT<T> a, int zchunk, int zb, int zn, double* partials) {
+    constexpr int V = 16 / (int)sizeof(T);
     // (central row groups are laid out like hybrid ones: both the top and the bottom row of every wave tile)
     // the call covers local planes [zb, zb + zn): classes 0 and 2 have grid z = zn; class 1 has two grid-z
     // slots (first / last plane) per z-chunk intersecting the range, starting at chunk a.chunk0
     __shared__ double sm[16];
-    const int nxv = g.nx / 4;
+    const int nxv = g.nx / V;
     const int tiles_x = (nxv + 63) / 64;
     double acc = 0.0;
     if (CLS == 0) {
@@ -682,9 +727,9 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
         // hybrid / central: first and last row of two consecutive wave tiles; up / down: one row of four tiles
         if (S == HYBRID || S == CENTRAL) y = grp * 2 * CP_TR + ((ty & 1) ? CP_TR - 1 : 0) + ((ty & 2) ? CP_TR : 0);
         else y = grp * 4 * CP_TR + CP_TR * ty + (S == DOWNWIND ? CP_TR - 1 : 0);
-        const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
+        const int col0 = (bx * 64 + (int)threadIdx.x) * V;
         if (col0 < g.nx && y < g.ny && is_fix_row<S>(g, y) && !is_seam_frame<S>(g, (int)blockIdx.y))
-            acc = fixup_site<S, XW>(g, w, a, zchunk, zb + (int)blockIdx.z, (int)blockIdx.y, y, col0);
+            acc = fixup_site<S, XW, T>(g, w, a, zchunk, zb + (int)blockIdx.z, (int)blockIdx.y, y, col0);
     } else if (CLS == 1) {
         const int k = (int)blockIdx.z, chunk = a.chunk0 + (k >> 1);
         const int zs = chunk * zchunk;
@@ -693,29 +738,29 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<float> w, FixupArgs a
         const bool dup = (k & 1) && (ze - 1 == zs);                      // one-plane chunk: handled as its "zs"
         const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
         const int y = by * 4 + (int)threadIdx.y;
-        const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
+        const int col0 = (bx * 64 + (int)threadIdx.x) * V;
         if (!dup && zs < g.nz && zl >= zb && zl < zb + zn && col0 < g.nx && y < g.ny && is_fix_plane<S>(g, zl, zchunk) &&
             !is_fix_row<S>(g, y) && !is_seam_frame<S>(g, (int)blockIdx.y))
-            acc = fixup_site<S, XW>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
+            acc = fixup_site<S, XW, T>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
     } else if (CLS == 3) {
         // time-window seam frames (M > CP_TWN): EVERY site of such a frame misses a time term; blockIdx.y counts
         // the seam frames: windows' first frames (up) and last frames (down), as 2 slots per window
         const int wdw = (int)blockIdx.y >> 1, t = wdw * CP_TWN + (((int)blockIdx.y & 1) ? CP_TWN - 1 : 0);
         const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
         const int y = by * 4 + (int)threadIdx.y;
-        const int col0 = (bx * 64 + (int)threadIdx.x) * 4;
+        const int col0 = (bx * 64 + (int)threadIdx.x) * V;
         if (t < g.m && col0 < g.nx && y < g.ny && is_seam_frame<S>(g, t))
-            acc = fixup_site<S, XW>(g, w, a, zchunk, zb + (int)blockIdx.z, t, y, col0);
+            acc = fixup_site<S, XW, T>(g, w, a, zchunk, zb + (int)blockIdx.z, t, y, col0);
     } else {
         // candidates per row: the first and the last vector of every block tile (XW) / wave tile
-        constexpr int TW = XW ? CP_BC : CP_WC;
+        constexpr int TW = XW ? CPG<V>::BC : CPG<V>::WC;
         const int ntile = (g.nx + TW - 1) / TW, ncand = 2 * ntile;
         const long long idx = (long long)blockIdx.x * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;
         const int zl = zb + (int)blockIdx.z;
         if (idx < (long long)g.ny * ncand && !is_fix_plane<S>(g, zl, zchunk) && !is_seam_frame<S>(g, (int)blockIdx.y)) {
             const int y = (int)(idx / ncand), cnd = (int)(idx % ncand);
-            const int col0 = (cnd >> 1) * TW + ((cnd & 1) ? TW - 4 : 0);
-            if (col0 < g.nx && !is_fix_row<S>(g, y)) acc = fixup_site<S, XW>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
+            const int col0 = (cnd >> 1) * TW + ((cnd & 1) ? TW - V : 0);
+            if (col0 < g.nx && !is_fix_row<S>(g, y)) acc = fixup_site<S, XW, T>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
         }
     }
     acc = block_sum(acc, sm);

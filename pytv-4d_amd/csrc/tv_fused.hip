@@ -6,6 +6,16 @@
 // every M <= 8 has its own instantiation; more frames run as time windows of CP_TWN = 8 frames (tv_fused.h)
 static bool fused_m_ok(int m) { return m >= 1; }
 
+// fp64 instantiations live in their own translation unit (tv_fused_f64.hip) so that the two compile in parallel
+namespace tvm {
+int cp_fused_f64(const tv_geom* g, const DG& d, const LC& lc, hipStream_t st, const void* x_in, const void* x_prev, const void* x_next, void* q,
+                 const void* x0, void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int zc, int chunk0, bool xw,
+                 bool force_win, double* w0, double* w1);
+int cp_fixup_f64(const tv_geom* g, const DG& d, hipStream_t st, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
+                 double tau, int chunk_lo, int zc, int zb, int zn, bool xw, dim3 g0, dim3 g1, dim3 g2, dim3 g3, long long n0, long long n1,
+                 long long n2, long long n3, double* w0);
+}
+
 template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
 #define TV_CASE_F(SC)                                              \
     case SC:                                                       \
@@ -34,7 +44,7 @@ template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
 static int fused_zchunk(const DG& d) {
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
-        const long long tiles = (long long)((d.nx / 4 + CP_NW * CP_TL - 1) / (CP_NW * CP_TL)) * ((d.ny + CP_TR - 1) / CP_TR);
+        const long long tiles = (long long)((d.nx / d.vl + CP_NW * CP_TL - 1) / (CP_NW * CP_TL)) * ((d.ny + CP_TR - 1) / CP_TR);
         const long long want = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);
         zc = (int)(d.nz / (want > 0 ? want : 1));
         if (zc > 32) zc = 32;
@@ -73,9 +83,9 @@ extern "C" {
 int tv_cp_fused_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
-    if (g->dtype != TV_F32 || d.nx % 4 != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;
+    if (d.nx % d.vl != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;          // fp32, and fp64 since round 3 (2 columns per lane)
     if (d.m > CP_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
-    if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
+    if ((long long)d.ny * d.nx * (16 / d.vl) > (1ll << 32)) return 0;         // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_FUSED", 0)) return 0;
     return 1;
 }
@@ -107,7 +117,7 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     }
     LC lc = march_cfg(d, zc);
     {   // block tile of the sweep: CP_TR rows x CP_BC columns (tv_fused.h)
-        const long long tx = (d.nx / 4 + CP_NW * CP_TL - 1) / (CP_NW * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
+        const long long tx = (d.nx / d.vl + CP_NW * CP_TL - 1) / (CP_NW * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
         lc.grid.x = (unsigned)(tx * ty);
         lc.block = dim3(64, CP_NW, 1);
         lc.nblocks = tx * ty * lc.grid.y;
@@ -128,23 +138,26 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     const int chunk0 = (int)chunk_begin;
     double* w0 = (double*)ws;
     double* w1 = w0 + nmax + kStage + 16;
-    FusedArgs a{(const float*)x_in, (const float*)x_prev, (const float*)x_next, (float*)q, (const float*)x0, (float*)p,
-                (float*)x_out, (float)sigma_D, (float)(1.0 / lambda), (float)tau, (float)sigma_A,
-                (float)(1.0 / (1.0 + sigma_A)), w0, w1};
     const bool xw = env_int("TV_FUSED_XW", 1) != 0;
     // M == 8, hybrid: the windowed instantiation (one window) needs 234 VGPRs and no scratch where the plain one sits at
     // 256 + 8 B/lane, and is 1 ms faster per sweep on the north-star volume (33.7 vs 34.8 ms); the other schemes are
     // 2 % faster with the plain one (measured).  TV_FUSED_FORCE_TWIN=0/1 overrides.
     const bool force_win = (d.m == CP_TWN) && env_int("TV_FUSED_FORCE_TWIN", g->scheme == TV_HYBRID ? 1 : 0);
-    int rc = dispatch_fused(g->scheme, (d.m > CP_TWN || force_win) ? 0 : d.m, [&]<int S, int M>() -> int {
-        if constexpr (M == 0) {          // M > 8: windows of 8 frames
-            if (xw) hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, true, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
-            else hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, false, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
-        } else if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
-        else hipLaunchKernelGGL((k_cp_fused<S, M, false>), lc.grid, lc.block, 0, st, d, make_w<float>(g), a, zc, chunk0);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    });
+    auto sweep = [&]<typename T>() -> int {
+        FusedArgsT<T> a{(const T*)x_in, (const T*)x_prev, (const T*)x_next, (T*)q, (const T*)x0, (T*)p,
+                        (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)), w0, w1};
+        return dispatch_fused(g->scheme, (d.m > CP_TWN || force_win) ? 0 : d.m, [&]<int S, int M>() -> int {
+            if constexpr (M == 0) {          // M > 8: windows of 8 frames
+                if (xw) hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, true, true, T>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
+                else hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, false, true, T>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
+            } else if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true, false, T>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
+            else hipLaunchKernelGGL((k_cp_fused<S, M, false, false, T>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        });
+    };
+    const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : tvm::cp_fused_f64(g, d, lc, st, x_in, x_prev, x_next, q, x0, p, x_out,
+                                                                                             sigma_D, lambda, tau, sigma_A, zc, chunk0, xw, force_win, w0, w1);
     if (rc) return rc;
     if (int r2 = reduce_partials(w0, lc.nblocks, nmax, tvout, st)) return r2;
     return reduce_partials(w1, lc.nblocks, nmax, fid, st);
@@ -169,12 +182,12 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     if (int rc = check_y_halos(g, d, (z_begin == 0) ? q_prev : q, (z_begin + z_count == d.nz) ? q_next : q)) return rc;
     const int zb = (int)z_begin, zn = (int)z_count;
     const int chunk_lo = zb / zc, chunk_hi = (zb + zn - 1) / zc;           // chunks intersecting the plane range
-    FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau, chunk_lo};
-    const long long tiles_x = (d.nx / 4 + 63) / 64, tiles_y = (d.ny + 3) / 4;
+    const long long tiles_x = (d.nx / d.vl + 63) / 64, tiles_y = (d.ny + 3) / 4;
     const long long ngrp = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL) ? (d.ny + 2 * CP_TR - 1) / (2 * CP_TR)
                                                                                 : (d.ny + 4 * CP_TR - 1) / (4 * CP_TR);
     const bool xw = env_int("TV_FUSED_XW", 1) != 0;
-    const long long ncand = xw ? 2ll * ((d.nx + CP_BC - 1) / CP_BC) : 2ll * ((d.nx + CP_WC - 1) / CP_WC);
+    const long long bc = (long long)CP_NW * CP_TL * d.vl, wc = (long long)CP_TL * d.vl;      // block / wave tile width in columns
+    const long long ncand = xw ? 2ll * ((d.nx + bc - 1) / bc) : 2ll * ((d.nx + wc - 1) / wc);
     const dim3 blk(64, 4, 1);
     const dim3 g0((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)zn);
     const dim3 g1((unsigned)(tiles_x * tiles_y), (unsigned)d.m, (unsigned)(2 * (chunk_hi - chunk_lo + 1)));
@@ -185,6 +198,11 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
                     n2 = (long long)g2.x * g2.y * g2.z, n3 = nwin > 0 ? (long long)g3.x * g3.y * g3.z : 0;
     if (n0 + n1 + n2 + n3 > nmax) return fail(TV_E_ARG, "internal: fix-up partials exceed the workspace");
     double* w0 = (double*)ws;
+    if (g->dtype == TV_F64) {
+        if (int rc64 = tvm::cp_fixup_f64(g, d, st, q, q_prev, q_next, x_out, x0, tau, chunk_lo, zc, zb, zn, xw, g0, g1, g2, g3, n0, n1, n2, n3, w0)) return rc64;
+        return reduce_partials(w0, n0 + n1 + n2 + n3, nmax, fid, st);
+    }
+    FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau, chunk_lo};
     auto launch = [&]<int S, bool XW>() -> int {
         hipLaunchKernelGGL((k_cp_fixup<S, 0, XW>), g0, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0);
         if (d.za) hipLaunchKernelGGL((k_cp_fixup<S, 1, XW>), g1, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0);

@@ -57,6 +57,7 @@ inline int make_dg(const tv_geom* g, DG& d) {
     d.nd = per * (2 + d.za + d.ta);
     d.ch_z = 2 * per;
     d.ch_t = d.ch_z + (d.za ? per : 0);
+    d.vl = (g->dtype == TV_F32) ? 4 : 2;
     d.z_two = (g->scheme == TV_CENTRAL && g->nz_global == 2) ? 1 : 0;
     d.t_two = (g->scheme == TV_CENTRAL && g->m == 2) ? 1 : 0;
     d.s_t = (long long)g->ny * g->nx;
@@ -100,7 +101,7 @@ inline long long max_partials(const DG& d) {
     LC lc = launch_cfg(d, 1, d.nz + 2);
     // the one-sweep fix-up launches up to four classes whose block counts add up to ~3 x (256-column tiles) x (4-row
     // groups) x m x nz when the z-chunks are short and the frame is narrow: bound them explicitly
-    const long long tiles = (long long)((d.nx / 4 + 63) / 64 + 1) * ((d.ny + 3) / 4 + 1);
+    const long long tiles = (long long)((d.nx / (d.vl > 0 ? d.vl : 4) + 63) / 64 + 1) * ((d.ny + 3) / 4 + 1);
     long long n = 4 * tiles * (d.m + 2) * (d.nz + 2) + 4096;
     if (lc.nblocks > n) n = lc.nblocks;
     return n > kFlatBlocks ? n : kFlatBlocks;

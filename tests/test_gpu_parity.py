@@ -215,10 +215,12 @@ FUSED_SHAPES = [(1, 1, 64, 64), (5, 1, 9, 64), (6, 2, 7, 68), (7, 3, 10, 256), (
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("zchunk,xw", [("2", "1"), ("16", "1"), ("0", "0"), ("3", "0")])
-def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, tvopt):
+def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, dtype, tvopt):
     """tv_cp_fused + tv_cp_fixup (q read/written once) against tv_cp_dual + tv_cp_primal and the oracle:
-    ragged rows (Ny % 4 != 0), partial wave tiles (Nx % 64 != 0), chunk edges inside the volume."""
+    ragged rows (Ny % 4 != 0), partial wave tiles (Nx % 64 != 0), chunk edges inside the volume.
+    Round 3: also in fp64 (2 columns per lane: the wave / block tiles are half as wide in columns), to 1e-10."""
     import torch
     from pytv import _native as nv
     tvopt("TV_ZCHUNK", zchunk)          # "0" = the library's own choice
@@ -228,24 +230,27 @@ def test_one_sweep_cp_equals_two_kernel_cp_and_oracle(pytv, scheme, zchunk, xw, 
         for lz, mu, use_mask in ((1.0, 1.0, False), (0.0, 0.6, True), (2.5, 0.0, False)):
             mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
             kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=3.0 if use_mask else 0)
-            x0 = (50.0 * rng.random(shape)).astype(np.float32)
-            a = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 5.0, scheme=scheme, **kw)
+            x0 = (50.0 * rng.random(shape)).astype(dtype)
+            a = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 5.0, scheme=scheme, fused=True, **kw)
             b = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 5.0, scheme=scheme, fused=False, **kw)
             assert a.fused and not b.fused
             la, lb = a.run(9), b.run(9)
             wx, wloss = orc.chambolle_pock(x0.astype(np.float64), 9, 5.0, scheme=scheme, **kw)
             msg = "%s %s %s" % (scheme, shape, (lz, mu, use_mask))
-            np.testing.assert_allclose(la, wloss, rtol=1e-5, err_msg=msg)
-            np.testing.assert_allclose(la, lb, rtol=2e-6, err_msg=msg)
-            np.testing.assert_allclose(a.result().cpu().numpy(), wx, rtol=1e-5, atol=1e-3, err_msg=msg)
-            np.testing.assert_allclose(a.q.cpu().numpy(), b.q.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
-            np.testing.assert_allclose(a.p.cpu().numpy(), b.p.cpu().numpy(), rtol=1e-5, atol=1e-4, err_msg=msg)
+            f32 = dtype == np.float32
+            np.testing.assert_allclose(la, wloss, rtol=1e-5 if f32 else 1e-11, err_msg=msg)
+            np.testing.assert_allclose(la, lb, rtol=2e-6 if f32 else 1e-12, err_msg=msg)
+            np.testing.assert_allclose(a.result().cpu().numpy(), wx, rtol=1e-5 if f32 else 1e-10, atol=1e-3 if f32 else 1e-9, err_msg=msg)
+            np.testing.assert_allclose(a.q.cpu().numpy(), b.q.cpu().numpy(), rtol=1e-5 if f32 else 1e-10, atol=1e-4 if f32 else 1e-10, err_msg=msg)
+            np.testing.assert_allclose(a.p.cpu().numpy(), b.p.cpu().numpy(), rtol=1e-5 if f32 else 1e-10, atol=1e-4 if f32 else 1e-10, err_msg=msg)
     g = nv.Geometry((4, 9, 8, 64), "hybrid", torch.float32, "cuda")
     assert nv.lib().tv_cp_fused_supported(g.ref) == 1          # M > 8 runs as time windows of 8 frames
     g = nv.Geometry((4, 4, 8, 32), "hybrid", torch.float32, "cuda")
     assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # Nx < 64
     g = nv.Geometry((4, 4, 8, 64), "central", torch.float64, "cuda")
-    assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # fp32 only
+    assert nv.lib().tv_cp_fused_supported(g.ref) == 1          # fp64: since round 3
+    g = nv.Geometry((4, 4, 8, 65), "central", torch.float64, "cuda")
+    assert nv.lib().tv_cp_fused_supported(g.ref) == 0          # ragged Nx
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)

@@ -6,7 +6,7 @@ shape = (64, 8, 1024, 1024)
 x0 = synth_slab(shape, 0, shape[0], torch.device("cuda", 0))
 for dt in (torch.float32, torch.float64):
     xx = x0.to(dt)
-    for fused in ((None, False) if dt == torch.float32 else (False,)):
+    for fused in (True, False):
         cp = pytv.solvers.ChambollePock(xx, 25.0, reg_time=1.0, fused=fused)
         for _ in range(2): cp.step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
