@@ -55,6 +55,46 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> vload(const T*
 template <typename T, int V> __device__ __forceinline__ void vstore(T* p, const Vec<T, V>& a) {
     *reinterpret_cast<Vec<T, V>*>(p) = a;
 }
+// Streamed-once arrays of the epilogues: non-temporal loads AND stores (mixing nt loads with plain stores
+// is slower than either, tools/bwtest3.hip).  Which epilogue uses them was settled by A/B on the device
+// (profiles/r3_epi_nt_ab.txt): CpPrimal and AxpyDT gain 4-8 %, CpDual gains for central and loses for the
+// 8-channel schemes, StoreDT / AdmmZU lose up to 30 % for central, StoreD is neutral.
+#ifndef TV_EPI_NT
+#define TV_EPI_NT 1
+#endif
+template <typename T, int V, bool NT = true> __device__ __forceinline__ Vec<T, V> vload_s(const T* p) {
+#if TV_EPI_NT
+    if constexpr (!NT) return vload<T, V>(p);
+    else if constexpr (V == 1) {
+        Vec<T, V> r; r.v[0] = __builtin_nontemporal_load(p); return r;
+    } else {
+        typedef T nt_v __attribute__((ext_vector_type(V)));
+        const nt_v v = __builtin_nontemporal_load(reinterpret_cast<const nt_v*>(p));
+        Vec<T, V> r;
+#pragma unroll
+        for (int i = 0; i < V; ++i) r.v[i] = v[i];
+        return r;
+    }
+#else
+    return vload<T, V>(p);
+#endif
+}
+template <typename T, int V, bool NT = true> __device__ __forceinline__ void vstore_s(T* p, const Vec<T, V>& a) {
+#if TV_EPI_NT
+    if constexpr (!NT) vstore<T, V>(p, a);
+    else if constexpr (V == 1) {
+        __builtin_nontemporal_store(a.v[0], p);
+    } else {
+        typedef T nt_v __attribute__((ext_vector_type(V)));
+        nt_v w;
+#pragma unroll
+        for (int i = 0; i < V; ++i) w[i] = a.v[i];
+        __builtin_nontemporal_store(w, reinterpret_cast<nt_v*>(p));
+    }
+#else
+    vstore<T, V>(p, a);
+#endif
+}
 template <typename T, int V> __device__ __forceinline__ Vec<T, V> vsplat(T s) {
     Vec<T, V> r;
 #pragma unroll

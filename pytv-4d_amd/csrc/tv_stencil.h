@@ -194,7 +194,7 @@ template <int S, typename T, int V> struct CpDual {
         Vec<T, V> vs = vsplat<T, V>(T(0));
         for_each_channel<S>(g, [&](auto slot, int ch) {
             constexpr int k = decltype(slot)::value;
-            v[k] = vload<T, V>(base + (long long)ch * g.s_z) + sigma * o[k];
+            v[k] = vload_s<T, V, S == CENTRAL>(base + (long long)ch * g.s_z) + sigma * o[k];
             vs = vs + v[k] * v[k];
         });
         const Vec<T, V> ds = sumsq_slots<T, V>(o);
@@ -207,7 +207,7 @@ template <int S, typename T, int V> struct CpDual {
         }
         for_each_channel<S>(g, [&](auto slot, int ch) {
             constexpr int k = decltype(slot)::value;
-            vstore<T, V>(base + (long long)ch * g.s_z, v[k] * scale);
+            vstore_s<T, V, S == CENTRAL>(base + (long long)ch * g.s_z, v[k] * scale);
         });
         return acc;
     }
@@ -382,9 +382,9 @@ template <typename T, int V> struct AxpyDT {     // out = base + beta * base2 + 
     const T* base2 = nullptr;       // tv_DT_axpy2: the primal step of Chambolle-Pock with a data-fidelity operator,
     T beta = T(0);                  // x - tau A^T p - tau D^T q in one pass (base = x, base2 = A^T p, beta = alpha = -tau)
     __device__ __forceinline__ double operator()(long long off, const Vec<T, V>& r) const {
-        Vec<T, V> b = (base != nullptr) ? vload<T, V>(base + off) : vsplat<T, V>(T(0));
-        if (base2 != nullptr) b = b + beta * vload<T, V>(base2 + off);
-        vstore<T, V>(out + off, b + alpha * r);
+        Vec<T, V> b = (base != nullptr) ? vload_s<T, V>(base + off) : vsplat<T, V>(T(0));
+        if (base2 != nullptr) b = b + beta * vload_s<T, V>(base2 + off);
+        vstore_s<T, V>(out + off, b + alpha * r);
         return 0.0;
     }
 };
@@ -397,7 +397,7 @@ template <typename T, int V> struct CpPrimal {
     T tau, sigma_a, inv_1p_sigma_a;
     double* partials;
     __device__ __forceinline__ double operator()(long long off, const Vec<T, V>& r) const {
-        const Vec<T, V> xv = vload<T, V>(x + off), x0v = vload<T, V>(x0 + off), pv = vload<T, V>(p + off);
+        const Vec<T, V> xv = vload_s<T, V>(x + off), x0v = vload_s<T, V>(x0 + off), pv = vload_s<T, V>(p + off);
         Vec<T, V> pn, xn;
         double acc = 0.0;
 #pragma unroll
@@ -407,8 +407,8 @@ template <typename T, int V> struct CpPrimal {
             const double e = (double)xn.v[i] - (double)x0v.v[i];
             acc += 0.5 * e * e;
         }
-        vstore<T, V>(p + off, pn);
-        vstore<T, V>(x + off, xn);
+        vstore_s<T, V>(p + off, pn);
+        vstore_s<T, V>(x + off, xn);
         return acc;
     }
 };

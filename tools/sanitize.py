@@ -17,7 +17,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pytv-4d_amd", "csrc")
-UNITS = ["tv_kernels", "tv_march_D", "tv_march_DT", "tv_fused", "tv_subgrad", "tv_sgstep", "tv_dstream", "tv_comm", "tv_nstream"]
+sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd"))
+import build as _product_build  # noqa: E402  (the product's own unit list, so that the two cannot drift)
+UNITS = [u[:-len(".hip")] for u in _product_build.UNITS]
 SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-g", "-O1"]
 
 
