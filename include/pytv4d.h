@@ -189,6 +189,22 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
 /* v = D x + u; z = v * max(0, 1 - thresh/|v|_2); u = v - z; *tv (device fp64) = |D x|_{2,1}. */
 int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* z, void* u,
                double thresh, double* tv, void* ws, void* stream);
+/* One-sweep form of the outer iteration's dual side (round 3; same geometries as tv_cp_fused: tv_cp_fused_supported):
+ * the z / u update AND the residual the next x-solve starts from, from one pass over u --
+ *   v = D x + u;  z = v * max(0, 1 - thresh/|v|_2);  u <- v - z (in place);  t' = (z - u) - D x;
+ *   r <- (x0 - x) + rho D^T t'  =  [x0 + rho D^T (z - u)] - (I + rho D^T D) x
+ *   *tv = |D x|_{2,1};  *rr = <r, r> over the sites that are already complete (device fp64, local planes)
+ * EXCEPT, exactly as in tv_cp_fused, the adjoint terms that cross a wave tile, a z-chunk, a time window or the slab:
+ * tv_admm_fixup adds those to r (t_prev / t_next: halo planes of t' as y_prev / y_next in tv_DT) and returns <r, r> of
+ * the sites it completed; total = sum of the two.  t (same shape as u) receives t': every sample if full_store != 0
+ * (then z = t' + u + D x), otherwise only the samples the fix-up and the neighbouring ranks read (the rest of the array is
+ * left untouched).  2 Nd + 3 words per voxel where tv_admm_tu + tv_DT_axpy + tv_normal_op2(b) move 4 Nd + 6.
+ * Chunk / plane ranges as in tv_cp_fused / tv_cp_fixup.  Replaces: nothing in the reference (README.md:26,135 name ADMM only). */
+int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* u, void* t, const void* x0, void* r,
+                  double thresh, double rho, int32_t full_store, int64_t chunk_begin, int64_t chunk_count, double* tv, double* rr,
+                  void* ws, void* stream);
+int tv_admm_fixup(const tv_geom* g, const void* t, const void* t_prev, const void* t_next, void* r, double rho, int64_t z_begin,
+                  int64_t z_count, double* rr, void* ws, void* stream);
 /* out = base + alpha * D^T (a - b)   (b and/or base may be NULL).  ab_prev / ab_next: halo planes
  * of (a - b) for the channels named in tv_DT. */
 int tv_DT_axpy2(const tv_geom* g, const void* a, const void* b, const void* ab_prev, const void* ab_next,

@@ -254,15 +254,27 @@ template <typename T> struct FusedArgsT {
     T sigma, inv_lambda, tau, sigma_a, inv_1p_sigma_a;
     double* part_tv;
     double* part_fid;
+    int full_store;       // ALG_ADMM: 1 = every sample of t' is stored (z stays recoverable), 0 = only what the fix-up reads
 };
 using FusedArgs = FusedArgsT<float>;
+
+// ALG: which inner loop the sweep runs.
+//   ALG_CP   (README.md:141-157): q <- proj(q + sigma D x); p, x updated one plane behind; partials: TV, 1/2 |x_out - x0|^2.
+//   ALG_ADMM (round 3): the z / u update of scaled-form ADMM and the residual of the NEXT x-solve in one pass:
+//            v = D x + u;  z = shrink(v, thresh);  u <- v - z  (in place, the array passed as `q`);  t' = (z - u) - D x;
+//            r = (x0 - x) + rho D^T t'  =  [x0 + rho D^T (z - u)] - (I + rho D^T D) x          (one plane behind, array `x_out`)
+//            partials: TV(x), <r, r>.  Arguments reused: sigma = thresh = reg / rho, tau = rho, p = the array t' goes to (same
+//            layout as q).  Nobody but the fix-up reads t', so by default only the samples the fix-up needs are stored
+//            (tile-edge rows / columns, chunk-edge planes, window-seam frames: ~0.3 words per voxel instead of Nd);
+//            4 Nd + 6 words per voxel of the kernel trio tv_admm_tu + tv_DT_axpy + tv_normal_op2(rhs) become 2 Nd + 3.
+constexpr int ALG_CP = 0, ALG_ADMM = 1;
 
 // XW: the CP_NW waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
 // TWIN: time windows for volumes with more than CP_TWN frames -- grid z = window, the block works on the frames
 // [t0, t0 + M) of the volume (M = CP_TWN), reads x of the frame on either side of its window for the time differences
 // and leaves the adjoint terms that cross a window seam to the fix-up (exactly like the z-chunk edges)
 // T: float (4 columns per 16-byte lane) or double (2 columns, round 3): the same tile in lanes, half as wide in columns.
-template <int S, int M, bool XW, bool TWIN = false, typename T = float>
+template <int S, int M, bool XW, bool TWIN = false, typename T = float, int ALG = ALG_CP>
 __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, FusedArgsT<T> a, int zchunk, int chunk0) {
     constexpr int V = 16 / (int)sizeof(T);
     using VT = Vec<T, V>;
@@ -364,6 +376,19 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
             if (DN && c.lx == CP_TL - 1 && wave < CP_NW - 1) racc.v[V - 1] -= edge_cd[eb][t][wave + 1][c.row];
         }
         const long long foff = (long long)zf * g.s_z + (long long)(t0 + t) * g.s_t;      // uniform
+        if constexpr (ALG == ALG_ADMM) {      // r = (x0 - x) + rho D^T t'
+            const VT x0v = ldu_s_t<T, V>(a.x0 + foff, voff);
+            VT ro;
+            double r2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                ro.v[i] = (x0v.v[i] - xv.v[i]) + a.tau * (s * racc.v[i]);
+                r2 += (double)ro.v[i] * (double)ro.v[i];
+            }
+            stu_s_t<T, V>(a.x_out + foff, voff, ro);
+            if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += r2;
+            return;
+        }
         const VT x0v = ldu_s_t<T, V>(a.x0 + foff, voff), pv = ldu_s_t<T, V>(a.p + foff, voff);
         VT pn, xo;
         double e2 = 0.0;
@@ -511,21 +536,50 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
                     const VT qv = PFQ ? qcur[k & 3] : ldu_s_t<T, V>(qbase + (long long)ch * g.s_z, voff);
-                    v[k] = qv + a.sigma * o[k];
+                    v[k] = (ALG == ALG_ADMM) ? o[k] + qv : qv + a.sigma * o[k];
                     vs = vs + v[k] * v[k];
                 });
                 const VT ds = sumsq_slots<T, V>(o);
                 VT scale;
+                if constexpr (ALG == ALG_ADMM) {
+                    // group soft threshold, the arithmetic of AdmmZU (tv_stencil.h): z = v scale, u = v - z, t = z - u
 #pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    acc_tv += (double)tsqrt(ds.v[i]);
-                    scale.v[i] = T(1) / tmax(T(1), tsqrt(vs.v[i]) * a.inv_lambda);
+                    for (int i = 0; i < V; ++i) {
+                        acc_tv += (double)tsqrt(ds.v[i]);
+                        const T nv = tsqrt(vs.v[i]);
+                        scale.v[i] = (nv > T(0)) ? tmax(T(0), T(1) - a.sigma / nv) : T(0);
+                    }
+                    // which samples of t' the fix-up will read (k_cp_fixup): the row channels on the rows next to a wave-tile
+                    // seam, the column channels on the vectors next to a block-tile seam, the z channels on chunk-edge planes, the
+                    // time channels on window-seam frames
+                    const bool lastv = (c.lx == CP_TL - 1) && (!XW || wave == CP_NW - 1), firstv = (c.lx == 0) && (!XW || wave == 0);
+                    const bool st_u[4] = {UP && c.row == CP_TR - 1, UP && lastv, UP && z == c.ze - 1, UP && TWIN && (t == M - 1 || tg + 1 >= Mg)};
+                    const bool st_d[4] = {DN && c.row == 0, DN && firstv, DN && z == c.zs, DN && TWIN && t == 0};
+                    T* tbase = a.p + (long long)z * g.s_dz + toff;
+                    for_each_channel<S>(g, [&](auto slot, int ch) {
+                        constexpr int k = decltype(slot)::value;
+                        const VT zz = v[k] * scale;
+                        const VT un = v[k] - zz;
+                        stu_s_t<T, V>(qbase + (long long)ch * g.s_z, voff, un);
+                        v[k] = (zz - un) - o[k];                                     // t': what the adjoint below is taken of
+                        constexpr int axis = (S == HYBRID) ? ((k < 4) ? (k & 1) : (k >> 1)) : k;          // 0 rows, 1 cols, 2 z, 3 t
+                        constexpr bool up_role = (S != HYBRID) || (k == 0 || k == 1 || k == 4 || k == 6);
+                        constexpr bool dn_role = (S != HYBRID) || !up_role;
+                        if (a.full_store || (up_role && st_u[axis]) || (dn_role && st_d[axis]))
+                            stu_t<T, V>(tbase + (long long)ch * g.s_z, voff, v[k]);
+                    });
+                } else {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        acc_tv += (double)tsqrt(ds.v[i]);
+                        scale.v[i] = T(1) / tmax(T(1), tsqrt(vs.v[i]) * a.inv_lambda);
+                    }
+                    for_each_channel<S>(g, [&](auto slot, int ch) {
+                        constexpr int k = decltype(slot)::value;
+                        v[k] = v[k] * scale;
+                        stu_s_t<T, V>(qbase + (long long)ch * g.s_z, voff, v[k]);
+                    });
                 }
-                for_each_channel<S>(g, [&](auto slot, int ch) {
-                    constexpr int k = decltype(slot)::value;
-                    v[k] = v[k] * scale;
-                    stu_s_t<T, V>(qbase + (long long)ch * g.s_z, voff, v[k]);
-                });
             }
             // slots: non-hybrid 0 rows, 1 cols, 2 z, 3 t ; hybrid 0 ru, 1 cu, 2 rd, 3 cd, 4 zu, 5 zd, 6 tu, 7 td
             constexpr int k_ru = 0, k_cu = 1, k_rd = (S == HYBRID) ? 2 : 0, k_cd = (S == HYBRID) ? 3 : 1;
@@ -633,7 +687,8 @@ template <typename T> struct FixupArgsT {
 using FixupArgs = FixupArgsT<float>;
 
 // all missing terms of one site-vector; returns its fidelity 1/2 |x_out - x0|^2 (0 if nothing was missing)
-template <int S, bool XW, typename T = float>
+// ALG_ADMM: `q` is the array of t', `x_out` the residual r, tau = -rho (r += rho s m), the returned partial is r^2 (no x0)
+template <int S, bool XW, typename T = float, int ALG = ALG_CP>
 __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const FixupArgsT<T>& a, int zchunk, int zl, int t, int y,
                                              int col0) {
     constexpr int V = 16 / (int)sizeof(T);
@@ -677,14 +732,16 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const 
     }
     const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : (CEN ? T(0.5) : T(1));
     const long long off = (long long)zl * g.s_z + inpl;
-    const VT xv = vload<T, V>(a.x_out + off), x0v = vload<T, V>(a.x0 + off);
+    const VT xv = vload<T, V>(a.x_out + off);
+    VT x0v = zero;
+    if constexpr (ALG == ALG_CP) x0v = vload<T, V>(a.x0 + off);
     VT xo;
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         xo.v[i] = xv.v[i] - a.tau * (s * m.v[i]);
         const double e = (double)xo.v[i] - (double)x0v.v[i];
-        acc += 0.5 * e * e;
+        acc += (ALG == ALG_CP ? 0.5 : 1.0) * e * e;
     }
     vstore<T, V>(a.x_out + off, xo);
     return acc;
@@ -710,7 +767,7 @@ template <int S> __device__ __forceinline__ bool is_fix_plane(const DG& g, int z
 //   CLS 1  chunk-edge planes, the remaining rows: generic (tiles, m, plane-list) mapping
 //   CLS 2  the sparse column-edge vectors of the remaining rows on the remaining planes: one per thread
 // grid: CLS 0 (tiles_x * row groups, m, nz); CLS 1 (tiles_x * tiles_y, m, 2 * nchunks); CLS 2 (ceil(cands/256), m, nz)
-template <int S, int CLS, bool XW, typename T = float>
+template <int S, int CLS, bool XW, typename T = float, int ALG = ALG_CP>
 __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<T> w, FixupArgsT<T> a, int zchunk, int zb, int zn, double* partials) {
     constexpr int V = 16 / (int)sizeof(T);
     // (central row groups are laid out like hybrid ones: both the top and the bottom row of every wave tile)
@@ -729,7 +786,7 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<T> w, FixupArgsT<T> a
         else y = grp * 4 * CP_TR + CP_TR * ty + (S == DOWNWIND ? CP_TR - 1 : 0);
         const int col0 = (bx * 64 + (int)threadIdx.x) * V;
         if (col0 < g.nx && y < g.ny && is_fix_row<S>(g, y) && !is_seam_frame<S>(g, (int)blockIdx.y))
-            acc = fixup_site<S, XW, T>(g, w, a, zchunk, zb + (int)blockIdx.z, (int)blockIdx.y, y, col0);
+            acc = fixup_site<S, XW, T, ALG>(g, w, a, zchunk, zb + (int)blockIdx.z, (int)blockIdx.y, y, col0);
     } else if (CLS == 1) {
         const int k = (int)blockIdx.z, chunk = a.chunk0 + (k >> 1);
         const int zs = chunk * zchunk;
@@ -741,7 +798,7 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<T> w, FixupArgsT<T> a
         const int col0 = (bx * 64 + (int)threadIdx.x) * V;
         if (!dup && zs < g.nz && zl >= zb && zl < zb + zn && col0 < g.nx && y < g.ny && is_fix_plane<S>(g, zl, zchunk) &&
             !is_fix_row<S>(g, y) && !is_seam_frame<S>(g, (int)blockIdx.y))
-            acc = fixup_site<S, XW, T>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
+            acc = fixup_site<S, XW, T, ALG>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
     } else if (CLS == 3) {
         // time-window seam frames (M > CP_TWN): EVERY site of such a frame misses a time term; blockIdx.y counts
         // the seam frames: windows' first frames (up) and last frames (down), as 2 slots per window
@@ -750,7 +807,7 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<T> w, FixupArgsT<T> a
         const int y = by * 4 + (int)threadIdx.y;
         const int col0 = (bx * 64 + (int)threadIdx.x) * V;
         if (t < g.m && col0 < g.nx && y < g.ny && is_seam_frame<S>(g, t))
-            acc = fixup_site<S, XW, T>(g, w, a, zchunk, zb + (int)blockIdx.z, t, y, col0);
+            acc = fixup_site<S, XW, T, ALG>(g, w, a, zchunk, zb + (int)blockIdx.z, t, y, col0);
     } else {
         // candidates per row: the first and the last vector of every block tile (XW) / wave tile
         constexpr int TW = XW ? CPG<V>::BC : CPG<V>::WC;
@@ -760,7 +817,7 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<T> w, FixupArgsT<T> a
         if (idx < (long long)g.ny * ncand && !is_fix_plane<S>(g, zl, zchunk) && !is_seam_frame<S>(g, (int)blockIdx.y)) {
             const int y = (int)(idx / ncand), cnd = (int)(idx % ncand);
             const int col0 = (cnd >> 1) * TW + ((cnd & 1) ? TW - V : 0);
-            if (col0 < g.nx && !is_fix_row<S>(g, y)) acc = fixup_site<S, XW, T>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
+            if (col0 < g.nx && !is_fix_row<S>(g, y)) acc = fixup_site<S, XW, T, ALG>(g, w, a, zchunk, zl, (int)blockIdx.y, y, col0);
         }
     }
     acc = block_sum(acc, sm);

@@ -1,40 +1,10 @@
 // tv_fused.hip -- instantiations + C-ABI of the one-sweep Chambolle-Pock iteration (tv_fused.h).
-#include "tv_host.h"
-#include "tv_stencil.h"
-#include "tv_fused.h"
+#include "tv_fused_launch.h"
+
+TV_FUSED_INSTANTIATE(float, ALG_CP)
 
 // every M <= 8 has its own instantiation; more frames run as time windows of CP_TWN = 8 frames (tv_fused.h)
 static bool fused_m_ok(int m) { return m >= 1; }
-
-// fp64 instantiations live in their own translation unit (tv_fused_f64.hip) so that the two compile in parallel
-namespace tvm {
-int cp_fused_f64(const tv_geom* g, const DG& d, const LC& lc, hipStream_t st, const void* x_in, const void* x_prev, const void* x_next, void* q,
-                 const void* x0, void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int zc, int chunk0, bool xw,
-                 bool force_win, double* w0, double* w1);
-int cp_fixup_f64(const tv_geom* g, const DG& d, hipStream_t st, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
-                 double tau, int chunk_lo, int zc, int zb, int zn, bool xw, dim3 g0, dim3 g1, dim3 g2, dim3 g3, long long n0, long long n1,
-                 long long n2, long long n3, double* w0);
-}
-
-template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
-#define TV_CASE_F(SC)                                              \
-    case SC:                                                       \
-        switch (m) {                                               \
-            case 0: return f.template operator()<SC, 0>();         \
-            case 1: return f.template operator()<SC, 1>();         \
-            case 2: return f.template operator()<SC, 2>();         \
-            case 3: return f.template operator()<SC, 3>();         \
-            case 4: return f.template operator()<SC, 4>();         \
-            case 5: return f.template operator()<SC, 5>();         \
-            case 6: return f.template operator()<SC, 6>();         \
-            case 7: return f.template operator()<SC, 7>();         \
-            case 8: return f.template operator()<SC, 8>();         \
-        }                                                          \
-        break;
-    switch (scheme) { TV_CASE_F(0) TV_CASE_F(1) TV_CASE_F(2) TV_CASE_F(3) }
-#undef TV_CASE_F
-    return fail(TV_E_ARG, "unsupported (scheme, M) for the one-sweep path");
-}
 
 // planes per z-chunk of the one-sweep path (sweep, fix-up and the host's interior-first schedule share it): its blocks are
 // CP_TR rows x CP_BC columns, half as many per plane as the marching kernels' -- with march_zchunk's rule (round 1) BASELINE
@@ -78,6 +48,83 @@ int subgrad_pass2(const tv_geom* g, const DG& d, const void* x, const void* xp, 
 }
 }  // namespace tvm
 
+// launch geometry of a sweep over the chunks [chunk_begin, chunk_begin + chunk_count) (count < 0: all); empty: nothing to launch
+struct SweepPlan {
+    LC lc;
+    int zc, chunk0;
+    long long nmax;
+    bool xw, force_win;
+};
+static int sweep_plan(const tv_geom* g, const DG& d, const void* x_in, const void* x_prev, const void* x_next, int64_t chunk_begin,
+                      int64_t chunk_count, SweepPlan& sp, bool& empty) {
+    sp.nmax = max_partials(d);
+    sp.zc = fused_zchunk(d);
+    const int zc = sp.zc;
+    {   // halos are only needed by the chunks that touch the slab boundary
+        const long long nch_all = (d.nz + zc - 1) / zc;
+        const long long cb = (chunk_count < 0) ? 0 : chunk_begin, ce = (chunk_count < 0) ? nch_all : chunk_begin + chunk_count;
+        const bool first = (cb == 0 && ce > 0), last = (ce == nch_all && ce > cb);
+        if (int rc = check_x_halos(g, d, first ? x_prev : x_in, last ? x_next : x_in)) return rc;
+    }
+    LC& lc = sp.lc;
+    lc = march_cfg(d, zc);
+    {   // block tile of the sweep: CP_TR rows x CP_BC columns (tv_fused.h)
+        const long long tx = (d.nx / d.vl + CP_NW * CP_TL - 1) / (CP_NW * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
+        lc.grid.x = (unsigned)(tx * ty);
+        lc.block = dim3(64, CP_NW, 1);
+        lc.nblocks = tx * ty * lc.grid.y;
+    }
+    const long long nch = lc.grid.y;
+    if (chunk_count < 0) { chunk_begin = 0; chunk_count = nch; }
+    if (chunk_begin < 0 || chunk_begin + chunk_count > nch) return fail(TV_E_ARG, "chunk range outside the slab");
+    empty = (chunk_count == 0);
+    if (empty) return 0;
+    const int nwin = (d.m > CP_TWN) ? (d.m + CP_TWN - 1) / CP_TWN : 1;      // time windows (grid z)
+    lc.grid.y = (unsigned)chunk_count;
+    lc.grid.z = (unsigned)nwin;
+    lc.nblocks = (long long)lc.grid.x * chunk_count * nwin;
+    if (lc.nblocks > sp.nmax) return fail(TV_E_ARG, "internal: sweep partials exceed the workspace");
+    sp.chunk0 = (int)chunk_begin;
+    sp.xw = env_int("TV_FUSED_XW", 1) != 0;
+    // M == 8, hybrid: the windowed instantiation (one window) needs 234 VGPRs and no scratch where the plain one sits at
+    // 256 + 8 B/lane, and is 1 ms faster per sweep on the north-star volume (33.7 vs 34.8 ms); the other schemes are
+    // 2 % faster with the plain one (measured).  TV_FUSED_FORCE_TWIN=0/1 overrides.
+    sp.force_win = (d.m == CP_TWN) && env_int("TV_FUSED_FORCE_TWIN", g->scheme == TV_HYBRID ? 1 : 0);
+    return 0;
+}
+
+// launch geometry of the fix-up over the local planes [z_begin, z_begin + z_count) (count < 0: all)
+static int fixup_plan(const tv_geom* g, const DG& d, const void* q, const void* q_prev, const void* q_next, int64_t z_begin, int64_t z_count,
+                      FixPlan& fp, long long& nmax, bool& empty) {
+    nmax = max_partials(d);
+    const int zc = fused_zchunk(d);
+    if (z_count < 0) { z_begin = 0; z_count = d.nz; }
+    if (z_begin < 0 || z_begin + z_count > d.nz) return fail(TV_E_ARG, "plane range outside the slab");
+    empty = (z_count == 0);
+    if (empty) return 0;
+    if (int rc = check_y_halos(g, d, (z_begin == 0) ? q_prev : q, (z_begin + z_count == d.nz) ? q_next : q)) return rc;
+    const int zb = (int)z_begin, zn = (int)z_count;
+    const int chunk_lo = zb / zc, chunk_hi = (zb + zn - 1) / zc;           // chunks intersecting the plane range
+    const long long tiles_x = (d.nx / d.vl + 63) / 64, tiles_y = (d.ny + 3) / 4;
+    const long long ngrp = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL) ? (d.ny + 2 * CP_TR - 1) / (2 * CP_TR)
+                                                                                : (d.ny + 4 * CP_TR - 1) / (4 * CP_TR);
+    const bool xw = env_int("TV_FUSED_XW", 1) != 0;
+    const long long bc = (long long)CP_NW * CP_TL * d.vl, wc = (long long)CP_TL * d.vl;      // block / wave tile width in columns
+    const long long ncand = xw ? 2ll * ((d.nx + bc - 1) / bc) : 2ll * ((d.nx + wc - 1) / wc);
+    fp.g0 = dim3((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)zn);
+    fp.g1 = dim3((unsigned)(tiles_x * tiles_y), (unsigned)d.m, (unsigned)(2 * (chunk_hi - chunk_lo + 1)));
+    fp.g2 = dim3((unsigned)(((long long)d.ny * ncand + 255) / 256), (unsigned)d.m, (unsigned)zn);
+    const int nwin = (d.m > CP_TWN && d.ta) ? (d.m + CP_TWN - 1) / CP_TWN : 0;     // time-window seams (M > 8)
+    fp.g3 = dim3((unsigned)(tiles_x * tiles_y), (unsigned)(2 * (nwin > 0 ? nwin : 1)), (unsigned)zn);
+    fp.n0 = (long long)fp.g0.x * fp.g0.y * fp.g0.z;
+    fp.n1 = d.za ? (long long)fp.g1.x * fp.g1.y * fp.g1.z : 0;
+    fp.n2 = (long long)fp.g2.x * fp.g2.y * fp.g2.z;
+    fp.n3 = nwin > 0 ? (long long)fp.g3.x * fp.g3.y * fp.g3.z : 0;
+    if (fp.n0 + fp.n1 + fp.n2 + fp.n3 > nmax) return fail(TV_E_ARG, "internal: fix-up partials exceed the workspace");
+    fp.chunk_lo = chunk_lo; fp.zc = zc; fp.zb = zb; fp.zn = zn; fp.xw = xw;
+    return 0;
+}
+
 extern "C" {
 
 int tv_cp_fused_supported(const tv_geom* g) {
@@ -107,60 +154,25 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
     if (!aligned16({x_in, x_prev, x_next, q, x0, p, x_out, d.wv})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const long long nmax = max_partials(d);
-    const int zc = fused_zchunk(d);
-    {   // halos are only needed by the chunks that touch the slab boundary
-        const long long nch_all = (d.nz + zc - 1) / zc;
-        const long long cb = (chunk_count < 0) ? 0 : chunk_begin, ce = (chunk_count < 0) ? nch_all : chunk_begin + chunk_count;
-        const bool first = (cb == 0 && ce > 0), last = (ce == nch_all && ce > cb);
-        if (int rc = check_x_halos(g, d, first ? x_prev : (const void*)x_in, last ? x_next : (const void*)x_in)) return rc;
-    }
-    LC lc = march_cfg(d, zc);
-    {   // block tile of the sweep: CP_TR rows x CP_BC columns (tv_fused.h)
-        const long long tx = (d.nx / d.vl + CP_NW * CP_TL - 1) / (CP_NW * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
-        lc.grid.x = (unsigned)(tx * ty);
-        lc.block = dim3(64, CP_NW, 1);
-        lc.nblocks = tx * ty * lc.grid.y;
-    }
-    const long long nch = lc.grid.y;
-    if (chunk_count < 0) { chunk_begin = 0; chunk_count = nch; }
-    if (chunk_begin < 0 || chunk_begin + chunk_count > nch) return fail(TV_E_ARG, "chunk range outside the slab");
-    if (chunk_count == 0) {
+    SweepPlan sp;
+    bool empty = false;
+    if (int rc = sweep_plan(g, d, x_in, x_prev, x_next, chunk_begin, chunk_count, sp, empty)) return rc;
+    if (empty) {
         HIP_TRY(hipMemsetAsync(tvout, 0, sizeof(double), st));
         HIP_TRY(hipMemsetAsync(fid, 0, sizeof(double), st));
         return 0;
     }
-    const int nwin = (d.m > CP_TWN) ? (d.m + CP_TWN - 1) / CP_TWN : 1;      // time windows (grid z)
-    lc.grid.y = (unsigned)chunk_count;
-    lc.grid.z = (unsigned)nwin;
-    lc.nblocks = (long long)lc.grid.x * chunk_count * nwin;
-    if (lc.nblocks > nmax) return fail(TV_E_ARG, "internal: sweep partials exceed the workspace");
-    const int chunk0 = (int)chunk_begin;
     double* w0 = (double*)ws;
-    double* w1 = w0 + nmax + kStage + 16;
-    const bool xw = env_int("TV_FUSED_XW", 1) != 0;
-    // M == 8, hybrid: the windowed instantiation (one window) needs 234 VGPRs and no scratch where the plain one sits at
-    // 256 + 8 B/lane, and is 1 ms faster per sweep on the north-star volume (33.7 vs 34.8 ms); the other schemes are
-    // 2 % faster with the plain one (measured).  TV_FUSED_FORCE_TWIN=0/1 overrides.
-    const bool force_win = (d.m == CP_TWN) && env_int("TV_FUSED_FORCE_TWIN", g->scheme == TV_HYBRID ? 1 : 0);
+    double* w1 = w0 + sp.nmax + kStage + 16;
     auto sweep = [&]<typename T>() -> int {
         FusedArgsT<T> a{(const T*)x_in, (const T*)x_prev, (const T*)x_next, (T*)q, (const T*)x0, (T*)p,
-                        (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)), w0, w1};
-        return dispatch_fused(g->scheme, (d.m > CP_TWN || force_win) ? 0 : d.m, [&]<int S, int M>() -> int {
-            if constexpr (M == 0) {          // M > 8: windows of 8 frames
-                if (xw) hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, true, true, T>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
-                else hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, false, true, T>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
-            } else if (xw) hipLaunchKernelGGL((k_cp_fused<S, M, true, false, T>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
-            else hipLaunchKernelGGL((k_cp_fused<S, M, false, false, T>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        });
+                        (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)), w0, w1, 0};
+        return tvm::fused_sweep<T, ALG_CP>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
     };
-    const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : tvm::cp_fused_f64(g, d, lc, st, x_in, x_prev, x_next, q, x0, p, x_out,
-                                                                                             sigma_D, lambda, tau, sigma_A, zc, chunk0, xw, force_win, w0, w1);
+    const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();
     if (rc) return rc;
-    if (int r2 = reduce_partials(w0, lc.nblocks, nmax, tvout, st)) return r2;
-    return reduce_partials(w1, lc.nblocks, nmax, fid, st);
+    if (int r2 = reduce_partials(w0, sp.lc.nblocks, sp.nmax, tvout, st)) return r2;
+    return reduce_partials(w1, sp.lc.nblocks, sp.nmax, fid, st);
 }
 
 int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
@@ -171,55 +183,81 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
     if (!aligned16({q, q_prev, q_next, x_out, x0})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const long long nmax = max_partials(d);
-    const int zc = fused_zchunk(d);
-    if (z_count < 0) { z_begin = 0; z_count = d.nz; }
-    if (z_begin < 0 || z_begin + z_count > d.nz) return fail(TV_E_ARG, "plane range outside the slab");
-    if (z_count == 0) {
+    FixPlan fp;
+    long long nmax = 0;
+    bool empty = false;
+    if (int rc = fixup_plan(g, d, q, q_prev, q_next, z_begin, z_count, fp, nmax, empty)) return rc;
+    if (empty) {
         HIP_TRY(hipMemsetAsync(fid, 0, sizeof(double), st));
         return 0;
     }
-    if (int rc = check_y_halos(g, d, (z_begin == 0) ? q_prev : q, (z_begin + z_count == d.nz) ? q_next : q)) return rc;
-    const int zb = (int)z_begin, zn = (int)z_count;
-    const int chunk_lo = zb / zc, chunk_hi = (zb + zn - 1) / zc;           // chunks intersecting the plane range
-    const long long tiles_x = (d.nx / d.vl + 63) / 64, tiles_y = (d.ny + 3) / 4;
-    const long long ngrp = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL) ? (d.ny + 2 * CP_TR - 1) / (2 * CP_TR)
-                                                                                : (d.ny + 4 * CP_TR - 1) / (4 * CP_TR);
-    const bool xw = env_int("TV_FUSED_XW", 1) != 0;
-    const long long bc = (long long)CP_NW * CP_TL * d.vl, wc = (long long)CP_TL * d.vl;      // block / wave tile width in columns
-    const long long ncand = xw ? 2ll * ((d.nx + bc - 1) / bc) : 2ll * ((d.nx + wc - 1) / wc);
-    const dim3 blk(64, 4, 1);
-    const dim3 g0((unsigned)(tiles_x * ngrp), (unsigned)d.m, (unsigned)zn);
-    const dim3 g1((unsigned)(tiles_x * tiles_y), (unsigned)d.m, (unsigned)(2 * (chunk_hi - chunk_lo + 1)));
-    const dim3 g2((unsigned)(((long long)d.ny * ncand + 255) / 256), (unsigned)d.m, (unsigned)zn);
-    const int nwin = (d.m > CP_TWN && d.ta) ? (d.m + CP_TWN - 1) / CP_TWN : 0;     // time-window seams (M > 8)
-    const dim3 g3((unsigned)(tiles_x * tiles_y), (unsigned)(2 * (nwin > 0 ? nwin : 1)), (unsigned)zn);
-    const long long n0 = (long long)g0.x * g0.y * g0.z, n1 = d.za ? (long long)g1.x * g1.y * g1.z : 0,
-                    n2 = (long long)g2.x * g2.y * g2.z, n3 = nwin > 0 ? (long long)g3.x * g3.y * g3.z : 0;
-    if (n0 + n1 + n2 + n3 > nmax) return fail(TV_E_ARG, "internal: fix-up partials exceed the workspace");
     double* w0 = (double*)ws;
-    if (g->dtype == TV_F64) {
-        if (int rc64 = tvm::cp_fixup_f64(g, d, st, q, q_prev, q_next, x_out, x0, tau, chunk_lo, zc, zb, zn, xw, g0, g1, g2, g3, n0, n1, n2, n3, w0)) return rc64;
-        return reduce_partials(w0, n0 + n1 + n2 + n3, nmax, fid, st);
-    }
-    FixupArgs a{(const float*)q, (const float*)q_prev, (const float*)q_next, (float*)x_out, (const float*)x0, (float)tau, chunk_lo};
-    auto launch = [&]<int S, bool XW>() -> int {
-        hipLaunchKernelGGL((k_cp_fixup<S, 0, XW>), g0, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0);
-        if (d.za) hipLaunchKernelGGL((k_cp_fixup<S, 1, XW>), g1, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0);
-        hipLaunchKernelGGL((k_cp_fixup<S, 2, XW>), g2, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0 + n1);
-        if (n3 > 0) hipLaunchKernelGGL((k_cp_fixup<S, 3, XW>), g3, blk, 0, st, d, make_w<float>(g), a, zc, zb, zn, w0 + n0 + n1 + n2);
-        HIP_TRY(hipGetLastError());
-        return 0;
+    auto fix = [&]<typename T>() -> int {
+        FixupArgsT<T> a{(const T*)q, (const T*)q_prev, (const T*)q_next, (T*)x_out, (const T*)x0, (T)tau, fp.chunk_lo};
+        return tvm::fused_fixup<T, ALG_CP>(g, d, st, a, fp, w0);
     };
-    int rc;
-    switch (g->scheme) {
-        case TV_UPWIND: rc = xw ? launch.template operator()<UPWIND, true>() : launch.template operator()<UPWIND, false>(); break;
-        case TV_DOWNWIND: rc = xw ? launch.template operator()<DOWNWIND, true>() : launch.template operator()<DOWNWIND, false>(); break;
-        case TV_CENTRAL: rc = xw ? launch.template operator()<CENTRAL, true>() : launch.template operator()<CENTRAL, false>(); break;
-        default: rc = xw ? launch.template operator()<HYBRID, true>() : launch.template operator()<HYBRID, false>(); break;
+    if (int rc = (g->dtype == TV_F32) ? fix.template operator()<float>() : fix.template operator()<double>()) return rc;
+    return reduce_partials(w0, fp.n0 + fp.n1 + fp.n2 + fp.n3, nmax, fid, st);
+}
+
+// One-sweep ADMM (tv_fused.h, ALG_ADMM): the z / u update of the outer iteration that ends and the residual of the x-solve that
+// starts, from ONE pass over u (build-defined, the reference ships no ADMM; README.md:26,135).
+int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* u, void* t, const void* x0, void* r,
+                  double thresh, double rho, int32_t full_store, int64_t chunk_begin, int64_t chunk_count, double* tvout, double* rr, void* ws,
+                  void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (!x || !u || !t || !x0 || !r || !tvout || !rr || !ws) return fail(TV_E_ARG, "NULL array");
+    if (x == r || x0 == r) return fail(TV_E_ARG, "r must not alias x or x0");
+    if (u == t) return fail(TV_E_ARG, "u and t must be different arrays");
+    if (!(thresh >= 0.0)) return fail(TV_E_ARG, "thresh must be >= 0");
+    if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
+    if (!aligned16({x, x_prev, x_next, u, t, x0, r, d.wv})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    SweepPlan sp;
+    bool empty = false;
+    if (int rc = sweep_plan(g, d, x, x_prev, x_next, chunk_begin, chunk_count, sp, empty)) return rc;
+    if (empty) {
+        HIP_TRY(hipMemsetAsync(tvout, 0, sizeof(double), st));
+        HIP_TRY(hipMemsetAsync(rr, 0, sizeof(double), st));
+        return 0;
     }
+    double* w0 = (double*)ws;
+    double* w1 = w0 + sp.nmax + kStage + 16;
+    auto sweep = [&]<typename T>() -> int {
+        FusedArgsT<T> a{(const T*)x, (const T*)x_prev, (const T*)x_next, (T*)u, (const T*)x0, (T*)t,
+                        (T*)r, (T)thresh, (T)0, (T)rho, (T)0, (T)0, w0, w1, full_store ? 1 : 0};
+        return tvm::fused_sweep<T, ALG_ADMM>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
+    };
+    const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();
     if (rc) return rc;
-    return reduce_partials(w0, n0 + n1 + n2 + n3, nmax, fid, st);
+    if (int r2 = reduce_partials(w0, sp.lc.nblocks, sp.nmax, tvout, st)) return r2;
+    return reduce_partials(w1, sp.lc.nblocks, sp.nmax, rr, st);
+}
+
+int tv_admm_fixup(const tv_geom* g, const void* t, const void* t_prev, const void* t_next, void* r, double rho, int64_t z_begin,
+                  int64_t z_count, double* rr, void* ws, void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (!t || !r || !rr || !ws) return fail(TV_E_ARG, "NULL array");
+    if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
+    if (!aligned16({t, t_prev, t_next, r})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    FixPlan fp;
+    long long nmax = 0;
+    bool empty = false;
+    if (int rc = fixup_plan(g, d, t, t_prev, t_next, z_begin, z_count, fp, nmax, empty)) return rc;
+    if (empty) {
+        HIP_TRY(hipMemsetAsync(rr, 0, sizeof(double), st));
+        return 0;
+    }
+    double* w0 = (double*)ws;
+    auto fix = [&]<typename T>() -> int {
+        FixupArgsT<T> a{(const T*)t, (const T*)t_prev, (const T*)t_next, (T*)r, nullptr, (T)(-rho), fp.chunk_lo};
+        return tvm::fused_fixup<T, ALG_ADMM>(g, d, st, a, fp, w0);
+    };
+    if (int rc = (g->dtype == TV_F32) ? fix.template operator()<float>() : fix.template operator()<double>()) return rc;
+    return reduce_partials(w0, fp.n0 + fp.n1 + fp.n2 + fp.n3, nmax, rr, st);
 }
 
 }  // extern "C"

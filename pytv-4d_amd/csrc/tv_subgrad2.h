@@ -698,7 +698,7 @@ __device__ __forceinline__ void sg2_tile(const SgTiles& tm, bool fast, long long
 }
 
 template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false, int NWX = 1>
-__global__ __launch_bounds__(64 * NW * NWX, 2) void k_subgrad_col(DG g, WT<T> w, const T* __restrict__ x, const T* __restrict__ xp,
+__global__ __launch_bounds__(64 * NW * NWX, (NW * NWX >= 16) ? 1 : 2) void k_subgrad_col(DG g, WT<T> w, const T* __restrict__ x, const T* __restrict__ xp,
                                                                             const T* __restrict__ xn, T* __restrict__ G, int zchunk, int nchunks,
                                                                             double* __restrict__ partials, SgArgs2<T> sa, SgTiles tm) {
     using K = SgCol<S, T, M, R, NW, MODE, TWIN, XLD, NWX>;

@@ -619,10 +619,20 @@ class ADMM(_SlabProblem):
     oracle.admm restates both."""
 
     def __init__(self, x0, regularization, rho, n_cg=10, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True):
+                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=False):
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.reg, self.rho, self.n_cg = float(regularization), float(rho), int(n_cg)
         self.single = bool(single_reduction)
+        # one-sweep dual side (round 3): z / u update + the residual of the next x-solve in one pass over u
+        # (tv_admm_fused + tv_admm_fixup: 2 Nd + 3 words per voxel instead of the 4 Nd + 6 of tv_admm_tu + tv_DT_axpy +
+        # tv_normal_op2).  keep_z=False stores only the samples of t' = (z - u) - D x the fix-up reads (2 Nd -> Nd + 0.3
+        # written words); the split variable z is then not recoverable and ``.z`` raises.
+        can_fuse = self.single and self.n_cg > 0 and bool(self.lib.tv_cp_fused_supported(self.geo.ref))
+        if fused and not can_fuse:
+            raise ValueError("fused=True needs single_reduction, n_cg > 0 and a geometry tv_cp_fused_supported() accepts")
+        self.fused = can_fuse if fused is None else bool(fused)
+        self.keep_z = bool(keep_z)
+        self._have_r = False
         self.x = self.x0.clone()
         self._zt = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)   # z, or t = z - u (single_reduction)
         self.u = torch.zeros_like(self._zt)
@@ -647,10 +657,19 @@ class ADMM(_SlabProblem):
         self.sc = torch.zeros(4, dtype=torch.float64, device=self.device)   # rs, dAd, rs_new, spare / gamma, delta, gamma_old, alpha_old
         self.dots3 = torch.zeros((3, 2), dtype=torch.float64, device=self.device)
         self.dots = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.rr = torch.zeros(2, dtype=torch.float64, device=self.device)     # <r, r> of the sweep / of the fix-up
 
     @property
     def z(self):
-        """The split variable z (single_reduction keeps t = z - u: z = t + u)."""
+        """The split variable z (single_reduction keeps t = z - u: z = t + u; the one-sweep path keeps t' = t - D x)."""
+        if self.fused and self._have_r:
+            if not self.keep_z:
+                raise RuntimeError("ADMM(keep_z=False) stores only the samples of z - u - D x its fix-up reads: z is not available")
+            d = torch.empty_like(self.u)
+            hp, hn = self._halo2(self.x)
+            _nv.check(self.lib.tv_D(self.geo.ref, _nv.ptr(self.x), _nv.ptr(hp[1:2] if hp is not None else None),
+                                    _nv.ptr(hn[0:1] if hn is not None else None), _nv.ptr(d), self.stream))
+            return self._zt + self.u + d
         return self._zt + self.u if self.single else self._zt
 
     def _halo2(self, v):
@@ -740,13 +759,35 @@ class ADMM(_SlabProblem):
         _nv.check(lib.tv_sub(code, self.x.numel(), _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(self.r), self.stream))
         _nv.check(lib.tv_dot(g.ref, _nv.ptr(self.r), _nv.ptr(self.r), out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
 
+    def _zu_fused(self, out_tv):
+        """z / u update and r = b - A x of the next solve in one sweep + fix-up; gamma = <r, r> (local) into sc[0]."""
+        g, lib, s, nz = self.geo, self.lib, self.slab, self.slab.nz
+        hp, hn = self._halo2(self.x)
+        xp = hp[1:2] if hp is not None else None      # plane z0-1
+        xn = hn[0:1] if hn is not None else None      # plane z0+nz
+        _nv.check(lib.tv_admm_fused(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.u), _nv.ptr(self._zt),
+                                    _nv.ptr(self.x0), _nv.ptr(self.r), self.reg / self.rho, self.rho, 1 if self.keep_z else 0,
+                                    0, -1, out_tv.data_ptr(), self.rr[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+        # the boundary planes of t' travel to the neighbours (as those of t = z - u do in _rhs)
+        h = s.exchange(send_prev=self._zt[0, self.ch_fwd] if self.plan.g_send_prev else None,
+                       send_next=self._zt[nz - 1, self.ch_back] if self.plan.g_send_next else None,
+                       recv_prev=self.wh_prev[0] if self.wh_prev is not None else None,
+                       recv_next=self.wh_next[0] if self.wh_next is not None else None)
+        s.wait(h)
+        _nv.check(lib.tv_admm_fixup(g.ref, _nv.ptr(self._zt), _nv.ptr(self.wh_prev), _nv.ptr(self.wh_next), _nv.ptr(self.r), self.rho,
+                                    0, -1, self.rr[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
+        torch.sum(self.rr, dim=0, keepdim=True, out=self.sc[0:1])
+        self._have_r = True
+
     def _step_single(self, out):
         g, lib, s = self.geo, self.lib, self.slab
         sc, w, sv = self.sc, self.b, self.Ad          # w = A r lives in b (free once r is formed), s = A d in Ad
-        self._rhs()
-        # r = b - A x with gamma = <r, r> (local); then w = A r with delta = <r, w>: ONE all-reduce for the pair
-        self._normal(self.x, self.r, self.dots, rhs=self.b, reduce=False)
-        sc[0:1].copy_(self.dots[0:1])
+        if not (self.fused and self._have_r):
+            self._rhs()
+            # r = b - A x with gamma = <r, r> (local); then w = A r with delta = <r, w>: ONE all-reduce for the pair
+            self._normal(self.x, self.r, self.dots, rhs=self.b, reduce=False)
+            sc[0:1].copy_(self.dots[0:1])
+        # (one-sweep path: r and gamma were left by the sweep that closed the previous outer iteration)
         self._normal(self.r, w, self.dots, reduce=False)
         sc[1:2].copy_(self.dots[0:1])
         sc[2:4].zero_()                               # alpha_old = 0: first step of this solve
@@ -766,7 +807,10 @@ class ADMM(_SlabProblem):
             out[1:2] = torch.sum((self.x.double() - self.x0.double()) ** 2)     # the slot holds |x - x0|^2: run() halves it
         else:
             out[1:2].mul_(2.0)                        # run() halves: the slot holds |x - x0|^2 like the textbook path
-        self._zu(out[0:1])
+        if self.fused:
+            self._zu_fused(out[0:1])
+        else:
+            self._zu(out[0:1])
 
     GRAPH_BLOCK = 4             # outer iterations captured per hipGraph
     GRAPH_MAX_VOXELS = 1 << 23  # below this an outer iteration (~10 + 2 n_cg launches) is launch-bound

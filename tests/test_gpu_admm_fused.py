@@ -1,0 +1,126 @@
+"""One-sweep dual side of ADMM (round 3; include/pytv4d.h: tv_admm_fused + tv_admm_fixup): the z / u update and the residual
+r = [x0 + rho D^T (z - u)] - (I + rho D^T D) x of the next x-solve from ONE pass over u.  Against the oracle's ADMM (the
+reference ships none: README.md:26,135 name it only -- parity is pinned op by op against the reference's D / D^T, SURVEY 8a-3
+row a9), against a NumPy restatement of the two calls, and against the kernel trio it replaces."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCHEMES
+from oracle import tv_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+os.environ["TV_FUSED_MIN_KVOXELS"] = "0"
+
+# (Nz, M, Ny, Nx): one frame, several frames, more than 8 frames (time windows), more rows than a wave tile, more columns than a
+# block tile (256 fp32 / 128 fp64 columns), ragged in everything
+SHAPES = [(1, 1, 24, 64), (5, 3, 16, 64), (4, 10, 9, 128), (3, 2, 19, 324), (9, 8, 6, 192)]
+
+
+@pytest.fixture(scope="module")
+def nvlib():
+    import pytv  # noqa: F401
+    from pytv import _native as nv
+    return nv
+
+
+def _shrink(v, thresh):
+    nv = np.sqrt(np.sum(v * v, axis=1, keepdims=True))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sc = np.where(nv > 0, np.maximum(0.0, 1.0 - thresh / nv), 0.0)
+    return v * sc
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("zchunk", [0, 2])
+def test_admm_fused_calls_match_numpy(nvlib, scheme, shape, zchunk, tvopt):
+    """tv_admm_fused + tv_admm_fixup on random x, u against NumPy over the oracle's D / D^T: u', r, TV, <r, r>, and t' where
+    it is stored in full."""
+    import torch
+    nv, lib = nvlib, nvlib.lib()
+    tvopt("TV_ZCHUNK", zchunk)
+    rng = np.random.default_rng(11)
+    kw = dict(reg_z_over_reg=1.3, reg_time=0.6)
+    thresh, rho = 0.7, 0.15
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 3e-5)):
+        x = (rng.random(shape) * 4).astype(dtype)
+        x0 = (x + rng.random(shape)).astype(dtype)
+        dx = orc.D(x.astype(np.float64), scheme, **kw)
+        u = (rng.standard_normal(dx.shape)).astype(dtype)
+        v = dx + u.astype(np.float64)
+        z = _shrink(v, thresh)
+        un = v - z
+        t = z - un
+        r = (x0.astype(np.float64) - x) + rho * orc.D_T(t - dx, scheme, **kw)
+        tv = np.sum(np.sqrt(np.sum(dx * dx, axis=1)))
+        for full in (1, 0):
+            g = nv.Geometry(shape, scheme, torch.as_tensor(x).dtype, torch.device("cuda", 0), **kw)
+            assert lib.tv_cp_fused_supported(g.ref) == 1
+            st, ws = nv.current_stream(torch.device("cuda", 0)), g.workspace()
+            xd, x0d, ud = torch.as_tensor(x).cuda(), torch.as_tensor(x0).cuda(), torch.as_tensor(u).cuda()
+            td = torch.full_like(ud, 7.0)
+            rd = torch.empty_like(xd)
+            sc = torch.zeros(3, dtype=torch.float64, device="cuda")
+            nv.check(lib.tv_admm_fused(g.ref, nv.ptr(xd), None, None, nv.ptr(ud), nv.ptr(td), nv.ptr(x0d), nv.ptr(rd), thresh, rho, full,
+                                       0, -1, sc[0:1].data_ptr(), sc[1:2].data_ptr(), nv.ptr(ws), st))
+            nv.check(lib.tv_admm_fixup(g.ref, nv.ptr(td), None, None, nv.ptr(rd), rho, 0, -1, sc[2:3].data_ptr(), nv.ptr(ws), st))
+            scale = max(1.0, np.abs(r).max())
+            np.testing.assert_allclose(ud.cpu().numpy(), un, rtol=0, atol=tol * 10, err_msg="u %s %s" % (dtype, full))
+            np.testing.assert_allclose(rd.cpu().numpy(), r, rtol=0, atol=tol * 10 * scale, err_msg="r %s %s" % (dtype, full))
+            s = sc.cpu().numpy()
+            np.testing.assert_allclose(s[0], tv, rtol=max(tol, 1e-12) * 10)
+            np.testing.assert_allclose(s[1] + s[2], np.sum(r * r), rtol=tol * 100)
+            if full:
+                np.testing.assert_allclose(td.cpu().numpy(), t - dx, rtol=0, atol=tol * 10)
+            else:
+                assert (td == 7.0).float().mean().item() > 0.3          # most samples are never written
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape,lz,mu", [((1, 1, 24, 64), 1.0, 0.0), ((5, 3, 16, 64), 1.5, 0.5), ((3, 10, 9, 128), 1.0, 0.7)])
+def test_admm_fused_matches_oracle(scheme, shape, lz, mu):
+    import torch
+    import pytv
+    rng = np.random.default_rng(6)
+    for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-5, 5e-3)):
+        x0 = (rng.random(shape) * 100).astype(dtype)
+        wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 6, 25.0, 0.05, 5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+                                     single_reduction=True, return_state=True)
+        for keep_z in (True, False):
+            ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 25.0, 0.05, n_cg=5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+                                   keep_z=keep_z)
+            assert ad.fused
+            loss = ad.run(6)
+            np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s" % (scheme, shape))
+            np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
+            np.testing.assert_allclose(ad.u.cpu().numpy(), wu, rtol=rtol * 10, atol=atol)
+            if keep_z:
+                np.testing.assert_allclose(ad.z.cpu().numpy(), wz, rtol=rtol * 10, atol=atol)
+            else:
+                with pytest.raises(RuntimeError):
+                    ad.z
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_admm_fused_equals_kernel_trio(scheme):
+    """The one-sweep path against tv_admm_tu + tv_DT_axpy + tv_normal_op2 on a volume with many tiles, chunks and a time-window
+    seam: the same iteration up to the rounding of r (formed as one sum instead of two); sparse == full storage of t' bit for bit."""
+    import torch
+    import pytv
+    rng = np.random.default_rng(8)
+    x0 = torch.as_tensor((rng.random((10, 12, 40, 320)) * 100).astype(np.float32)).cuda()
+    kw = dict(n_cg=4, scheme=scheme, reg_time=0.8)
+    a = pytv.solvers.ADMM(x0, 20.0, 0.1, fused=True, **kw)
+    b = pytv.solvers.ADMM(x0, 20.0, 0.1, fused=False, **kw)
+    c = pytv.solvers.ADMM(x0, 20.0, 0.1, fused=True, keep_z=True, **kw)
+    la, lb, lc = a.run(5), b.run(5), c.run(5)
+    assert np.array_equal(la, lc)
+    assert torch.equal(a.result(), c.result()) and torch.equal(a.u, c.u)
+    np.testing.assert_allclose(la, lb, rtol=2e-6)
+    np.testing.assert_allclose(a.result().cpu().numpy(), b.result().cpu().numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(c.z.cpu().numpy(), b.z.cpu().numpy(), rtol=0, atol=2e-3)
+    assert la[-1] < la[0]

@@ -12,19 +12,24 @@ x0 = synth_slab(shape, 0, shape[0], torch.device("cuda", 0))
 V = x0.numel()
 print("ADMM on %s (V = %.0f Mvox), %d CG steps per outer iteration, rho = 0.05, lambda = 25" % (shape, V / 1e6, n_cg))
 for scheme in ("upwind", "downwind", "central", "hybrid"):
-    for single in (True, False):
-        ad = pytv.solvers.ADMM(x0, 25.0, 0.05, n_cg=n_cg, scheme=scheme, reg_time=1.0, single_reduction=single)
-        ad.run(1)
+    # one-sweep dual side (round 3, sparse / full storage of t'), the kernel trio it replaces, the textbook recurrence
+    for name, kw in (("one-sweep", dict(fused=True)), ("one-sweep keep_z", dict(fused=True, keep_z=True)),
+                     ("single-reduction", dict(fused=False)), ("textbook CG", dict(single_reduction=False))):
+        if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+            continue
+        ad = pytv.solvers.ADMM(x0, 25.0, 0.05, n_cg=n_cg, scheme=scheme, reg_time=1.0, **kw)
+        ad.run(2)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         loss = ad.run(4)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
         nd = ad.geo.nd
         # words / voxel per outer iteration.  single reduction: rhs (Nd + 2) + residual (3) + n_cg normal ops on r (2) + n_cg
         # updates (9; the first 7; the last +1 for x0) + t/u update (1 + 3 Nd) = 4 Nd + 11 n_cg + 5; textbook: rhs (2 Nd + 2) +
-        # residual with the copy (4) + n_cg (normal op 2, cg1 6, cg2 3) + z/u (1 + 3 Nd) + fidelity (sub 3 + dot 2)
-        words = (4 * nd + 11 * n_cg + 5) if single else (5 * nd + 11 * n_cg + 12)
+        # residual with the copy (4) + n_cg (normal op 2, cg1 6, cg2 3) + z/u (1 + 3 Nd) + fidelity (sub 3 + dot 2);
+        # one-sweep: sweep (x, x0 read, r written, u read + written: 2 Nd + 3; + Nd with keep_z) + n_cg (2 + 9) - 1
+        words = {"one-sweep": 2 * nd + 11 * n_cg + 2, "one-sweep keep_z": 3 * nd + 11 * n_cg + 2, "single-reduction": 4 * nd + 11 * n_cg + 5,
+                 "textbook CG": 5 * nd + 11 * n_cg + 12}[name]
         print("%-9s Nd=%d %-16s %.2f ms/outer  %.1f it/s  loss %.6e -> %.6e  | algorithmic %.0f words/voxel -> %.0f GB/s" % (
-            scheme, nd, "single-reduction" if single else "textbook CG", dt * 1e3, 1 / dt, loss[0], loss[-1], words,
-            words * 4.0 * V / dt / 1e9))
+            scheme, nd, name, dt * 1e3, 1 / dt, loss[0], loss[-1], words, words * 4.0 * V / dt / 1e9))
         del ad
         torch.cuda.empty_cache()
