@@ -15,7 +15,7 @@ for scheme in ("upwind", "downwind", "central", "hybrid"):
     # one-sweep dual side (round 3, sparse / full storage of t'), the kernel trio it replaces, the textbook recurrence
     for name, kw in (("one-sweep", dict(fused=True)), ("one-sweep keep_z", dict(fused=True, keep_z=True)),
                      ("single-reduction", dict(fused=False)), ("textbook CG", dict(single_reduction=False))):
-        if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+        if os.environ.get("ONLY") and os.environ["ONLY"] != name:          # ONLY=<exact name>: one variant (profiling)
             continue
         ad = pytv.solvers.ADMM(x0, 25.0, 0.05, n_cg=n_cg, scheme=scheme, reg_time=1.0, **kw)
         ad.run(2)

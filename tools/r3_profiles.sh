@@ -19,4 +19,6 @@ DTYPE=f64 OPS=tv_subgrad_fused bash tools/prof_op.sh r3_sg_f64 32x8x1024x1024 hy
 cp $R/gpurun_out/op_r3_sg_f64/digest.json $O/sg_f64_hybrid_digest.json
 for w in config1 config2; do python3 bench.py --workload $w --pmc off --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_$w.json 2>/dev/null; done
 python3 tools/admm_bench.py 32x16x1024x1024 5 > $O/admm_config4_slab.txt 2>&1
+ONLY=one-sweep bash tools/prof_admm.sh r3_fused 32x16x1024x1024 5 > $O/admm_prof.txt 2>&1
+cp $R/gpurun_out/admm_r3_fused/kernel_stats_top.csv $O/admm_one_sweep_kernel_stats.csv; cp $R/gpurun_out/admm_r3_fused/digest.json $O/admm_one_sweep_pmc_digest.json
 ls -la $O
