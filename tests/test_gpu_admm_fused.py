@@ -81,25 +81,29 @@ def test_admm_fused_calls_match_numpy(nvlib, scheme, shape, zchunk, tvopt):
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("reg,rho", [(25.0, 0.05), (4.0, 0.1)])      # threshold reg / rho = 500 (z stays 0) and 40 (z active)
 @pytest.mark.parametrize("shape,lz,mu", [((1, 1, 24, 64), 1.0, 0.0), ((5, 3, 16, 64), 1.5, 0.5), ((3, 10, 9, 128), 1.0, 0.7)])
-def test_admm_fused_matches_oracle(scheme, shape, lz, mu):
+def test_admm_fused_matches_oracle(scheme, shape, lz, mu, reg, rho):
+    """fp32 bounds: ~10 x the measured deviation from the fp64 oracle (profiles/r3_admm_tolerances.txt)."""
     import torch
     import pytv
     rng = np.random.default_rng(6)
-    for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-5, 5e-3)):
+    for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-6, 2e-4)):
         x0 = (rng.random(shape) * 100).astype(dtype)
-        wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 6, 25.0, 0.05, 5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+        wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 6, reg, rho, 5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
                                      single_reduction=True, return_state=True)
+        if rho == 0.1:
+            assert np.abs(wz).max() > 1.0              # the shrinkage branch is exercised
         for keep_z in (True, False):
-            ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 25.0, 0.05, n_cg=5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+            ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), reg, rho, n_cg=5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
                                    keep_z=keep_z)
             assert ad.fused
             loss = ad.run(6)
-            np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s" % (scheme, shape))
+            np.testing.assert_allclose(loss, wloss, rtol=rtol / 2, err_msg="%s %s" % (scheme, shape))
             np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
-            np.testing.assert_allclose(ad.u.cpu().numpy(), wu, rtol=rtol * 10, atol=atol)
+            np.testing.assert_allclose(ad.u.cpu().numpy(), wu, rtol=rtol * 10, atol=atol * 3)
             if keep_z:
-                np.testing.assert_allclose(ad.z.cpu().numpy(), wz, rtol=rtol * 10, atol=atol)
+                np.testing.assert_allclose(ad.z.cpu().numpy(), wz, rtol=rtol * 10, atol=atol * 3)
             else:
                 with pytest.raises(RuntimeError):
                     ad.z
@@ -114,13 +118,14 @@ def test_admm_fused_equals_kernel_trio(scheme):
     rng = np.random.default_rng(8)
     x0 = torch.as_tensor((rng.random((10, 12, 40, 320)) * 100).astype(np.float32)).cuda()
     kw = dict(n_cg=4, scheme=scheme, reg_time=0.8)
-    a = pytv.solvers.ADMM(x0, 20.0, 0.1, fused=True, **kw)
-    b = pytv.solvers.ADMM(x0, 20.0, 0.1, fused=False, **kw)
-    c = pytv.solvers.ADMM(x0, 20.0, 0.1, fused=True, keep_z=True, **kw)
+    a = pytv.solvers.ADMM(x0, 4.0, 0.1, fused=True, **kw)             # threshold 40 against differences of +-100: z is active
+    b = pytv.solvers.ADMM(x0, 4.0, 0.1, fused=False, **kw)
+    c = pytv.solvers.ADMM(x0, 4.0, 0.1, fused=True, keep_z=True, **kw)
     la, lb, lc = a.run(5), b.run(5), c.run(5)
     assert np.array_equal(la, lc)
     assert torch.equal(a.result(), c.result()) and torch.equal(a.u, c.u)
     np.testing.assert_allclose(la, lb, rtol=2e-6)
     np.testing.assert_allclose(a.result().cpu().numpy(), b.result().cpu().numpy(), rtol=0, atol=2e-3)
     np.testing.assert_allclose(c.z.cpu().numpy(), b.z.cpu().numpy(), rtol=0, atol=2e-3)
+    assert c.z.abs().max().item() > 1.0
     assert la[-1] < la[0]

@@ -129,5 +129,5 @@ def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, z
             z0, nz = ret[r]["z"]
             np.testing.assert_allclose(ret[r]["sg_loss"], sloss, rtol=1e-5)
             np.testing.assert_allclose(ret[r]["sg_x"], sx[z0:z0 + nz], rtol=1e-5, atol=2e-3)
-            np.testing.assert_allclose(ret[r]["ad_loss"], aloss, rtol=5e-5)
-            np.testing.assert_allclose(ret[r]["ad_x"], ax[z0:z0 + nz], rtol=1e-4, atol=5e-3)
+            np.testing.assert_allclose(ret[r]["ad_loss"], aloss, rtol=1e-6)          # ~10 x measured: profiles/r3_admm_tolerances.txt
+            np.testing.assert_allclose(ret[r]["ad_x"], ax[z0:z0 + nz], rtol=2e-6, atol=2e-4)

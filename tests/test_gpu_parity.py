@@ -471,21 +471,26 @@ def test_subgradient_descent_head_matches_oracle(pytv, scheme):
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("reg,rho", [(25.0, 0.05), (4.0, 0.1)])      # threshold reg / rho = 500 (z stays 0: pure u accumulation) and 40 (z active)
 @pytest.mark.parametrize("shape,lz,mu", [((1, 1, 16, 16), 1.0, 0.0), ((5, 3, 8, 12), 1.5, 0.5)])
-def test_admm_matches_oracle(pytv, scheme, shape, lz, mu):
+def test_admm_matches_oracle(pytv, scheme, shape, lz, mu, reg, rho):
+    """fp32 bounds: ~10 x the deviation measured from the fp64 oracle (profiles/r3_admm_tolerances.txt: loss 3.5e-8 relative, x 2e-5,
+    z 2e-5, u 6e-5 absolute at |x| <= 95 -- a few units in the last place)."""
     import torch
-    for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-5, 5e-3)):
+    for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-6, 2e-4)):
         x0 = _noisy(shape, 6, dtype)
         for single in (True, False):      # Chronopoulos-Gear (default) and textbook CG, each against the oracle's restatement
-            wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 8, 25.0, 0.05, 6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+            wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 8, reg, rho, 6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
                                          single_reduction=single, return_state=True)
-            ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 25.0, 0.05, n_cg=6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
-                                   single_reduction=single)
+            ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), reg, rho, n_cg=6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+                                   single_reduction=single, keep_z=True)
             loss = ad.run(8)
-            np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s single=%s" % (scheme, shape, single))
+            np.testing.assert_allclose(loss, wloss, rtol=rtol / 2, err_msg="%s %s single=%s" % (scheme, shape, single))
             np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
-            np.testing.assert_allclose(ad.z.cpu().numpy(), wz, rtol=rtol * 10, atol=atol)
-            np.testing.assert_allclose(ad.u.cpu().numpy(), wu, rtol=rtol * 10, atol=atol)
+            np.testing.assert_allclose(ad.z.cpu().numpy(), wz, rtol=rtol * 10, atol=atol * 3)
+            np.testing.assert_allclose(ad.u.cpu().numpy(), wu, rtol=rtol * 10, atol=atol * 3)
+            if rho == 0.1:
+                assert np.abs(wz).max() > 1.0          # the shrinkage branch is exercised
 
 
 def test_denoise_tv_chambolle_front_end(pytv):

@@ -78,7 +78,7 @@ def test_general_weight_map_matches_oracle(pytv, scheme, dtype, shape):
     ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, **kw)
     la = ad.run(3)
     _, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, single_reduction=True, **kw)
-    np.testing.assert_allclose(la, lref, rtol=1e-4 if dtype == np.float32 else 1e-9)
+    np.testing.assert_allclose(la, lref, rtol=1e-6 if dtype == np.float32 else 1e-9)      # measured 3e-8: profiles/r3_admm_tolerances.txt
     # adjointness with the map
     g = nv.Geometry(shape, scheme, torch.float64 if dtype == np.float64 else torch.float32, "cuda", **kw)
     assert g.factor_dev is not None and g.mask_dev is None

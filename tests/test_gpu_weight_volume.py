@@ -104,8 +104,9 @@ def test_general_weight_volume_matches_oracle(pytv, scheme, dtype, shape):
     ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, **kw)
     la = ad.run(3)
     ax, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, single_reduction=True, **kw)
-    np.testing.assert_allclose(la, lref, rtol=1e-4 if dtype == np.float32 else 1e-9)
-    np.testing.assert_allclose(ad.result().cpu().numpy(), ax, rtol=1e-4, atol=5e-3 if dtype == np.float32 else 1e-8)
+    # fp32 bounds ~10 x the measured deviation (profiles/r3_admm_tolerances.txt)
+    np.testing.assert_allclose(la, lref, rtol=1e-6 if dtype == np.float32 else 1e-9)
+    np.testing.assert_allclose(ad.result().cpu().numpy(), ax, rtol=2e-6 if dtype == np.float32 else 1e-9, atol=2e-4 if dtype == np.float32 else 1e-8)
     sx, sref = orc.subgradient_descent(x64 * 5, 5, 7.0, 2e-3, scheme=scheme, **kw)
     for one_pass in ((False, True) if fast_sg else (False,)):
         sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, one_pass=one_pass, **kw)
