@@ -147,10 +147,18 @@ struct SgCol {
 
     // FAST: the tile (ring included) lies strictly inside the frame and there is no per-pixel time factor: no border
     // multipliers.  Everything else takes the generic variant (same memory operations, masks on the differences).
-    template <bool FAST>
+    // BK (round 3, late): 0 = FAST; 1 = COLUMN border -- the tile's rows (ring and halo rows included) lie strictly inside the frame,
+    // its columns do not, and there is no per-pixel / per-voxel time factor: only the column multipliers survive (one value per
+    // lane, the same for all R rows), the time channel runs as in FAST.  2 = generic.  On a 1024 x 1024 frame 148 of the 162 outline
+    // blocks are column-border blocks; the generic variant costs 27 % more than FAST (TV_SPARE=7 forces it everywhere: 8.0 ->
+    // 10.2 ms per descent step on 256x8x1024x1024), which made the outline 9 % of the kernel.
+    template <int BK>
     static __device__ __forceinline__ void run(const DG& g, const WT<T>& w, const T* __restrict__ x, const T* __restrict__ xp,
                                                const T* __restrict__ xn, T* __restrict__ G, int zchunk, int chunk, int tile_x, int tile_y,
                                                int win, long long lid, double* __restrict__ partials, const SgArgs2<T>& sa, Shared& sh) {
+        constexpr bool FAST = (BK == 0);         // no border multipliers at all
+        constexpr bool ROWS_IN = (BK <= 1);      // every row this thread touches exists and has both neighbours
+        constexpr bool TFAST = (BK <= 1);        // uniform time factor: the weighted time difference is carried from frame to frame
         const int lane = (int)threadIdx.x, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.y);    // the wave index is uniform: keep it scalar
         const int wv = wid % NW, wx = wid / NW;                 // position in the block: row strip, wave column
         tile_x = tile_x * NWX + wx;
@@ -179,7 +187,7 @@ struct SgCol {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int y = yb + i;
-            const bool in = in_x && (FAST || (y >= 0 && y < g.ny));
+            const bool in = in_x && (ROWS_IN || (y >= 0 && y < g.ny));
             const bool own = in && lane_ok && (TV_SG2_WIDE || (!(wv == 0 && i == 0) && !(wv == NW - 1 && i == R - 1)));
             const unsigned off = (unsigned)(((long long)y * g.nx + cx) * (long long)sizeof(T));
             roff[i] = in ? off : SG2_OOB;
@@ -187,14 +195,14 @@ struct SgCol {
             cm.v[i] = own ? T(1) : T(0);
             // border multipliers of the generic variant: mi: site exists; mfr / mbr: it has a next / previous row; mfc / mbc:
             // a next / previous column (central: both, for a difference to exist)
-            const bool hn = in && (y + 1 < g.ny), hp = in && (y > 0), cn = in && (cx + 1 < g.nx), cp = in && (cx > 0);
+            const bool hn = in && (ROWS_IN || y + 1 < g.ny), hp = in && (ROWS_IN || y > 0), cn = in && (cx + 1 < g.nx), cp = in && (cx > 0);
             mi.v[i] = in ? T(1) : T(0);
             mfr.v[i] = (CEN ? (hn && hp) : hn) ? T(1) : T(0);
             mbr.v[i] = (CEN ? (hn && hp) : hp) ? T(1) : T(0);
             mfc.v[i] = (CEN ? (cn && cp) : cn) ? T(1) : T(0);
             mbc.v[i] = (CEN ? (cn && cp) : cp) ? T(1) : T(0);
             mft.v[i] = T(0);
-            if (!FAST && g.ta && in) mft.v[i] = w.wt * mask_factor1<T>(g, w.sf, y, cx);
+            if (!TFAST && g.ta && in) mft.v[i] = w.wt * mask_factor1<T>(g, w.sf, y, cx);
         }
         const int zs = chunk * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
@@ -416,7 +424,7 @@ struct SgCol {
                 // longer the forward one of frame t-1 and the carry is the unweighted difference.  No volume: a descriptor with
                 // num_records = 0, the loads cost nothing and the factor is 1.
                 C wv_t;
-                if (!FAST) {
+                if (!TFAST) {
                     const T* wpl = vol_plane<T>(g, zl, t0 + t);          // uniform: the weight frame of (zl, t), ghost planes included
                     const Rsrc rw = sg2_rsrc<T>(wpl, wpl != nullptr, fbytes);
 #pragma unroll
@@ -427,11 +435,11 @@ struct SgCol {
                 }
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    const T wti = FAST ? wt_u : (mft.v[i] * m_pl) * wv_t.v[i];
+                    const T wti = FAST ? wt_u : (TFAST ? wt_u * (mi.v[i] * m_pl) : (mft.v[i] * m_pl) * wv_t.v[i]);
                     if (CEN) {
                         f_t.v[i] = (has_tn && has_tp) ? wti * (xtn.v[i] - xtp.v[i]) : T(0);
                         b_t.v[i] = T(0);
-                    } else if (FAST) {
+                    } else if (TFAST) {
                         f_t.v[i] = has_tn ? wti * (xtn.v[i] - c.v[i]) : T(0);
                         b_t.v[i] = f_t_prev.v[i];
                         if (TWIN && t == 0 && DN) b_t.v[i] = has_tp ? wti * (c.v[i] - xtp.v[i]) : T(0);   // backward difference of the window's first frame
@@ -443,7 +451,7 @@ struct SgCol {
                         f_t_prev.v[i] = dt;
                     }
                 }
-                if (FAST || CEN)
+                if (TFAST || CEN)
                 f_t_prev = f_t;
                 c_old_prev = c;
                 // ---- 1 / |Dx| -------------------------------------------------------------------------------------------
@@ -537,7 +545,7 @@ struct SgCol {
                             gc.v[i] += pz_b - pz_f;
                             gn.v[i] = pz_f;
                             Gp[t].v[i] -= pz_b;
-                            if (FAST) {
+                            if (TFAST) {
                                 T pt_;
                                 if (TWIN && t == 0) pt_ = b_t.v[i] * n.v[i];          // the edge into the window: its other end is not ours
                                 else pt_ = b_t.v[i] * (pf_t_prev.v[i] + n.v[i]);      // pf_t_prev carries 1 / |Dx| of frame t-1 here
@@ -722,8 +730,12 @@ __global__ __launch_bounds__(64 * NW * NWX, (NW * NWX >= 16) ? 1 : 2) void k_sub
     int bx, by;
     sg2_tile(tm, fast, lid % ntiles, bx, by);
     const long long slot = (fast ? nb_border : 0) + lid;
-    if (fast) K::template run<true>(g, w, x, xp, xn, G, zchunk, chunk, bx, by, win, slot, partials, sa, sh);
-    else K::template run<false>(g, w, x, xp, xn, G, zchunk, chunk, bx, by, win, slot, partials, sa, sh);
+    // outline blocks in the rows of the interior rectangle are column-border blocks (an empty rectangle -- small frames, a time
+    // factor -- has iy1 < iy0: none)
+    const bool colb = !fast && by >= tm.iy0 && by <= tm.iy1;
+    if (fast) K::template run<0>(g, w, x, xp, xn, G, zchunk, chunk, bx, by, win, slot, partials, sa, sh);
+    else if (colb) K::template run<1>(g, w, x, xp, xn, G, zchunk, chunk, bx, by, win, slot, partials, sa, sh);
+    else K::template run<2>(g, w, x, xp, xn, G, zchunk, chunk, bx, by, win, slot, partials, sa, sh);
 }
 
 }  // namespace tv

@@ -99,7 +99,7 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
     tm.tx = (int)txb; tm.ty = (int)ty;
     int ix0 = 1, ix1 = (int)((d.nx - 2 - 63 + RING) / UC), iy0 = 1, iy1 = (int)((d.ny - RB) / UR);
     if (TV_SG2_WIDE) { ix1 = (int)tx - 1; ix0 = 0; iy0 = 0; iy1 = (int)ty - 1; }
-    else if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || d.wv != nullptr || ix1 < ix0 || iy1 < iy0) { ix0 = iy0 = 1; ix1 = iy1 = 0; }
+    else if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || d.wv != nullptr || ix1 < ix0 || iy1 < iy0 || env_int("TV_SPARE", 0) == 7) { ix0 = iy0 = 1; ix1 = iy1 = 0; }   // (TV_SPARE=7: experiment, every block generic)
     if (ix1 >= ix0) {            // wave-tile columns [ix0, ix1] -> block-tile columns whose NWX wave tiles all lie inside
         const int b0 = (ix0 + NWX - 1) / NWX, b1 = (ix1 + 1) / NWX - 1;
         ix0 = b0; ix1 = b1;
