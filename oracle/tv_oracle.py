@@ -366,8 +366,40 @@ def group_soft_threshold(v, thresh):
     return v * scale
 
 
+def normal_spectral_bound(scheme, shape, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False, factor_reg_static=0):
+    """L >= lambda_max(D^T D): a forward / backward difference has norm^2 <= 4, a halved central one <= 1, each axis weighted
+    by the square of its weight (the time axis by the largest per-pixel factor); hybrid is the mean of the two one-sided
+    operators.  The same rule as pytv.solvers (and as the Chambolle-Pock step size 1 / (1 + L), README.md:141-143)."""
+    nz, m = shape[0], shape[1]
+    twmax = 1.0
+    if not isinstance(mask_static, bool):
+        mk = np.asarray(mask_static)
+        if mk.dtype == bool:
+            twmax = float(factor_reg_static) if bool(mk.all()) else max(1.0, float(factor_reg_static))
+        else:
+            twmax = float(mk.max())
+    s = 2.0 + (reg_z_over_reg if (nz > 1 and reg_z_over_reg > 0) else 0.0) + (reg_time * twmax if (m > 1 and reg_time > 0) else 0.0)
+    return (1.0 if scheme == "central" else 4.0) * s
+
+
+def chebyshev_coefficients(lmax, n):
+    """(alpha_k, beta_k), k = 0 .. n-1, of the Chebyshev iteration e_{k+1} = e_k + alpha_k (b - A e_k) + beta_k (e_k - e_{k-1})
+    (e_0 = e_{-1} = 0) for a symmetric A with spectrum in [1, lmax] (Saad, Iterative Methods, alg. 12.1, written as a
+    three-term recurrence in e)."""
+    theta, delta = 0.5 * (lmax + 1.0), 0.5 * (lmax - 1.0)
+    if delta <= 1e-14 * theta:
+        return [(1.0 / theta, 0.0)] * n
+    sigma = theta / delta
+    out, rho_prev = [(1.0 / theta, 0.0)], 1.0 / sigma
+    for _ in range(1, n):
+        rho_k = 1.0 / (2.0 * sigma - rho_prev)
+        out.append((2.0 * rho_k / delta, rho_k * rho_prev))
+        rho_prev = rho_k
+    return out[:n]
+
+
 def admm(x0, n_outer, regularization, rho, n_cg, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-         mask_static=False, factor_reg_static=0, return_state=False, single_reduction=False):
+         mask_static=False, factor_reg_static=0, return_state=False, single_reduction=False, x_solver="cg"):
     """Scaled-form ADMM for min 1/2|x-x0|^2 + reg |z|_{2,1} s.t. Dx = z.  NOT in the reference
     (README.md:26,135 only mention it): build-defined, parity unpinned; this NumPy version pins
     the HIP implementation to the same arithmetic.
@@ -377,7 +409,9 @@ def admm(x0, n_outer, regularization, rho, n_cg, scheme="hybrid", reg_z_over_reg
     loss[k] = 1/2|x-x0|^2 + reg |Dx|_{2,1} after the x-step.
     single_reduction: the Chronopoulos-Gear form of the same CG recurrence (w = A r, gamma = <r,r>, delta = <r,w>
     reduced together: one all-reduce per step on a sharded volume) -- what pytv.solvers.ADMM(single_reduction=True)
-    runs; identical to the textbook form in exact arithmetic."""
+    runs; identical to the textbook form in exact arithmetic.
+    x_solver="chebyshev": n_cg steps of the Chebyshev iteration on A e = b - A x (spectrum in [1, 1 + rho L],
+    normal_spectral_bound) instead of CG -- what pytv.solvers.ADMM(x_solver="chebyshev") runs (no dot products)."""
     x0 = np.asarray(x0)
     kw = dict(reg_z_over_reg=reg_z_over_reg, reg_time=reg_time, mask_static=mask_static,
               factor_reg_static=factor_reg_static)
@@ -394,7 +428,14 @@ def admm(x0, n_outer, regularization, rho, n_cg, scheme="hybrid", reg_z_over_reg
         r = b - A(x)
         d = r.copy()
         rs = float(np.sum(r.astype(np.float64) ** 2))
-        if single_reduction:
+        if x_solver == "chebyshev":
+            L = normal_spectral_bound(scheme, x0.shape, reg_z_over_reg, reg_time, mask_static, factor_reg_static)
+            coef = chebyshev_coefficients(1.0 + rho * L, n_cg)
+            e_prev, e = np.zeros_like(r), np.zeros_like(r)
+            for a_k, b_k in coef:
+                e, e_prev = e + e.dtype.type(a_k) * (r - A(e)) + e.dtype.type(b_k) * (e - e_prev), e
+            x = x + e
+        elif single_reduction:
             w = A(r)
             gamma, delta = rs, float(np.sum(r.astype(np.float64) * w))
             alpha, beta = (gamma / delta if delta > 0 else 0.0), 0.0
@@ -413,7 +454,7 @@ def admm(x0, n_outer, regularization, rho, n_cg, scheme="hybrid", reg_z_over_reg
                 den = delta - beta * gamma_new / alpha if alpha != 0.0 else 0.0
                 alpha = gamma_new / den if den > 0 else 0.0
                 gamma = gamma_new
-        for _ in range(0 if single_reduction else n_cg):
+        for _ in range(0 if (single_reduction or x_solver == "chebyshev") else n_cg):
             Ad = A(d)
             dAd = float(np.sum(d.astype(np.float64) * Ad))
             alpha = rs / dAd if dAd > 0 else 0.0

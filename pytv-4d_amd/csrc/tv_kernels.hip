@@ -670,6 +670,61 @@ __global__ __launch_bounds__(256) void k_sub_dot(long long nv, const T* a, const
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
+// Chebyshev step, composed form (tv_cheb_step where the streaming normal operator does not apply): ax = A x is in `out`
+//   out = [add +] x + alpha (b - ax) + beta (x - y);  partials: |b - ax|^2 and |out - ref|^2 (or |x|^2)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_cheb_combine(long long nv, const T* x, const T* b, const T* y, const T* add, const T* ref, T* out, T alpha,
+                                                      T beta, double* part0, double* part1) {
+    __shared__ double sm[16];
+    double acc0 = 0.0, acc1 = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const Vec<T, V> xv = vload<T, V>(x + i * V), ax = vload<T, V>(out + i * V), bv = vload<T, V>(b + i * V);
+        const Vec<T, V> yv = (y != nullptr) ? vload<T, V>(y + i * V) : vsplat<T, V>(T(0));
+        Vec<T, V> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const T res = bv.v[k] - ax.v[k];
+            o.v[k] = (xv.v[k] + alpha * res) + beta * (xv.v[k] - yv.v[k]);
+            acc0 += (double)res * (double)res;
+        }
+        if (add != nullptr) o = vload<T, V>(add + i * V) + o;
+        Vec<T, V> rv = xv;
+        if (ref != nullptr) rv = vload<T, V>(ref + i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const double e = (ref != nullptr) ? (double)o.v[k] - (double)rv.v[k] : (double)xv.v[k];
+            acc1 += e * e;
+        }
+        vstore<T, V>(out + i * V, o);
+    }
+    acc0 = block_sum(acc0, sm);
+    if (threadIdx.x == 0) part0[blockIdx.x] = acc0;
+    acc1 = block_sum(acc1, sm);
+    if (threadIdx.x == 0) part1[blockIdx.x] = acc1;
+}
+// out = a x + b y (y may be nullptr: out = a x); partial |out - ref|^2 when ref is given
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_axpby(long long nv, T a, const T* x, T b, const T* y, const T* ref, T* out, double* partials) {
+    __shared__ double sm[16];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        Vec<T, V> o = a * vload<T, V>(x + i * V);
+        if (y != nullptr) o = o + b * vload<T, V>(y + i * V);
+        if (ref != nullptr) {
+            const Vec<T, V> rv = vload<T, V>(ref + i * V);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const double e = (double)o.v[k] - (double)rv.v[k];
+                acc += e * e;
+            }
+        }
+        vstore<T, V>(out + i * V, o);
+    }
+    if (ref != nullptr) {
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+    }
+}
 // Chambolle-Pock with a data-fidelity operator (README.md:148 with A != I), data space, any length:
 //   k_cpop_p  : p <- (p + sigma r) / (1 + sigma)              (r = A x - b carried from the previous iteration)
 //   k_cpop_res: r <- Ax - b,  partial 1/2 |r|^2
@@ -1201,6 +1256,53 @@ int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const voi
         HIP_TRY(hipGetLastError());
         return reduce_partials((double*)ws, kFlatBlocks, nmax, dots, st);
     }
+    return 0;
+}
+
+// One Chebyshev step on A e = b, A = I + rho D^T D (include/pytv4d.h): out = [add +] x + alpha (b - A x) + beta (x - y);
+// dots[0] = |b - A x|^2, dots[1] = |out - ref|^2 (ref given) or |x|^2.  No scalar of the recurrence depends on the vectors: a
+// sharded solve needs halo planes only, no all-reduce.
+int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, const void* b, const void* y,
+                 const void* add, const void* ref, double alpha, double beta, void* out, double* dots, void* ws, void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (x == nullptr || b == nullptr || out == nullptr || dots == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
+    if (out == x || out == y || out == b || out == add || out == ref) return fail(TV_E_ARG, "out must not alias an input");
+    const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
+    if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr)))
+        return fail(TV_E_HALO, "tv_cheb_step on a slab needs two halo planes on each interior side");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nmax = max_partials(d);
+    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out, b, y, add, ref, d.wv});
+    double* w0 = (double*)ws;
+    double* w1 = w0 + nmax + kStage + 16;
+    if (env_int("TV_NORMAL_KERNEL", 2) == 2 && tvm::N_stream_ok(g, d, vec)) {
+        long long nb;
+        const tvm::NCheb c{y, add, ref, alpha, beta};
+        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, b, out, nullptr, rho, st, &nb, w0, w1, &c)) return rc;
+        if (int rc = reduce_partials(w0, nb, nmax, dots, st)) return rc;
+        return reduce_partials(w1, nb, nmax, dots + 1, st);
+    }
+    // composition: out <- A x with the operator of this geometry, then one flat pass
+    if (int rc = tv_normal_op(g, x, x_prev, x_next, rho, out, dots, ws, stream)) return rc;
+    TV_FLAT_LAUNCH(k_cheb_combine, g->dtype, nvox(d), ({x, b, y, add, ref, out}), (const T*)x, (const T*)b, (const T*)y, (const T*)add,
+                   (const T*)ref, (T*)out, (T)alpha, (T)beta, w0, w1);
+    HIP_TRY(hipGetLastError());
+    if (int rc = reduce_partials(w0, kFlatBlocks, nmax, dots, st)) return rc;
+    return reduce_partials(w1, kFlatBlocks, nmax, dots + 1, st);
+}
+
+// out = a x + b y (y == NULL: out = a x); *dist2 (or NULL) = |out - ref|^2
+int tv_axpby(const tv_geom* g, double a, const void* x, double b, const void* y, const void* ref, void* out, double* dist2, void* ws,
+             void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (x == nullptr || out == nullptr) return fail(TV_E_ARG, "NULL array");
+    if ((ref != nullptr) != (dist2 != nullptr) || (ref != nullptr && ws == nullptr)) return fail(TV_E_ARG, "ref, dist2 and ws go together");
+    hipStream_t st = (hipStream_t)stream;
+    TV_FLAT_LAUNCH(k_axpby, g->dtype, nvox(d), ({x, y, ref, out}), (T)a, (const T*)x, (T)b, (const T*)y, (const T*)ref, (T*)out, (double*)ws);
+    HIP_TRY(hipGetLastError());
+    if (ref != nullptr) return reduce_partials((double*)ws, kFlatBlocks, max_partials(d), dist2, st);
     return 0;
 }
 

@@ -27,8 +27,55 @@ template <typename T> struct NormalArgsT {
     T rho;
     double* part0;         // per-block partials of the first / second dot product
     double* part1;
+    // Chebyshev step (round 3, tv_cheb_step; needs b): out = [add +] x + alpha (b - A x) + beta (x - y);  y (nullptr: 0), add, ref or nullptr
+    // part0 <- |b - A x|^2, part1 <- |out - ref|^2 (ref given) or |x|^2
+    const T* y;
+    const T* add;
+    const T* ref;
+    T alpha, beta;
+    int cheb;
 };
 using NormalArgs = NormalArgsT<float>;
+
+// epilogue of one site-vector: xm = x, ax = A x there (formed by the caller exactly as before round 3: the dot products of the
+// CG path must not change)
+template <typename T, int V>
+__device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long fo, unsigned voff, const Vec<T, V>& xm, const Vec<T, V>& ax,
+                                            double& acc0, double& acc1) {
+    Vec<T, V> o;
+    if (a.b == nullptr) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            o.v[i] = ax.v[i];
+            acc0 += (double)xm.v[i] * (double)o.v[i];
+            acc1 += (double)xm.v[i] * (double)xm.v[i];
+        }
+    } else if (!a.cheb) {
+        const Vec<T, V> bv = ldu_t<T, V>(a.b + fo, voff);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            o.v[i] = bv.v[i] - ax.v[i];
+            acc0 += (double)o.v[i] * (double)o.v[i];
+            acc1 += (double)xm.v[i] * (double)xm.v[i];
+        }
+        if (a.out2 != nullptr) stu_t<T, V>(a.out2 + fo, voff, o);
+    } else {
+        const Vec<T, V> bv = ldu_t<T, V>(a.b + fo, voff);
+        Vec<T, V> yv = vsplat<T, V>(T(0)), av = vsplat<T, V>(T(0)), rv = xm;
+        if (a.y != nullptr) yv = ldu_t<T, V>(a.y + fo, voff);            // no y: y = 0 (the step after e_0 = 0)
+        if (a.add != nullptr) av = ldu_t<T, V>(a.add + fo, voff);
+        if (a.ref != nullptr) rv = ldu_t<T, V>(a.ref + fo, voff);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const T res = bv.v[i] - ax.v[i];
+            o.v[i] = av.v[i] + ((xm.v[i] + a.alpha * res) + a.beta * (xm.v[i] - yv.v[i]));
+            acc0 += (double)res * (double)res;
+            const double e = (a.ref != nullptr) ? (double)o.v[i] - (double)rv.v[i] : (double)xm.v[i];
+            acc1 += e * e;
+        }
+    }
+    stu_t<T, V>(a.out + fo, voff, o);
+}
 
 constexpr int NS_TWN = 8;
 
@@ -184,25 +231,10 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG
                 // ---- epilogue of plane z-1 --------------------------------------------------------------------------------
                 if (!ok || z == zs) continue;
                 const long long fo = (long long)(z - 1) * g.s_z + foff(t);
-                VT o;
-                if (a.b == nullptr) {
+                VT ax;
 #pragma unroll
-                    for (int i = 0; i < V; ++i) {
-                        o.v[i] = xm.v[i] + a.rho * rfin.v[i];
-                        acc0 += (double)xm.v[i] * (double)o.v[i];
-                        acc1 += (double)xm.v[i] * (double)xm.v[i];
-                    }
-                } else {
-                    const VT bv = ldu_t<T, V>(a.b + fo, voff);
-#pragma unroll
-                    for (int i = 0; i < V; ++i) {
-                        o.v[i] = bv.v[i] - (xm.v[i] + a.rho * rfin.v[i]);
-                        acc0 += (double)o.v[i] * (double)o.v[i];
-                        acc1 += (double)xm.v[i] * (double)xm.v[i];
-                    }
-                    if (a.out2 != nullptr) stu_t<T, V>(a.out2 + fo, voff, o);
-                }
-                stu_t<T, V>(a.out + fo, voff, o);
+                for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * rfin.v[i];
+                ns_epilogue<T, V>(a, fo, voff, xm, ax, acc0, acc1);
             }
         }
     }
@@ -357,25 +389,10 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_ce
                     E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu2(pn + foff(t), eoff) : F2{0.f, 0.f};
                     if (!ok || z == zfirst) continue;
                     const long long fo = (long long)(z - 2) * g.s_z + foff(t);
-                    F4 o;
-                    if (a.b == nullptr) {
+                    F4 ax;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            o.v[i] = xm.v[i] + a.rho * (0.25f * rfin.v[i]);
-                            acc0 += (double)xm.v[i] * (double)o.v[i];
-                            acc1 += (double)xm.v[i] * (double)xm.v[i];
-                        }
-                    } else {
-                        const F4 bv = ldu(a.b + fo, voff);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            o.v[i] = bv.v[i] - (xm.v[i] + a.rho * (0.25f * rfin.v[i]));
-                            acc0 += (double)o.v[i] * (double)o.v[i];
-                            acc1 += (double)xm.v[i] * (double)xm.v[i];
-                        }
-                        if (a.out2 != nullptr) stu(a.out2 + fo, voff, o);
-                    }
-                    stu(a.out + fo, voff, o);
+                    for (int i = 0; i < 4; ++i) ax.v[i] = xm.v[i] + a.rho * (0.25f * rfin.v[i]);
+                    ns_epilogue<float, 4>(a, fo, voff, xm, ax, acc0, acc1);
                 }
             }
         }

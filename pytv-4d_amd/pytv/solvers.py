@@ -37,6 +37,31 @@ def cp_step_size(nz_global, m, reg_z_over_reg, reg_time, time_weight_max=1.0):
     return 1.0 / (1.0 + 4.0 * (2.0 + (reg_z_over_reg if z else 0.0) + (reg_time * time_weight_max if t else 0.0)))
 
 
+def normal_spectral_bound(scheme, nz_global, m, reg_z_over_reg, reg_time, time_weight_max=1.0):
+    """L >= lambda_max(D^T D): 4 per one-sided difference axis (1 per halved central one) times the square of the axis weight;
+    hybrid is the mean of the two one-sided operators.  1 / (1 + L) is cp_step_size for the one-sided schemes."""
+    z = nz_global > 1 and reg_z_over_reg > 0
+    t = m > 1 and reg_time > 0
+    s = 2.0 + (reg_z_over_reg if z else 0.0) + (reg_time * time_weight_max if t else 0.0)
+    return (1.0 if scheme == "central" else 4.0) * s
+
+
+def chebyshev_coefficients(lmax, n):
+    """(alpha_k, beta_k), k = 0 .. n-1, of e_{k+1} = e_k + alpha_k (b - A e_k) + beta_k (e_k - e_{k-1}), e_0 = e_{-1} = 0, for a
+    symmetric A with spectrum in [1, lmax] (Saad, Iterative Methods for Sparse Linear Systems, alg. 12.1 as a three-term
+    recurrence).  The scalars depend on the interval only: no dot product, no all-reduce."""
+    theta, delta = 0.5 * (lmax + 1.0), 0.5 * (lmax - 1.0)
+    if delta <= 1e-14 * theta:
+        return [(1.0 / theta, 0.0)] * n
+    sigma = theta / delta
+    out, rho_prev = [(1.0 / theta, 0.0)], 1.0 / sigma
+    for _ in range(1, n):
+        rho_k = 1.0 / (2.0 * sigma - rho_prev)
+        out.append((2.0 * rho_k / delta, rho_k * rho_prev))
+        rho_prev = rho_k
+    return out[:n]
+
+
 class _SlabProblem:
     """Common state: local slab geometry (and sub-slab geometries for interior / edge launches)."""
 
@@ -619,10 +644,22 @@ class ADMM(_SlabProblem):
     oracle.admm restates both."""
 
     def __init__(self, x0, regularization, rho, n_cg=10, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=False):
+                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=False, x_solver="cg"):
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.reg, self.rho, self.n_cg = float(regularization), float(rho), int(n_cg)
         self.single = bool(single_reduction)
+        # x_solver="chebyshev" (round 3): n_cg steps of the Chebyshev iteration on (I + rho D^T D) e = b - A x instead of CG.  Its
+        # scalars follow from the spectral interval [1, 1 + rho L] alone, so a step is ONE streaming kernel (tv_cheb_step: e_k with
+        # its stencil, r0 and e_{k-1} read, e_{k+1} written -- 4 words per voxel where a CG step moves 11) and a sharded solve
+        # exchanges halo planes only: no all-reduce.  Same convergence as CG on this operator within the digits the loss is
+        # reported to (the spectrum of D^T D fills its interval); oracle.admm(x_solver="chebyshev") restates it.
+        if x_solver not in ("cg", "chebyshev"):
+            raise ValueError("x_solver must be 'cg' or 'chebyshev'")
+        self.cheb = (x_solver == "chebyshev")
+        if self.cheb and not (self.single and self.n_cg > 0):
+            raise ValueError("x_solver='chebyshev' needs single_reduction=True (the default) and n_cg > 0")
+        L = normal_spectral_bound(scheme, self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time, self.geo.time_weight_max)
+        self._cheb_coef = chebyshev_coefficients(1.0 + self.rho * L, self.n_cg) if self.cheb else None
         # one-sweep dual side (round 3): z / u update + the residual of the next x-solve in one pass over u
         # (tv_admm_fused + tv_admm_fixup: 2 Nd + 3 words per voxel instead of the 4 Nd + 6 of tv_admm_tu + tv_DT_axpy +
         # tv_normal_op2).  keep_z=False stores only the samples of t' = (z - u) - D x the fix-up reads (2 Nd -> Nd + 0.3
@@ -701,6 +738,49 @@ class ADMM(_SlabProblem):
             self._normal_range(v, out, 0, nz, hp, hn, dots, rhs, out2)
         if reduce:
             self.slab.allreduce_sum_(dots)
+
+    def _cheb_range(self, v, y, add, ref, out, alpha, beta, a, b, hp, hn, dots):
+        g = self.geom(a, b)
+        sl = lambda t_: _nv.ptr(t_[a:b]) if t_ is not None else None      # noqa: E731
+        _nv.check(self.lib.tv_cheb_step(g.ref, _nv.ptr(v[a:b]), _nv.ptr(hp), _nv.ptr(hn), self.rho, _nv.ptr(self.r[a:b]), sl(y), sl(add),
+                                        sl(ref), alpha, beta, _nv.ptr(out[a:b]), dots.data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def _cheb_step(self, v, y, add, ref, out, alpha, beta, dots):
+        """out = [add +] v + alpha (r - A v) + beta (v - y) on the slab; the two-plane halo exchange of v hides behind the interior
+        planes exactly as in _normal; dots <- [|r - A v|^2, |out - ref|^2 or |v|^2] summed over the launches (local)."""
+        nz = self.slab.nz
+        if self.sh and nz >= 5:
+            h = self.plan.exchange_image2(v, self.h2_prev, self.h2_next)
+            self._cheb_range(v, y, add, ref, out, alpha, beta, 2, nz - 2, v[0:2], v[nz - 2:nz], self.dots3[0])
+            self.slab.wait(h)
+            self._cheb_range(v, y, add, ref, out, alpha, beta, 0, 2, self.h2_prev, v[2:4], self.dots3[1])
+            self._cheb_range(v, y, add, ref, out, alpha, beta, nz - 2, nz, v[nz - 4:nz - 2], self.h2_next, self.dots3[2])
+            torch.sum(self.dots3, dim=0, out=dots)
+        else:
+            hp, hn = self._halo2(v)
+            self._cheb_range(v, y, add, ref, out, alpha, beta, 0, nz, hp, hn, dots)
+
+    def _solve_cheb(self, fid_slot):
+        """x <- x + e_K, e_K = K Chebyshev steps on A e = r (self.r = b - A x); fid_slot <- |x - x0|^2 (local)."""
+        g, lib, K, coef = self.geo, self.lib, self.n_cg, self._cheb_coef
+        bufs = [self.d, self.Ad, self.b]                  # all free between two solves
+        a0 = coef[0][0]
+        if K == 1:
+            _nv.check(lib.tv_axpby(g.ref, a0, _nv.ptr(self.r), 1.0, _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(bufs[0]),
+                                   fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
+            last = 0
+        else:
+            _nv.check(lib.tv_axpby(g.ref, a0, _nv.ptr(self.r), 0.0, None, None, _nv.ptr(bufs[0]), None, None, self.stream))     # e_1
+            for k in range(1, K):
+                fin = (k + 1 == K)
+                alpha, beta = coef[k]
+                self._cheb_step(bufs[(k - 1) % 3], bufs[(k - 2) % 3] if k >= 2 else None, self.x if fin else None,
+                                self.x0 if fin else None, bufs[k % 3], alpha, beta, self.dots)
+            fid_slot.copy_(self.dots[1:2])
+            last = (K - 1) % 3
+        # the new image was written next to the old one: swap the roles (the old x becomes a scratch vector)
+        self.x, bufs[last] = bufs[last], self.x
+        self.d, self.Ad, self.b = bufs
 
     def _rhs(self):
         """b = x0 + rho D^T (z - u); the boundary planes of (z - u) travel to the neighbours first."""
@@ -788,6 +868,14 @@ class ADMM(_SlabProblem):
             self._normal(self.x, self.r, self.dots, rhs=self.b, reduce=False)
             sc[0:1].copy_(self.dots[0:1])
         # (one-sweep path: r and gamma were left by the sweep that closed the previous outer iteration)
+        if self.cheb:
+            self._solve_cheb(out[1:2])
+            if self.fused:
+                self._zu_fused(out[0:1])
+            else:
+                self._zu(out[0:1])
+            return
+        sc, w, sv = self.sc, self.b, self.Ad          # (b may have been rebound by an earlier Chebyshev solve: take it again)
         self._normal(self.r, w, self.dots, reduce=False)
         sc[1:2].copy_(self.dots[0:1])
         sc[2:4].zero_()                               # alpha_old = 0: first step of this solve

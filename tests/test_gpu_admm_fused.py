@@ -129,3 +129,107 @@ def test_admm_fused_equals_kernel_trio(scheme):
     np.testing.assert_allclose(c.z.cpu().numpy(), b.z.cpu().numpy(), rtol=0, atol=2e-3)
     assert c.z.abs().max().item() > 1.0
     assert la[-1] < la[0]
+
+
+# ------------------------------------------------------------------------------------------------
+# Chebyshev x-solve (tv_cheb_step, tv_axpby; solvers.ADMM(x_solver="chebyshev"))
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape", SHAPES + [(5, 3, 8, 12), (7, 2, 6, 70)])          # the last two: the composed fallback (ragged Nx)
+def test_cheb_step_matches_numpy(nvlib, scheme, shape):
+    """out = add + x + alpha (b - A x) + beta (x - y) and its two reductions against NumPy over the oracle's D / D^T; the streaming
+    kernels (fp32 all schemes, fp64 one-sided schemes) and the composition of tv_normal_op with one flat pass (everything else)."""
+    import torch
+    nv, lib = nvlib, nvlib.lib()
+    rng = np.random.default_rng(21)
+    kw = dict(reg_z_over_reg=1.3, reg_time=0.6)
+    rho, alpha, beta = 0.15, 0.8, 0.3
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 3e-5)):
+        x, y, b, add, ref = [(rng.standard_normal(shape) * 3).astype(dtype) for _ in range(5)]
+        x64 = x.astype(np.float64)
+        ax = x64 + rho * orc.D_T(orc.D(x64, scheme, **kw), scheme, **kw)
+        res = b - ax
+        g = nv.Geometry(shape, scheme, torch.as_tensor(x).dtype, torch.device("cuda", 0), **kw)
+        st, ws = nv.current_stream(torch.device("cuda", 0)), g.workspace()
+        xd, yd, bd, addd, refd = [torch.as_tensor(v).cuda() for v in (x, y, b, add, ref)]
+        for use_y, use_add, use_ref in ((True, True, True), (False, False, False), (True, False, False)):
+            want = x64 + alpha * res + beta * (x64 - (y if use_y else 0.0)) + (add if use_add else 0.0)
+            od = torch.empty_like(xd)
+            sc = torch.zeros(2, dtype=torch.float64, device="cuda")
+            nv.check(lib.tv_cheb_step(g.ref, nv.ptr(xd), None, None, rho, nv.ptr(bd), nv.ptr(yd) if use_y else None,
+                                      nv.ptr(addd) if use_add else None, nv.ptr(refd) if use_ref else None, alpha, beta, nv.ptr(od),
+                                      sc.data_ptr(), nv.ptr(ws), st))
+            scale = max(1.0, np.abs(want).max())
+            np.testing.assert_allclose(od.cpu().numpy(), want, rtol=0, atol=tol * 10 * scale)
+            s_ = sc.cpu().numpy()
+            np.testing.assert_allclose(s_[0], np.sum(res * res), rtol=tol * 100)
+            np.testing.assert_allclose(s_[1], np.sum((want - ref) ** 2) if use_ref else np.sum(x64 * x64), rtol=tol * 100)
+        # tv_axpby
+        od = torch.empty_like(xd)
+        sc = torch.zeros(1, dtype=torch.float64, device="cuda")
+        nv.check(lib.tv_axpby(g.ref, 0.7, nv.ptr(xd), -1.3, nv.ptr(yd), nv.ptr(refd), nv.ptr(od), sc.data_ptr(), nv.ptr(ws), st))
+        want = 0.7 * x64 - 1.3 * y
+        np.testing.assert_allclose(od.cpu().numpy(), want, rtol=0, atol=tol * 10)
+        np.testing.assert_allclose(sc.item(), np.sum((want - ref) ** 2), rtol=tol * 100)
+        nv.check(lib.tv_axpby(g.ref, 0.5, nv.ptr(xd), 0.0, None, None, nv.ptr(od), None, None, st))
+        np.testing.assert_allclose(od.cpu().numpy(), 0.5 * x64, rtol=0, atol=tol)
+
+
+def test_chebyshev_coefficients_and_bound():
+    """The recurrence of pytv.solvers restates the oracle's; the bound L really bounds D^T D (power iteration on the oracle)."""
+    import pytv
+    for lmax in (1.0, 1.8, 17.0):
+        a = pytv.solvers.chebyshev_coefficients(lmax, 6)
+        b = orc.chebyshev_coefficients(lmax, 6)
+        np.testing.assert_allclose(a, b, rtol=1e-15)
+    rng = np.random.default_rng(3)
+    shape, kw = (4, 3, 10, 12), dict(reg_z_over_reg=1.5, reg_time=0.7)
+    for scheme in SCHEMES:
+        v = rng.standard_normal(shape)
+        for _ in range(150):
+            w = orc.D_T(orc.D(v, scheme, **kw), scheme, **kw)
+            lam = np.linalg.norm(w) / np.linalg.norm(v)
+            v = w / np.linalg.norm(w)
+        L = pytv.solvers.normal_spectral_bound(scheme, shape[0], shape[1], kw["reg_z_over_reg"], kw["reg_time"])
+        assert L == orc.normal_spectral_bound(scheme, shape, **kw)
+        assert lam <= L and lam > 0.6 * L
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("shape,lz,mu", [((1, 1, 24, 64), 1.0, 0.0), ((5, 3, 16, 64), 1.5, 0.5), ((3, 10, 9, 128), 1.0, 0.7), ((5, 3, 8, 12), 1.5, 0.5)])
+def test_admm_chebyshev_matches_oracle(scheme, shape, lz, mu):
+    """ADMM with the Chebyshev x-solve (one-sweep dual side where the geometry allows, the kernel trio otherwise) against the
+    oracle's restatement; and it reaches the objective of the CG variant (same number of steps) to 1e-5."""
+    import torch
+    import pytv
+    rng = np.random.default_rng(6)
+    reg, rho = 4.0, 0.1
+    for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-6, 2e-4)):
+        x0 = (rng.random(shape) * 100).astype(dtype)
+        for n_cg in (1, 2, 5):
+            wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 6, reg, rho, n_cg, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+                                         x_solver="chebyshev", return_state=True)
+            for fused in ((True, False) if shape[-1] >= 64 else (False,)):
+                ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), reg, rho, n_cg=n_cg, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
+                                       x_solver="chebyshev", fused=fused, keep_z=True)
+                loss = ad.run(6)
+                np.testing.assert_allclose(loss, wloss, rtol=rtol / 2, err_msg="%s %s n_cg=%d fused=%s" % (scheme, shape, n_cg, fused))
+                np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
+                np.testing.assert_allclose(ad.z.cpu().numpy(), wz, rtol=rtol * 10, atol=atol * 3)
+                np.testing.assert_allclose(ad.u.cpu().numpy(), wu, rtol=rtol * 10, atol=atol * 3)
+        _, closs = orc.admm(x0.astype(np.float64), 6, reg, rho, 5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu, single_reduction=True)
+        np.testing.assert_allclose(wloss[-1], closs[-1], rtol=1e-5)
+
+
+@pytest.mark.parametrize("scheme", ["hybrid", "central"])
+def test_admm_chebyshev_graph_replay_equals_eager(scheme):
+    import torch
+    import pytv
+    rng = np.random.default_rng(6)
+    x0 = torch.as_tensor((rng.random((1, 1, 96, 128)) * 100).astype(np.float32)).cuda()
+    a = pytv.solvers.ADMM(x0, 4.0, 0.1, n_cg=3, scheme=scheme, x_solver="chebyshev")
+    b = pytv.solvers.ADMM(x0, 4.0, 0.1, n_cg=3, scheme=scheme, x_solver="chebyshev")
+    la, lb = a.run(19, graph=True), b.run(19, graph=False)
+    assert np.array_equal(la, lb)
+    assert torch.equal(a.result(), b.result())
+    assert la[-1] < la[0]

@@ -63,6 +63,9 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
             ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, **kw)
             out["ad_loss"] = ad.run(3)
             out["ad_x"] = ad.result().cpu().numpy()
+            ac = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, slab=slab, x_solver="chebyshev", **kw)      # no all-reduce in the x-solve
+            out["ac_loss"] = ac.run(3)
+            out["ac_x"] = ac.result().cpu().numpy()
         # data-fidelity operator slot on a slab: a diagonal operator (local to the slab), TV part with halos
         a_full = 0.2 + 0.8 * np.random.default_rng(92).random(shape)
         at = torch.as_tensor(slab.local(a_full).astype(np.float32).copy()).cuda()
@@ -131,3 +134,8 @@ def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, z
             np.testing.assert_allclose(ret[r]["sg_x"], sx[z0:z0 + nz], rtol=1e-5, atol=2e-3)
             np.testing.assert_allclose(ret[r]["ad_loss"], aloss, rtol=1e-6)          # ~10 x measured: profiles/r3_admm_tolerances.txt
             np.testing.assert_allclose(ret[r]["ad_x"], ax[z0:z0 + nz], rtol=2e-6, atol=2e-4)
+        cx, closs = orc.admm(x0, 3, 7.0, 0.1, 4, scheme=scheme, x_solver="chebyshev", **kw)
+        for r in range(world):
+            z0, nz = ret[r]["z"]
+            np.testing.assert_allclose(ret[r]["ac_loss"], closs, rtol=1e-6)
+            np.testing.assert_allclose(ret[r]["ac_x"], cx[z0:z0 + nz], rtol=2e-6, atol=2e-4)

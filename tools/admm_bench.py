@@ -13,7 +13,8 @@ V = x0.numel()
 print("ADMM on %s (V = %.0f Mvox), %d CG steps per outer iteration, rho = 0.05, lambda = 25" % (shape, V / 1e6, n_cg))
 for scheme in ("upwind", "downwind", "central", "hybrid"):
     # one-sweep dual side (round 3, sparse / full storage of t'), the kernel trio it replaces, the textbook recurrence
-    for name, kw in (("one-sweep", dict(fused=True)), ("one-sweep keep_z", dict(fused=True, keep_z=True)),
+    for name, kw in (("one-sweep+chebyshev", dict(fused=True, x_solver="chebyshev")), ("one-sweep", dict(fused=True)),
+                     ("one-sweep keep_z", dict(fused=True, keep_z=True)),
                      ("single-reduction", dict(fused=False)), ("textbook CG", dict(single_reduction=False))):
         if os.environ.get("ONLY") and os.environ["ONLY"] != name:          # ONLY=<exact name>: one variant (profiling)
             continue
@@ -27,9 +28,11 @@ for scheme in ("upwind", "downwind", "central", "hybrid"):
         # updates (9; the first 7; the last +1 for x0) + t/u update (1 + 3 Nd) = 4 Nd + 11 n_cg + 5; textbook: rhs (2 Nd + 2) +
         # residual with the copy (4) + n_cg (normal op 2, cg1 6, cg2 3) + z/u (1 + 3 Nd) + fidelity (sub 3 + dot 2);
         # one-sweep: sweep (x, x0 read, r written, u read + written: 2 Nd + 3; + Nd with keep_z) + n_cg (2 + 9) - 1
-        words = {"one-sweep": 2 * nd + 11 * n_cg + 2, "one-sweep keep_z": 3 * nd + 11 * n_cg + 2, "single-reduction": 4 * nd + 11 * n_cg + 5,
+        # + chebyshev: the x-solve is e_1 = a r (2), n_cg - 2 steps of 4 (e_k with its stencil, r, e_{k-1} read; e_{k+1} written) and a
+        # last step of 6 (+ x read, x0 read; the new x written instead of e): 4 n_cg words
+        words = {"one-sweep+chebyshev": 2 * nd + 3 + 4 * n_cg, "one-sweep": 2 * nd + 11 * n_cg + 2, "one-sweep keep_z": 3 * nd + 11 * n_cg + 2, "single-reduction": 4 * nd + 11 * n_cg + 5,
                  "textbook CG": 5 * nd + 11 * n_cg + 12}[name]
-        print("%-9s Nd=%d %-16s %.2f ms/outer  %.1f it/s  loss %.6e -> %.6e  | algorithmic %.0f words/voxel -> %.0f GB/s" % (
+        print("%-9s Nd=%d %-19s %.2f ms/outer  %.1f it/s  loss %.6e -> %.6e  | algorithmic %.0f words/voxel -> %.0f GB/s" % (
             scheme, nd, name, dt * 1e3, 1 / dt, loss[0], loss[-1], words, words * 4.0 * V / dt / 1e9))
         del ad
         torch.cuda.empty_cache()
