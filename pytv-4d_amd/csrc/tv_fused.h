@@ -41,6 +41,9 @@ using F4 = Vec<float, 4>;
 #ifndef TV_FUSED_NW
 #define TV_FUSED_NW 8
 #endif
+#ifndef TV_FUSED_PFQ_TWIN
+#define TV_FUSED_PFQ_TWIN 1      // the central dual prefetch (PFQ) in the windowed (M > 8) instantiations too (round 3)
+#endif
 #ifndef TV_FUSED_PFQ
 #define TV_FUSED_PFQ 1
 #endif
@@ -335,13 +338,13 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
     // so its waves waited ~77 % of the time with too few bytes in flight: sweep 26.6 - 27.4 -> 21.2 - 23.0 ms on the
     // north-star volume (0.52 -> 0.63 of peak; profiles/r2_ab_pfq.txt).  Measured for upwind / downwind too: 3 - 7 % SLOWER
     // there (they already request plane z+1 of x a step ahead), so it stays off; hybrid has no registers for it.
-    constexpr bool PFQ = (TV_FUSED_PFQ != 0) && (S == CENTRAL) && !TWIN;
+    constexpr bool PFQ = (TV_FUSED_PFQ != 0) && (S == CENTRAL) && (!TWIN || TV_FUSED_PFQ_TWIN != 0);
     VT qpre[PFQ ? 4 : 1];
     if (PFQ) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) qpre[k] = zero;
         if (c.ok) {
-            const T* qb0 = a.q + (long long)c.zs * g.s_dz;
+            const T* qb0 = a.q + (long long)c.zs * g.s_dz + (long long)t0 * g.s_t;
             for_each_channel<S>(g, [&](auto slot, int ch) {
                 constexpr int k = decltype(slot)::value;
                 qpre[k & 3] = ldu_s_t<T, V>(qb0 + (long long)ch * g.s_z, voff);
@@ -456,9 +459,10 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
             if (PFQ) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) qcur[k] = qpre[k];
-                const int tn = (t + 1 < M) ? t + 1 : 0, zn = (t + 1 < M) ? z : z + 1;
+                const bool wrap = (t + 1 >= M) || (TWIN && t0 + t + 1 >= Mg);         // the window's last frame: on to the next plane
+                const int tn = wrap ? 0 : t + 1, zn = wrap ? z + 1 : z;
                 if (c.ok && zn < c.ze) {
-                    const T* qbn = a.q + (long long)zn * g.s_dz + (long long)tn * g.s_t;
+                    const T* qbn = a.q + (long long)zn * g.s_dz + (long long)(t0 + tn) * g.s_t;
                     for_each_channel<S>(g, [&](auto slot, int ch) {
                         constexpr int k = decltype(slot)::value;
                         qpre[k & 3] = ldu_s_t<T, V>(qbn + (long long)ch * g.s_z, voff);
