@@ -80,7 +80,7 @@ constexpr int ST_BR = 4 * ST_NWY;        // rows per block tile
 // (tile, chunk, window) ids.  TWIN: the block works on frames [t0, t0 + M) of a volume with more than 8 frames and reads
 // the x frame on either side of its window for the time differences (M == DS_TWN).
 template <int S, int M, bool TWIN, typename T = float>
-__global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || (S == HYBRID && M >= 8)) ? 2 : 3) void k_D_stream(DG g, WT<T> w, const T* __restrict__ x,
+__global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || M >= 8) ? 2 : 3) void k_D_stream(DG g, WT<T> w, const T* __restrict__ x,
                                                                        const T* __restrict__ xp, const T* __restrict__ xn,
                                                                        T* __restrict__ d, int zchunk, int nchunks) {
     constexpr int V = 16 / (int)sizeof(T);          // columns per lane (16-byte lanes): 4 floats / 2 doubles

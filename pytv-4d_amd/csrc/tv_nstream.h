@@ -37,29 +37,14 @@ template <typename T> struct NormalArgsT {
 };
 using NormalArgs = NormalArgsT<float>;
 
-// epilogue of one site-vector: xm = x, ax = A x there (formed by the caller exactly as before round 3: the dot products of the
-// CG path must not change)
-template <typename T, int V>
+// epilogue of one site-vector: xm = x, ax = A x there.  CHEB is a TEMPLATE parameter: as a run-time branch in the same kernel the
+// Chebyshev form cost the CG instantiations 35 % (tv_normal_op 0.95 -> 1.30 ms at 64x8x1024x1024: the extra pointers and the
+// branch sit in the hot loop of a kernel that is at its register limit).
+template <typename T, int V, bool CHEB>
 __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long fo, unsigned voff, const Vec<T, V>& xm, const Vec<T, V>& ax,
                                             double& acc0, double& acc1) {
     Vec<T, V> o;
-    if (a.b == nullptr) {
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            o.v[i] = ax.v[i];
-            acc0 += (double)xm.v[i] * (double)o.v[i];
-            acc1 += (double)xm.v[i] * (double)xm.v[i];
-        }
-    } else if (!a.cheb) {
-        const Vec<T, V> bv = ldu_t<T, V>(a.b + fo, voff);
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-            o.v[i] = bv.v[i] - ax.v[i];
-            acc0 += (double)o.v[i] * (double)o.v[i];
-            acc1 += (double)xm.v[i] * (double)xm.v[i];
-        }
-        if (a.out2 != nullptr) stu_t<T, V>(a.out2 + fo, voff, o);
-    } else {
+    if constexpr (CHEB) {
         const Vec<T, V> bv = ldu_t<T, V>(a.b + fo, voff);
         Vec<T, V> yv = vsplat<T, V>(T(0)), av = vsplat<T, V>(T(0)), rv = xm;
         if (a.y != nullptr) yv = ldu_t<T, V>(a.y + fo, voff);            // no y: y = 0 (the step after e_0 = 0)
@@ -73,6 +58,22 @@ __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long f
             const double e = (a.ref != nullptr) ? (double)o.v[i] - (double)rv.v[i] : (double)xm.v[i];
             acc1 += e * e;
         }
+    } else if (a.b == nullptr) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            o.v[i] = ax.v[i];
+            acc0 += (double)xm.v[i] * (double)o.v[i];
+            acc1 += (double)xm.v[i] * (double)xm.v[i];
+        }
+    } else {
+        const Vec<T, V> bv = ldu_t<T, V>(a.b + fo, voff);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            o.v[i] = bv.v[i] - ax.v[i];
+            acc0 += (double)o.v[i] * (double)o.v[i];
+            acc1 += (double)xm.v[i] * (double)xm.v[i];
+        }
+        if (a.out2 != nullptr) stu_t<T, V>(a.out2 + fo, voff, o);
     }
     stu_t<T, V>(a.out + fo, voff, o);
 }
@@ -110,7 +111,7 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> ns_sub(const V
     return r;
 }
 
-template <int M, bool TWIN, typename T = float>
+template <int M, bool TWIN, typename T = float, bool CHEB = false>
 __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
     constexpr int V = 16 / (int)sizeof(T);          // columns per 16-byte lane: 4 floats / 2 doubles (round 3)
     using VT = Vec<T, V>;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG
                 VT ax;
 #pragma unroll
                 for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * rfin.v[i];
-                ns_epilogue<T, V>(a, fo, voff, xm, ax, acc0, acc1);
+                ns_epilogue<T, V, CHEB>(a, fo, voff, xm, ax, acc0, acc1);
             }
         }
     }
@@ -271,7 +272,7 @@ __device__ __forceinline__ F2 ldu2(const float* ubase, unsigned voff) {
     return F2{v.x, v.y};
 }
 
-template <int M, bool TWIN>
+template <int M, bool TWIN, bool CHEB = false>
 __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_ce
                     F4 ax;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ax.v[i] = xm.v[i] + a.rho * (0.25f * rfin.v[i]);
-                    ns_epilogue<float, 4>(a, fo, voff, xm, ax, acc0, acc1);
+                    ns_epilogue<float, 4, CHEB>(a, fo, voff, xm, ax, acc0, acc1);
                 }
             }
         }

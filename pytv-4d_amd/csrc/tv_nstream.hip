@@ -44,11 +44,17 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
                  (const float*)c.y, (const float*)c.add, (const float*)c.ref, (float)c.alpha, (float)c.beta, cheb ? 1 : 0};
     NormalArgsT<double> ad{(const double*)x, (const double*)xp, (const double*)xn, (const double*)b, (double*)out, (double*)out2, rho, part0, part1,
                            (const double*)c.y, (const double*)c.add, (const double*)c.ref, c.alpha, c.beta, cheb ? 1 : 0};
+#define TV_NS_LAUNCH1(MM, TW, CH)                                                                                       \
+    do {                                                                                                               \
+        if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
+        else if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH>), grid, block, 0, st, d, w, a, zc, (int)nch); \
+        else hipLaunchKernelGGL((k_normal_stream<MM, TW, float, CH>), grid, block, 0, st, d, w, a, zc, (int)nch);       \
+    } while (0)
+    // the Chebyshev epilogue is its own instantiation (tv_nstream.h, ns_epilogue)
 #define TV_NS_LAUNCH(MM, TW)                                                                                            \
     do {                                                                                                               \
-        if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
-        else if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW>), grid, block, 0, st, d, w, a, zc, (int)nch); \
-        else hipLaunchKernelGGL((k_normal_stream<MM, TW, float>), grid, block, 0, st, d, w, a, zc, (int)nch);           \
+        if (cheb) TV_NS_LAUNCH1(MM, TW, true);                                                                         \
+        else TV_NS_LAUNCH1(MM, TW, false);                                                                             \
     } while (0)
     switch (d.m > NS_TWN ? 0 : d.m) {
         case 0: TV_NS_LAUNCH(NS_TWN, true); break;
@@ -62,6 +68,7 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
         default: TV_NS_LAUNCH(8, false); break;
     }
 #undef TV_NS_LAUNCH
+#undef TV_NS_LAUNCH1
     HIP_TRY(hipGetLastError());
     return 0;
 }
