@@ -15,7 +15,6 @@ int tv_subgrad_fused(const tv_geom* g, const void* x, const void* x_prev, const 
 int tv_subgrad_fused_norms(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, void* norms,
                            double* tvout, void* ws, void* stream) {
     if (G == nullptr || norms == nullptr) return fail(TV_E_ARG, "NULL array");
-    if (!aligned16({norms})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     SgHostArgs sa{};
     sa.norms = norms;
     return sg_launch<2>(g, x, x_prev, x_next, G, tvout, nullptr, ws, stream, sa,

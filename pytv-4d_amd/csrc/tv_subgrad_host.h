@@ -13,8 +13,11 @@ inline int sg_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d)) return 0;
     if (!sg_m_ok(d.m)) return 0;
-    if (g->dtype == TV_F32 ? (d.nx % 4 != 0) : (d.nx % 2 != 0 || env_int("TV_SG_KERNEL", 2) == 1)) return 0;   // fp64: round-3 kernel only
-    if (g->dtype == TV_F64 && d.s_t * 8 >= (1ll << 31)) return 0;
+    // the round-3 kernel holds ONE column per lane (4- / 8-byte buffer loads): any Nx, any element-aligned pointer (late round 3;
+    // before, ragged Nx took the two-pass path at 0.11 - 0.17 of the roofline).  The round-1 kernel (TV_SG_KERNEL=1, frames of
+    // 2^31 bytes and more) is fp32 with 16-byte lanes.
+    const bool k2 = env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * (g->dtype == TV_F32 ? 4 : 8) < (1ll << 31);
+    if (!k2 && (g->dtype != TV_F32 || d.nx % 4 != 0)) return 0;
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return 0;   // two-point axes: forward stencil
     if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
     if (d.m > SG_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
@@ -138,7 +141,7 @@ inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const 
     if (int rc = make_dg(g, d)) return rc;
     if (x == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!sg_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-pass sub-gradient");
-    if (!aligned16({x, x_prev, x_next, G, ha.x0, ha.x_out})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    const bool vec16 = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, G, ha.x0, ha.x_out, ha.norms});      // what the round-1 kernel needs
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
     if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr))) return fail(TV_E_HALO, who);
     hipStream_t st = (hipStream_t)stream;
@@ -152,6 +155,7 @@ inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const 
     if (env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * 4 < (1ll << 31) && step_ok)
         return sg2_launch<float, MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
     if (d.wv != nullptr) return fail(TV_E_ARG, "a weight volume needs the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad");
+    if (!vec16) return fail(TV_E_ARG, "ragged Nx / unaligned arrays need the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad + tv_subgrad_step");
     SgStepArgs sa{(const float*)ha.x0, (float*)ha.x_out, (float)ha.step, (float)ha.lambda, nullptr, (float*)ha.norms};
     const long long nmax = max_partials(d);
     constexpr int NW = 4, UR = 4 * NW - 2, UC = 14;

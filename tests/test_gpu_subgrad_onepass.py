@@ -60,6 +60,12 @@ def _one_pass(pytv, x, scheme, **kw):
     ((2, 2, 5, 68), 1.0, 1.0, False),
     ((3, 2, 6, 8), 1.0, 1.0, False),          # frame narrower than a tile
     ((2, 1, 3, 4), 1.0, 0.0, False),
+    # Nx not a multiple of 4 (late round 3: the column-strip kernel holds one column per lane, so any Nx takes the one-pass path)
+    ((3, 3, 17, 67), 1.3, 0.6, True),
+    ((4, 1, 30, 125), 1.0, 0.0, False),
+    ((2, 9, 5, 61), 1.0, 1.0, False),
+    ((5, 2, 9, 7), 1.0, 0.5, False),
+    ((1, 1, 21, 1001), 1.0, 0.0, False),
 ])
 def test_one_pass_matches_oracle_and_two_pass(pytv, scheme, zchunk, shape, lz, mu, use_mask, tvopt):
     import torch
@@ -168,9 +174,7 @@ def test_one_pass_rejects_what_it_does_not_support(pytv):
     lib = nv.lib()
     for shape, scheme, dt, kw in (((2, 1, 8, 64), "central", torch.float32, {}),                       # two-point z axis
                                   ((3, 2, 8, 64), "central", torch.float32, dict(reg_time=1.0)),       # two-point time axis
-                                  ((2, 1, 8, 65), "hybrid", torch.float64, {}), ((2, 1, 8, 66), "hybrid", torch.float32, {}),
-                                  ((2, 1, 8, 7), "downwind", torch.float32, {}),
-                                  ((2, 16, 8, 66), "upwind", torch.float32, {})):
+                                  ):
         g = nv.Geometry(shape, scheme, dt, torch.device("cuda", 0), **kw)
         assert lib.tv_subgrad_fused_supported(g.ref) == 0, (shape, scheme)
         x = torch.zeros(shape, dtype=dt, device="cuda")
@@ -178,9 +182,11 @@ def test_one_pass_rejects_what_it_does_not_support(pytv):
         rc = lib.tv_subgrad_fused(g.ref, nv.ptr(x), None, None, nv.ptr(G), nv.ptr(g.scalar()), nv.ptr(g.workspace()),
                                   nv.current_stream(x.device))
         assert rc < 0
-    # round 3: fp64 has a one-pass kernel of its own (even Nx)
-    g = nv.Geometry((2, 1, 8, 64), "hybrid", torch.float64, torch.device("cuda", 0))
-    assert lib.tv_subgrad_fused_supported(g.ref) == 1
+    # round 3: fp64 has a one-pass kernel of its own, and (late round 3) Nx may be anything, in both dtypes
+    for shape, dt in (((2, 1, 8, 64), torch.float64), ((2, 1, 8, 65), torch.float64), ((2, 1, 8, 66), torch.float32), ((2, 1, 8, 7), torch.float32),
+                      ((2, 16, 8, 66), torch.float32)):
+        g = nv.Geometry(shape, "hybrid", dt, torch.device("cuda", 0), reg_time=1.0)
+        assert lib.tv_subgrad_fused_supported(g.ref) == 1, shape
     # central with a two-point axis that is switched off is fine
     g = nv.Geometry((3, 2, 8, 64), "central", torch.float32, torch.device("cuda", 0), reg_time=0.0)
     assert lib.tv_subgrad_fused_supported(g.ref) == 1

@@ -16,7 +16,7 @@ for case in range(n_cases):
     m = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 16, 19]))
     nz = int(rng.integers(1, 12))
     ny = int(rng.integers(1, 70))
-    nx = 4 * int(rng.integers(1, 80))
+    nx = 4 * int(rng.integers(1, 80)) if case % 3 else int(rng.integers(3, 320))     # every third case: any Nx (late round 3)
     lz = float(rng.choice([0.0, 0.3, 1.0, 2.5])); mu = float(rng.choice([0.0, 2.0 ** -5, 1.0, 1.7]))
     use_mask = bool(rng.random() < 0.3)
     kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=(rng.random((ny, nx)) < 0.4) if use_mask else False,
