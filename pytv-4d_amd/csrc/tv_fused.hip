@@ -89,7 +89,8 @@ static int sweep_plan(const tv_geom* g, const DG& d, const void* x_in, const voi
     // M == 8, hybrid: the windowed instantiation (one window) needs 234 VGPRs and no scratch where the plain one sits at
     // 256 + 8 B/lane, and is 1 ms faster per sweep on the north-star volume (33.7 vs 34.8 ms); the other schemes are
     // 2 % faster with the plain one (measured).  TV_FUSED_FORCE_TWIN=0/1 overrides.
-    sp.force_win = (d.m == CP_TWN) && env_int("TV_FUSED_FORCE_TWIN", g->scheme == TV_HYBRID ? 1 : 0);
+    // central (round 3, once its windowed form had the dual prefetch): 253 VGPRs / no scratch against 256 + 20 B/lane, 22.7 vs 23.5 ms
+    sp.force_win = (d.m == CP_TWN) && env_int("TV_FUSED_FORCE_TWIN", (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL) ? 1 : 0);
     return 0;
 }
 
