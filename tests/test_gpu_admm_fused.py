@@ -233,3 +233,45 @@ def test_admm_chebyshev_graph_replay_equals_eager(scheme):
     assert np.array_equal(la, lb)
     assert torch.equal(a.result(), b.result())
     assert la[-1] < la[0]
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_admm_sweep_and_cheb_step_stay_inside_their_arrays(nvlib, scheme, dtype):
+    """Every array of tv_admm_fused / tv_admm_fixup / tv_cheb_step sits between NaN guard bands: nothing outside is written, and
+    (inputs between NaNs) nothing outside is read into a result."""
+    import torch
+    nv, lib = nvlib, nvlib.lib()
+    shape = (4, 10, 19, 132)                     # ragged in rows, two block tiles in fp64, a time-window seam
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    g = nv.Geometry(shape, scheme, tdt, torch.device("cuda", 0), reg_z_over_reg=1.2, reg_time=0.8)
+    pad = 4100
+    rng = np.random.default_rng(3)
+
+    def guarded(shp, fill=None):
+        n = int(np.prod(shp))
+        buf = torch.full((n + 2 * pad,), float("nan"), device="cuda", dtype=tdt)
+        v = buf[pad:pad + n].view(shp)
+        v.copy_(torch.as_tensor(rng.standard_normal(shp).astype(dtype)).cuda() if fill is None else torch.full(shp, fill, dtype=tdt, device="cuda"))
+        return buf, v
+
+    def bands_intact(buf):
+        return bool(torch.isnan(buf[:pad]).all() and torch.isnan(buf[-pad:]).all())
+
+    st, ws = nv.current_stream(torch.device("cuda", 0)), g.workspace()
+    (xb, x), (x0b, x0), (ub, u), (tb, t), (rb, r) = guarded(shape), guarded(shape), guarded(g.grad_shape), guarded(g.grad_shape, 0.0), guarded(shape, 0.0)
+    sc = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for full in (0, 1):
+        nv.check(lib.tv_admm_fused(g.ref, nv.ptr(x), None, None, nv.ptr(u), nv.ptr(t), nv.ptr(x0), nv.ptr(r), 0.7, 0.15, full, 0, -1,
+                                   sc[0:1].data_ptr(), sc[1:2].data_ptr(), nv.ptr(ws), st))
+        nv.check(lib.tv_admm_fixup(g.ref, nv.ptr(t), None, None, nv.ptr(r), 0.15, 0, -1, sc[2:3].data_ptr(), nv.ptr(ws), st))
+        torch.cuda.synchronize()
+        assert all(bands_intact(b) for b in (xb, x0b, ub, tb, rb))
+        assert bool(torch.isfinite(u).all() and torch.isfinite(t).all() and torch.isfinite(r).all()) and bool(torch.isfinite(sc).all())
+    (yb, y), (ab, a), (ob, o) = guarded(shape), guarded(shape), guarded(shape, 0.0)
+    dots = torch.zeros(2, dtype=torch.float64, device="cuda")
+    nv.check(lib.tv_cheb_step(g.ref, nv.ptr(x), None, None, 0.15, nv.ptr(r), nv.ptr(y), nv.ptr(a), nv.ptr(x0), 0.8, 0.3, nv.ptr(o),
+                              dots.data_ptr(), nv.ptr(ws), st))
+    torch.cuda.synchronize()
+    assert all(bands_intact(b) for b in (xb, rb, yb, ab, x0b, ob))
+    assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(dots).all())
