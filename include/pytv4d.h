@@ -205,6 +205,15 @@ int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const voi
                   void* ws, void* stream);
 int tv_admm_fixup(const tv_geom* g, const void* t, const void* t_prev, const void* t_next, void* r, double rho, int64_t z_begin,
                   int64_t z_count, double* rr, void* ws, void* stream);
+/* One-sweep form of Chambolle-Pock with a data-fidelity operator A (README.md:2,148 with A != I; same geometries as tv_cp_fused):
+ *   tv_cpop_fused : q <- proj(q + sigma_D D x_in);  x_out <- x_in - tau atp - tau D^T q   (atp = A^T p, an image, read only)
+ *                   EXCEPT the adjoint terms tv_cp_fused leaves out;  *tv = |D x_in|_{2,1}
+ *   tv_cpop_fixup : adds those terms to x_out (q_prev / q_next as in tv_DT)
+ * 2 Nd + 4 words per voxel where tv_cp_dual + tv_DT_axpy2 move 3 Nd + 4.  Chunk / plane ranges as in tv_cp_fused / tv_cp_fixup. */
+int tv_cpop_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* atp, void* x_out,
+                  double sigma_D, double lambda, double tau, int64_t chunk_begin, int64_t chunk_count, double* tv, void* ws, void* stream);
+int tv_cpop_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, double tau, int64_t z_begin,
+                  int64_t z_count, void* ws, void* stream);
 /* out = base + alpha * D^T (a - b)   (b and/or base may be NULL).  ab_prev / ab_next: halo planes
  * of (a - b) for the channels named in tv_DT. */
 int tv_DT_axpy2(const tv_geom* g, const void* a, const void* b, const void* ab_prev, const void* ab_next,

@@ -270,7 +270,10 @@ using FusedArgs = FusedArgsT<float>;
 //            layout as q).  Nobody but the fix-up reads t', so by default only the samples the fix-up needs are stored
 //            (tile-edge rows / columns, chunk-edge planes, window-seam frames: ~0.3 words per voxel instead of Nd);
 //            4 Nd + 6 words per voxel of the kernel trio tv_admm_tu + tv_DT_axpy + tv_normal_op2(rhs) become 2 Nd + 3.
-constexpr int ALG_CP = 0, ALG_ADMM = 1;
+//   ALG_CPOP (round 3): Chambolle-Pock with a user-supplied data-fidelity operator A (README.md:2,148; solvers.ChambollePockOperator):
+//            the dual update of ALG_CP and x_out <- x - tau A^T p - tau D^T q' one plane behind; `p` is the image A^T p (read only),
+//            x0 is not touched, the second partial is unused.  Its fix-up is the ALG_ADMM one with the coefficient tau.
+constexpr int ALG_CP = 0, ALG_ADMM = 1, ALG_CPOP = 2;
 
 // XW: the CP_NW waves of a block exchange their tile-edge column terms through LDS (one barrier per plane)
 // TWIN: time windows for volumes with more than CP_TWN frames -- grid z = window, the block works on the frames
@@ -390,6 +393,14 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
             }
             stu_s_t<T, V>(a.x_out + foff, voff, ro);
             if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += r2;
+            return;
+        }
+        if constexpr (ALG == ALG_CPOP) {      // x_out = (x - tau A^T p) - tau D^T q'   (the arithmetic of tv_DT_axpy2)
+            const VT atp = ldu_s_t<T, V>(a.p + foff, voff);
+            VT xo;
+#pragma unroll
+            for (int i = 0; i < V; ++i) xo.v[i] = (xv.v[i] - a.tau * atp.v[i]) - a.tau * (s * racc.v[i]);
+            stu_s_t<T, V>(a.x_out + foff, voff, xo);
             return;
         }
         const VT x0v = ldu_s_t<T, V>(a.x0 + foff, voff), pv = ldu_s_t<T, V>(a.p + foff, voff);

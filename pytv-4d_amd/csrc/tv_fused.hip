@@ -261,4 +261,47 @@ int tv_admm_fixup(const tv_geom* g, const void* t, const void* t_prev, const voi
     return reduce_partials(w0, fp.n0 + fp.n1 + fp.n2 + fp.n3, nmax, rr, st);
 }
 
+// One-sweep Chambolle-Pock with a data-fidelity operator (tv_fused.h, ALG_CPOP): q <- proj(q + sigma_D D x_in) and
+// x_out <- x_in - tau atp - tau D^T q in one pass over q; atp = A^T p is the caller's (solvers.ChambollePockOperator).
+int tv_cpop_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* atp, void* x_out,
+                  double sigma_D, double lambda, double tau, int64_t chunk_begin, int64_t chunk_count, double* tvout, void* ws, void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (!x_in || !q || !atp || !x_out || !tvout || !ws) return fail(TV_E_ARG, "NULL array");
+    if (x_in == x_out || atp == x_out) return fail(TV_E_ARG, "x_out must be a buffer of its own (ping-pong)");
+    if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
+    if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
+    if (!aligned16({x_in, x_prev, x_next, q, atp, x_out, d.wv})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    SweepPlan sp;
+    bool empty = false;
+    if (int rc = sweep_plan(g, d, x_in, x_prev, x_next, chunk_begin, chunk_count, sp, empty)) return rc;
+    if (empty) {
+        HIP_TRY(hipMemsetAsync(tvout, 0, sizeof(double), st));
+        return 0;
+    }
+    double* w0 = (double*)ws;
+    double* w1 = w0 + sp.nmax + kStage + 16;
+    auto sweep = [&]<typename T>() -> int {
+        FusedArgsT<T> a{(const T*)x_in, (const T*)x_prev, (const T*)x_next, (T*)q, nullptr, (T*)const_cast<void*>(atp),
+                        (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)0, (T)1, w0, w1, 0};
+        return tvm::fused_sweep<T, ALG_CPOP>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
+    };
+    const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();
+    if (rc) return rc;
+    return reduce_partials(w0, sp.lc.nblocks, sp.nmax, tvout, st);
+}
+
+// its fix-up: x_out -= tau (missing adjoint terms); the ALG_ADMM instantiation with the coefficient tau (r += rho ... with rho = -tau)
+int tv_cpop_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, double tau, int64_t z_begin,
+                  int64_t z_count, void* ws, void* stream) {
+    DG d;
+    if (int rc = make_dg(g, d)) return rc;
+    if (ws == nullptr) return fail(TV_E_ARG, "NULL array");
+    // the fix-up's reduction (unused here) goes to the last word of the workspace: the pad behind the second partial array, which
+    // this call does not use
+    double* unused = (double*)ws + 2 * (max_partials(d) + kStage + 16) - 1;
+    return tv_admm_fixup(g, q, q_prev, q_next, x_out, -tau, z_begin, z_count, unused, ws, stream);
+}
+
 }  // extern "C"

@@ -39,7 +39,7 @@ template <typename F> static int dispatch_fused(int scheme, int m, F&& f) {
 template <typename T, int ALG>
 static int fused_sweep_launch(const tv_geom* g, const DG& d, const LC& lc, hipStream_t st, const FusedArgsT<T>& a, int zc, int chunk0, bool xw,
                               bool force_win) {
-    if (ALG == ALG_ADMM && !xw) return fail(TV_E_ARG, "the ADMM sweep is built with TV_FUSED_XW=1 only");
+    if (ALG != ALG_CP && !xw) return fail(TV_E_ARG, "the ADMM / operator sweeps are built with TV_FUSED_XW=1 only");
     return dispatch_fused(g->scheme, (d.m > CP_TWN || force_win) ? 0 : d.m, [&]<int S, int M>() -> int {
         if constexpr (M == 0) {          // M > 8: windows of 8 frames
             if (xw) hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, true, true, T, ALG>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
@@ -55,7 +55,7 @@ static int fused_sweep_launch(const tv_geom* g, const DG& d, const LC& lc, hipSt
 
 template <typename T, int ALG>
 static int fused_fixup_launch(const tv_geom* g, const DG& d, hipStream_t st, const FixupArgsT<T>& a, const FixPlan& p, double* w0) {
-    if (ALG == ALG_ADMM && !p.xw) return fail(TV_E_ARG, "the ADMM sweep is built with TV_FUSED_XW=1 only");
+    if (ALG != ALG_CP && !p.xw) return fail(TV_E_ARG, "the ADMM / operator sweeps are built with TV_FUSED_XW=1 only");
     const dim3 blk(64, 4, 1);
     auto launch = [&]<int S, bool XW>() -> int {
         if constexpr (ALG == ALG_CP || XW) {

@@ -418,8 +418,8 @@ class ChambollePockOperator(_SlabProblem):
     reference is written for: README.md:2; its CP snippet is the special case A = I, README.md:148 ``sigma_A``).
 
         p <- (p + sigma_A (A x - b)) / (1 + sigma_A)
-        q <- proj_{|.|_2 <= reg}(q + sigma_D D x)                       HIP: tv_cp_dual  (D + prox, fused)
-        x <- x - tau A^T p - tau D^T q                                   HIP: tv_DT_axpy  (D^T + axpy, fused)
+        q <- proj_{|.|_2 <= reg}(q + sigma_D D x)                       HIP: ONE sweep over q for both lines (tv_cpop_fused +
+        x <- x - tau A^T p - tau D^T q                                   tv_cpop_fixup, round 3) or tv_cp_dual + tv_DT_axpy2
 
     ``A`` and ``AT`` are callables taking and returning DEVICE tensors (``A``: image (Nz, M, Ny, Nx) -> data of any
     shape, ``AT``: data -> image); they stay the user's code, the TV part runs in the HIP kernels.  ``tau`` must
@@ -430,9 +430,15 @@ class ChambollePockOperator(_SlabProblem):
     communication inside the callables); the TV part trades the image / gradient halo planes like ``ChambollePock``."""
 
     def __init__(self, A, AT, b, x_init, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None):
+                 mask_static=False, factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, fused=None):
         super().__init__(x_init, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
         self.A, self.AT = A, AT
+        # fused (round 3): the TV part as ONE sweep over q (tv_cpop_fused + tv_cpop_fixup: the one-sweep Chambolle-Pock kernel with
+        # A^T p in the place of the fidelity dual) instead of tv_cp_dual + tv_DT_axpy2 -- 2 Nd + 4 words per voxel instead of 3 Nd + 4
+        can_fuse = bool(self.lib.tv_cp_fused_supported(self.geo.ref))
+        if fused and not can_fuse:
+            raise ValueError("fused=True needs a geometry tv_cp_fused_supported() accepts")
+        self.fused = can_fuse if fused is None else bool(fused)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
         self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x_init.shape[1], reg_z_over_reg, reg_time,
@@ -481,6 +487,23 @@ class ChambollePockOperator(_SlabProblem):
         g, s = self.geo, self.slab
         h = self.plan.exchange_image(self.x, self.xh_prev, self.xh_next)      # in flight while the data-space update runs
         _nv.check(self.lib.tv_cpop_p(_nv.dtype_code(self.dtype), self.p.numel(), _nv.ptr(self.p), _nv.ptr(self.r), self.sigma_A, self.stream))
+        if self.fused:
+            # one sweep: A^T p first (the user's operator runs while the x halos travel), then dual + primal update in one pass
+            # over q, the q' halos, the fix-up
+            atp = self._apply(self.AT, self.p, self.x.shape, "AT(p)")
+            self.n_AT += 1
+            s.wait(h)
+            _nv.check(self.lib.tv_cpop_fused(g.ref, _nv.ptr(self.x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.q),
+                                             _nv.ptr(atp), _nv.ptr(self.x_new), self.sigma_D, self.reg, self.tau, 0, -1,
+                                             out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+            h = self.plan.exchange_grad(self.q, self.qh_prev[0] if self.qh_prev is not None else None,
+                                        self.qh_next[0] if self.qh_next is not None else None)
+            s.wait(h)
+            _nv.check(self.lib.tv_cpop_fixup(g.ref, _nv.ptr(self.q), _nv.ptr(self.qh_prev), _nv.ptr(self.qh_next), _nv.ptr(self.x_new),
+                                             self.tau, 0, -1, _nv.ptr(self.ws), self.stream))
+            self.x, self.x_new = self.x_new, self.x
+            self._residual(self.x, out[1:2])
+            return
         s.wait(h)
         _nv.check(self.lib.tv_cp_dual(g.ref, _nv.ptr(self.x), _nv.ptr(self.xh_prev), _nv.ptr(self.xh_next), _nv.ptr(self.q),
                                       self.sigma_D, self.reg, out[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))

@@ -86,6 +86,9 @@ def main():
         "tv_cp_fused": lambda G, x: lib.tv_cp_fused(G, x, N, N, x, x, x, x, ctypes.c_double(.5), ctypes.c_double(25.), ctypes.c_double(.1),
                                                     ctypes.c_double(1.), ctypes.c_int64(0), ctypes.c_int64(-1), dp, dp, x, N),
         "tv_cp_fixup": lambda G, x: lib.tv_cp_fixup(G, x, N, N, x, x, ctypes.c_double(.1), ctypes.c_int64(0), ctypes.c_int64(-1), dp if x else N, x, N),
+        "tv_cpop_fused": lambda G, x: lib.tv_cpop_fused(G, x, N, N, x, x, x, ctypes.c_double(.5), ctypes.c_double(25.), ctypes.c_double(.1),
+                                                        ctypes.c_int64(0), ctypes.c_int64(-1), dp, x, N),
+        "tv_cpop_fixup": lambda G, x: lib.tv_cpop_fixup(G, x, N, N, x, ctypes.c_double(.1), ctypes.c_int64(0), ctypes.c_int64(-1), x, N),
         "tv_cheb_step": lambda G, x: lib.tv_cheb_step(G, x, N, N, ctypes.c_double(.1), x, N, N, N, ctypes.c_double(.5), ctypes.c_double(.1), x, dp if x else N, x, N),
         "tv_axpby": lambda G, x: lib.tv_axpby(G, ctypes.c_double(1.), x, ctypes.c_double(1.), N, N, x, N, N, N),
         "tv_admm_fused": lambda G, x: lib.tv_admm_fused(G, x, N, N, x, x, x, x, ctypes.c_double(1.), ctypes.c_double(.1), ctypes.c_int32(0),
@@ -102,7 +105,7 @@ def main():
         "tv_subgrad_step": lambda G, x: lib.tv_subgrad_step(G, x, x, x, ctypes.c_double(.1), ctypes.c_double(1.), dp if x else N, x, N),
     }
     halo_ops = ("tv_D", "tv_DT", "tv_DT_axpy", "tv_subgrad", "tv_subgrad_fused", "tv_subgrad_fused_norms", "tv_cp_dual", "tv_cp_primal",
-                "tv_admm_zu", "tv_admm_tu", "tv_normal_op", "tv_normal_op2", "tv_cp_fixup", "tv_admm_fixup", "tv_cheb_step")
+                "tv_admm_zu", "tv_admm_tu", "tv_normal_op", "tv_normal_op2", "tv_cp_fixup", "tv_admm_fixup", "tv_cheb_step", "tv_cpop_fixup")
     for name, call in calls.items():
         expect_neg(call(None, a), name + "(NULL geometry)")
         expect_neg(call(ctypes.byref(g), None), name + "(NULL arrays)")
