@@ -64,8 +64,23 @@ for scheme in schemes:
                                  nv.ptr(sc), nv.ptr(sc), nv.ptr(ws), st))
         nv.check(lib.tv_cp_fixup(g.ref, nv.ptr(d), None, None, nv.ptr(o), nv.ptr(x), 1.0 / 17.0, 0, -1, nv.ptr(sc), nv.ptr(ws), st))
 
+    def admm_sweep():          # z / u update + residual of the next x-solve (u in place, t' stored sparsely)
+        nv.check(lib.tv_admm_fused(g.ref, nv.ptr(x), None, None, nv.ptr(u), nv.ptr(d), nv.ptr(o2), nv.ptr(o), 1.0, 0.05, 0, 0, -1,
+                                   nv.ptr(sc), nv.ptr(sc), nv.ptr(ws), st))
+        nv.check(lib.tv_admm_fixup(g.ref, nv.ptr(d), None, None, nv.ptr(o), 0.05, 0, -1, nv.ptr(sc), nv.ptr(ws), st))
+
+    def cpop_sweep():          # operator-slot CP: dual update + x - tau A^T p - tau D^T q
+        nv.check(lib.tv_cpop_fused(g.ref, nv.ptr(x), None, None, nv.ptr(d), nv.ptr(o2), nv.ptr(o), 0.5, 25.0, 1.0 / 17.0, 0, -1, nv.ptr(sc),
+                                   nv.ptr(ws), st))
+        nv.check(lib.tv_cpop_fixup(g.ref, nv.ptr(d), None, None, nv.ptr(o), 1.0 / 17.0, 0, -1, nv.ptr(ws), st))
+
+    dots2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    ops.append(("tv_cheb_step", 4, lambda: nv.check(lib.tv_cheb_step(g.ref, nv.ptr(x), None, None, 0.05, nv.ptr(o2), nv.ptr(ne[1:1 + shape[0]]), None, None,
+                                                                     0.8, 0.3, nv.ptr(o), dots2.data_ptr(), nv.ptr(ws), st))))
     if lib.tv_cp_fused_supported(g.ref):
         ops.append(("cp_sweep+fixup", 5 + 2 * nd + wvol, cp_sweep))
+        ops.append(("admm_sweep+fixup", 3 + 2 * nd + wvol, admm_sweep))
+        ops.append(("cpop_sweep+fixup", 3 + 2 * nd + wvol, cpop_sweep))
     if wvol:
         ops = [(n, wd + (1 if n in ("tv_D", "tv_subgrad_fused", "tv_subgrad_fused_norms", "tv_cp_dual", "tv_subgrad", "tv_admm_zu") else 0), f) for n, wd, f in ops]
     only = [o for o in os.environ.get("OPS", "").split(",") if o]
