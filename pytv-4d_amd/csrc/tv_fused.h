@@ -41,6 +41,9 @@ using F4 = Vec<float, 4>;
 #ifndef TV_FUSED_NW
 #define TV_FUSED_NW 8
 #endif
+#ifndef TV_ADMM_T_NT
+#define TV_ADMM_T_NT 0           // 1: the sparse t' stores of the ADMM sweep non-temporal like its u / r stores (A/B)
+#endif
 #ifndef TV_FUSED_PFQ_TWIN
 #define TV_FUSED_PFQ_TWIN 1      // the central dual prefetch (PFQ) in the windowed (M > 8) instantiations too (round 3)
 #endif
@@ -581,7 +584,11 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
                         constexpr bool up_role = (S != HYBRID) || (k == 0 || k == 1 || k == 4 || k == 6);
                         constexpr bool dn_role = (S != HYBRID) || !up_role;
                         if (a.full_store || (up_role && st_u[axis]) || (dn_role && st_d[axis]))
+#if TV_ADMM_T_NT
+                            stu_s_t<T, V>(tbase + (long long)ch * g.s_z, voff, v[k]);
+#else
                             stu_t<T, V>(tbase + (long long)ch * g.s_z, voff, v[k]);
+#endif
                     });
                 } else {
 #pragma unroll
