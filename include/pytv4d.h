@@ -239,14 +239,16 @@ int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const voi
                   void* out2, double* dots, void* ws, void* stream);
 /* One step of the Chebyshev iteration on (I + rho D^T D) e = b (round 3: an x-solve whose scalars do not depend on the vectors --
  * no dot product, hence no all-reduce on a sharded volume, and 4 words per voxel and step where a CG step moves 11):
- *   out = [add +] x + alpha (b - A x) + beta (x - y)          y, add, ref may be NULL (y = 0; no add)
+ *   out = [add +] x + alpha (b - A x) + beta (x - y)          y NULL: y = yscale * b (0: no y); add, ref may be NULL
+ *   (x may be b itself: with e_1 = a_0 b never stored, the first two steps are  e_2 = b + a' (b - A b) + b' b  and a step with
+ *   y = a_0 b -- 2 + 3 words instead of 2 + 3 + 4)
  *   dots[0] = |b - A x|^2,  dots[1] = |out - ref|^2 if ref is given, else |x|^2      (device fp64, local planes)
  * out must not alias an input.  x_prev / x_next: TWO halo planes each, as in tv_normal_op.  The coefficients of step k follow from
  * the spectral interval [1, 1 + rho L] alone (pytv/solvers.py::chebyshev_coefficients restates the recurrence).
  * tv_axpby: out = a x + b y (y NULL: a x); *dist2 (or NULL, then ref and ws may be NULL too) = |out - ref|^2.
  * Replaces: nothing in the reference (its README names ADMM only, README.md:26,135). */
 int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, const void* b, const void* y,
-                 const void* add, const void* ref, double alpha, double beta, void* out, double* dots, void* ws, void* stream);
+                 double yscale, const void* add, const void* ref, double alpha, double beta, void* out, double* dots, void* ws, void* stream);
 int tv_axpby(const tv_geom* g, double a, const void* x, double b, const void* y, const void* ref, void* out, double* dist2, void* ws,
              void* stream);
 /* One step of the SINGLE-REDUCTION conjugate gradient (Chronopoulos-Gear form; one all-reduce of two scalars per step on

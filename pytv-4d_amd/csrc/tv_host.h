@@ -262,7 +262,7 @@ int D_admm_zu(const tv_geom* g, const DG& d, const void* x, const void* xp, cons
 // streaming normal operator (tv_nstream.h): radius-1 schemes, fp32; two dot products
 bool N_stream_ok(const tv_geom* g, const DG& d, bool vec);
 // optional Chebyshev form of the epilogue (tv_cheb_step): out = [add +] x + alpha (b - A x) + beta (x - y)
-struct NCheb { const void* y; const void* add; const void* ref; double alpha, beta; };
+struct NCheb { const void* y; const void* add; const void* ref; double alpha, beta, yscale; };
 int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, void* out, void* out2,
              double rho, hipStream_t st, long long* nblocks, double* part0, double* part1, const NCheb* cheb = nullptr);
 // streaming forward kernel (tv_dstream.h): d = D x without LDS tile or barrier, every load one plane ahead of its use

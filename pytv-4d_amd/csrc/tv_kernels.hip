@@ -674,12 +674,12 @@ __global__ __launch_bounds__(256) void k_sub_dot(long long nv, const T* a, const
 //   out = [add +] x + alpha (b - ax) + beta (x - y);  partials: |b - ax|^2 and |out - ref|^2 (or |x|^2)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_cheb_combine(long long nv, const T* x, const T* b, const T* y, const T* add, const T* ref, T* out, T alpha,
-                                                      T beta, double* part0, double* part1) {
+                                                      T beta, T yscale, double* part0, double* part1) {
     __shared__ double sm[16];
     double acc0 = 0.0, acc1 = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
         const Vec<T, V> xv = vload<T, V>(x + i * V), ax = vload<T, V>(out + i * V), bv = vload<T, V>(b + i * V);
-        const Vec<T, V> yv = (y != nullptr) ? vload<T, V>(y + i * V) : vsplat<T, V>(T(0));
+        const Vec<T, V> yv = (y != nullptr) ? vload<T, V>(y + i * V) : yscale * bv;
         Vec<T, V> o;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -1263,11 +1263,12 @@ int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const voi
 // dots[0] = |b - A x|^2, dots[1] = |out - ref|^2 (ref given) or |x|^2.  No scalar of the recurrence depends on the vectors: a
 // sharded solve needs halo planes only, no all-reduce.
 int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, const void* b, const void* y,
-                 const void* add, const void* ref, double alpha, double beta, void* out, double* dots, void* ws, void* stream) {
+                 double yscale, const void* add, const void* ref, double alpha, double beta, void* out, double* dots, void* ws, void* stream) {
     DG d;
     if (int rc = make_dg(g, d)) return rc;
     if (x == nullptr || b == nullptr || out == nullptr || dots == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (out == x || out == y || out == b || out == add || out == ref) return fail(TV_E_ARG, "out must not alias an input");
+    if (y != nullptr && yscale != 0.0) return fail(TV_E_ARG, "yscale is the stand-in for a missing y (y = yscale * b)");
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
     if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr)))
         return fail(TV_E_HALO, "tv_cheb_step on a slab needs two halo planes on each interior side");
@@ -1278,7 +1279,7 @@ int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void
     double* w1 = w0 + nmax + kStage + 16;
     if (env_int("TV_NORMAL_KERNEL", 2) == 2 && tvm::N_stream_ok(g, d, vec)) {
         long long nb;
-        const tvm::NCheb c{y, add, ref, alpha, beta};
+        const tvm::NCheb c{y, add, ref, alpha, beta, yscale};
         if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, b, out, nullptr, rho, st, &nb, w0, w1, &c)) return rc;
         if (int rc = reduce_partials(w0, nb, nmax, dots, st)) return rc;
         return reduce_partials(w1, nb, nmax, dots + 1, st);
@@ -1286,7 +1287,7 @@ int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void
     // composition: out <- A x with the operator of this geometry, then one flat pass
     if (int rc = tv_normal_op(g, x, x_prev, x_next, rho, out, dots, ws, stream)) return rc;
     TV_FLAT_LAUNCH(k_cheb_combine, g->dtype, nvox(d), ({x, b, y, add, ref, out}), (const T*)x, (const T*)b, (const T*)y, (const T*)add,
-                   (const T*)ref, (T*)out, (T)alpha, (T)beta, w0, w1);
+                   (const T*)ref, (T*)out, (T)alpha, (T)beta, (T)yscale, w0, w1);
     HIP_TRY(hipGetLastError());
     if (int rc = reduce_partials(w0, kFlatBlocks, nmax, dots, st)) return rc;
     return reduce_partials(w1, kFlatBlocks, nmax, dots + 1, st);

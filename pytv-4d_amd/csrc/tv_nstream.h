@@ -34,6 +34,7 @@ template <typename T> struct NormalArgsT {
     const T* ref;
     T alpha, beta;
     int cheb;
+    T yscale;              // y == nullptr: y = yscale * b (0: no y) -- the second Chebyshev step, whose e_1 = a_0 b need not exist in memory
 };
 using NormalArgs = NormalArgsT<float>;
 
@@ -47,7 +48,8 @@ __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long f
     if constexpr (CHEB) {
         const Vec<T, V> bv = ldu_t<T, V>(a.b + fo, voff);
         Vec<T, V> yv = vsplat<T, V>(T(0)), av = vsplat<T, V>(T(0)), rv = xm;
-        if (a.y != nullptr) yv = ldu_t<T, V>(a.y + fo, voff);            // no y: y = 0 (the step after e_0 = 0)
+        if (a.y != nullptr) yv = ldu_t<T, V>(a.y + fo, voff);            // no y: y = yscale * b (0 after e_0 = 0)
+        else yv = a.yscale * bv;
         if (a.add != nullptr) av = ldu_t<T, V>(a.add + fo, voff);
         if (a.ref != nullptr) rv = ldu_t<T, V>(a.ref + fo, voff);
 #pragma unroll

@@ -38,12 +38,12 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
     *nblocks = 8 * per_xcd;
     if (*nblocks > max_partials(d)) return fail(TV_E_ARG, "internal: normal-operator partials exceed the workspace");
     const WT<float> w = make_w<float>(g);
-    const NCheb c0{nullptr, nullptr, nullptr, 0.0, 0.0};
+    const NCheb c0{nullptr, nullptr, nullptr, 0.0, 0.0, 0.0};
     const NCheb& c = cheb ? *cheb : c0;
     NormalArgs a{(const float*)x, (const float*)xp, (const float*)xn, (const float*)b, (float*)out, (float*)out2, (float)rho, part0, part1,
-                 (const float*)c.y, (const float*)c.add, (const float*)c.ref, (float)c.alpha, (float)c.beta, cheb ? 1 : 0};
+                 (const float*)c.y, (const float*)c.add, (const float*)c.ref, (float)c.alpha, (float)c.beta, cheb ? 1 : 0, (float)c.yscale};
     NormalArgsT<double> ad{(const double*)x, (const double*)xp, (const double*)xn, (const double*)b, (double*)out, (double*)out2, rho, part0, part1,
-                           (const double*)c.y, (const double*)c.add, (const double*)c.ref, c.alpha, c.beta, cheb ? 1 : 0};
+                           (const double*)c.y, (const double*)c.add, (const double*)c.ref, c.alpha, c.beta, cheb ? 1 : 0, c.yscale};
 #define TV_NS_LAUNCH1(MM, TW, CH)                                                                                       \
     do {                                                                                                               \
         if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \

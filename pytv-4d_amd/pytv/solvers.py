@@ -766,26 +766,27 @@ class ADMM(_SlabProblem):
         if reduce:
             self.slab.allreduce_sum_(dots)
 
-    def _cheb_range(self, v, y, add, ref, out, alpha, beta, a, b, hp, hn, dots):
+    def _cheb_range(self, v, y, yscale, add, ref, out, alpha, beta, a, b, hp, hn, dots):
         g = self.geom(a, b)
         sl = lambda t_: _nv.ptr(t_[a:b]) if t_ is not None else None      # noqa: E731
-        _nv.check(self.lib.tv_cheb_step(g.ref, _nv.ptr(v[a:b]), _nv.ptr(hp), _nv.ptr(hn), self.rho, _nv.ptr(self.r[a:b]), sl(y), sl(add),
-                                        sl(ref), alpha, beta, _nv.ptr(out[a:b]), dots.data_ptr(), _nv.ptr(self.ws), self.stream))
+        _nv.check(self.lib.tv_cheb_step(g.ref, _nv.ptr(v[a:b]), _nv.ptr(hp), _nv.ptr(hn), self.rho, _nv.ptr(self.r[a:b]), sl(y), yscale,
+                                        sl(add), sl(ref), alpha, beta, _nv.ptr(out[a:b]), dots.data_ptr(), _nv.ptr(self.ws), self.stream))
 
-    def _cheb_step(self, v, y, add, ref, out, alpha, beta, dots):
-        """out = [add +] v + alpha (r - A v) + beta (v - y) on the slab; the two-plane halo exchange of v hides behind the interior
-        planes exactly as in _normal; dots <- [|r - A v|^2, |out - ref|^2 or |v|^2] summed over the launches (local)."""
+    def _cheb_step(self, v, y, yscale, add, ref, out, alpha, beta, dots):
+        """out = [add +] v + alpha (r - A v) + beta (v - y) on the slab (y None: y = yscale r); the two-plane halo exchange of v hides
+        behind the interior planes exactly as in _normal; dots <- [|r - A v|^2, |out - ref|^2 or |v|^2] summed over the launches."""
         nz = self.slab.nz
+        args = (y, yscale, add, ref, out, alpha, beta)
         if self.sh and nz >= 5:
             h = self.plan.exchange_image2(v, self.h2_prev, self.h2_next)
-            self._cheb_range(v, y, add, ref, out, alpha, beta, 2, nz - 2, v[0:2], v[nz - 2:nz], self.dots3[0])
+            self._cheb_range(v, *args, 2, nz - 2, v[0:2], v[nz - 2:nz], self.dots3[0])
             self.slab.wait(h)
-            self._cheb_range(v, y, add, ref, out, alpha, beta, 0, 2, self.h2_prev, v[2:4], self.dots3[1])
-            self._cheb_range(v, y, add, ref, out, alpha, beta, nz - 2, nz, v[nz - 4:nz - 2], self.h2_next, self.dots3[2])
+            self._cheb_range(v, *args, 0, 2, self.h2_prev, v[2:4], self.dots3[1])
+            self._cheb_range(v, *args, nz - 2, nz, v[nz - 4:nz - 2], self.h2_next, self.dots3[2])
             torch.sum(self.dots3, dim=0, out=dots)
         else:
             hp, hn = self._halo2(v)
-            self._cheb_range(v, y, add, ref, out, alpha, beta, 0, nz, hp, hn, dots)
+            self._cheb_range(v, *args, 0, nz, hp, hn, dots)
 
     def _solve_cheb(self, fid_slot):
         """x <- x + e_K, e_K = K Chebyshev steps on A e = r (self.r = b - A x); fid_slot <- |x - x0|^2 (local)."""
@@ -797,14 +798,20 @@ class ADMM(_SlabProblem):
                                    fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
             last = 0
         else:
-            _nv.check(lib.tv_axpby(g.ref, a0, _nv.ptr(self.r), 0.0, None, None, _nv.ptr(bufs[0]), None, None, self.stream))     # e_1
-            for k in range(1, K):
+            # e_1 = a0 r is never stored: the first kernel forms e_2 = e_1 + alpha_1 (r - A e_1) + beta_1 e_1 from r alone (x = b = r:
+            # e_2 = r + a' (r - A r) + b' r), the second one takes y = a0 r on the fly -- 2 + 3 words instead of 2 + 3 + 4
+            al1, be1 = coef[1]
+            ap = al1 * a0
+            bp = a0 + al1 + be1 * a0 - 1.0 - ap
+            fin = (K == 2)
+            self._cheb_step(self.r, None, 0.0, self.x if fin else None, self.x0 if fin else None, bufs[0], ap, bp, self.dots)
+            for k in range(2, K):         # e_k lives in bufs[(k - 2) % 3]
                 fin = (k + 1 == K)
                 alpha, beta = coef[k]
-                self._cheb_step(bufs[(k - 1) % 3], bufs[(k - 2) % 3] if k >= 2 else None, self.x if fin else None,
-                                self.x0 if fin else None, bufs[k % 3], alpha, beta, self.dots)
+                self._cheb_step(bufs[(k - 2) % 3], bufs[(k - 3) % 3] if k >= 3 else None, a0 if k == 2 else 0.0,
+                                self.x if fin else None, self.x0 if fin else None, bufs[(k - 1) % 3], alpha, beta, self.dots)
             fid_slot.copy_(self.dots[1:2])
-            last = (K - 1) % 3
+            last = (K - 2) % 3
         # the new image was written next to the old one: swap the roles (the old x becomes a scratch vector)
         self.x, bufs[last] = bufs[last], self.x
         self.d, self.Ad, self.b = bufs

@@ -152,11 +152,12 @@ def test_cheb_step_matches_numpy(nvlib, scheme, shape):
         g = nv.Geometry(shape, scheme, torch.as_tensor(x).dtype, torch.device("cuda", 0), **kw)
         st, ws = nv.current_stream(torch.device("cuda", 0)), g.workspace()
         xd, yd, bd, addd, refd = [torch.as_tensor(v).cuda() for v in (x, y, b, add, ref)]
-        for use_y, use_add, use_ref in ((True, True, True), (False, False, False), (True, False, False)):
-            want = x64 + alpha * res + beta * (x64 - (y if use_y else 0.0)) + (add if use_add else 0.0)
+        for use_y, yscale, use_add, use_ref in ((True, 0.0, True, True), (False, 0.0, False, False), (True, 0.0, False, False),
+                                                (False, 0.4, False, True)):          # y missing: y = yscale * b
+            want = x64 + alpha * res + beta * (x64 - (y if use_y else yscale * b.astype(np.float64))) + (add if use_add else 0.0)
             od = torch.empty_like(xd)
             sc = torch.zeros(2, dtype=torch.float64, device="cuda")
-            nv.check(lib.tv_cheb_step(g.ref, nv.ptr(xd), None, None, rho, nv.ptr(bd), nv.ptr(yd) if use_y else None,
+            nv.check(lib.tv_cheb_step(g.ref, nv.ptr(xd), None, None, rho, nv.ptr(bd), nv.ptr(yd) if use_y else None, yscale,
                                       nv.ptr(addd) if use_add else None, nv.ptr(refd) if use_ref else None, alpha, beta, nv.ptr(od),
                                       sc.data_ptr(), nv.ptr(ws), st))
             scale = max(1.0, np.abs(want).max())
@@ -164,6 +165,14 @@ def test_cheb_step_matches_numpy(nvlib, scheme, shape):
             s_ = sc.cpu().numpy()
             np.testing.assert_allclose(s_[0], np.sum(res * res), rtol=tol * 100)
             np.testing.assert_allclose(s_[1], np.sum((want - ref) ** 2) if use_ref else np.sum(x64 * x64), rtol=tol * 100)
+        # x may be b itself (the fused first two steps of the solver)
+        od = torch.empty_like(xd)
+        nv.check(lib.tv_cheb_step(g.ref, nv.ptr(bd), None, None, rho, nv.ptr(bd), None, 0.0, None, None, alpha, beta, nv.ptr(od),
+                                  sc.data_ptr(), nv.ptr(ws), st))
+        b64 = b.astype(np.float64)
+        ab = b64 + rho * orc.D_T(orc.D(b64, scheme, **kw), scheme, **kw)
+        want = b64 + alpha * (b64 - ab) + beta * b64
+        np.testing.assert_allclose(od.cpu().numpy(), want, rtol=0, atol=tol * 10 * max(1.0, np.abs(want).max()))
         # tv_axpby
         od = torch.empty_like(xd)
         sc = torch.zeros(1, dtype=torch.float64, device="cuda")
@@ -270,7 +279,7 @@ def test_admm_sweep_and_cheb_step_stay_inside_their_arrays(nvlib, scheme, dtype)
         assert bool(torch.isfinite(u).all() and torch.isfinite(t).all() and torch.isfinite(r).all()) and bool(torch.isfinite(sc).all())
     (yb, y), (ab, a), (ob, o) = guarded(shape), guarded(shape), guarded(shape, 0.0)
     dots = torch.zeros(2, dtype=torch.float64, device="cuda")
-    nv.check(lib.tv_cheb_step(g.ref, nv.ptr(x), None, None, 0.15, nv.ptr(r), nv.ptr(y), nv.ptr(a), nv.ptr(x0), 0.8, 0.3, nv.ptr(o),
+    nv.check(lib.tv_cheb_step(g.ref, nv.ptr(x), None, None, 0.15, nv.ptr(r), nv.ptr(y), 0.0, nv.ptr(a), nv.ptr(x0), 0.8, 0.3, nv.ptr(o),
                               dots.data_ptr(), nv.ptr(ws), st))
     torch.cuda.synchronize()
     assert all(bands_intact(b) for b in (xb, rb, yb, ab, x0b, ob))

@@ -89,7 +89,7 @@ def main():
         "tv_cpop_fused": lambda G, x: lib.tv_cpop_fused(G, x, N, N, x, x, x, ctypes.c_double(.5), ctypes.c_double(25.), ctypes.c_double(.1),
                                                         ctypes.c_int64(0), ctypes.c_int64(-1), dp, x, N),
         "tv_cpop_fixup": lambda G, x: lib.tv_cpop_fixup(G, x, N, N, x, ctypes.c_double(.1), ctypes.c_int64(0), ctypes.c_int64(-1), x, N),
-        "tv_cheb_step": lambda G, x: lib.tv_cheb_step(G, x, N, N, ctypes.c_double(.1), x, N, N, N, ctypes.c_double(.5), ctypes.c_double(.1), x, dp if x else N, x, N),
+        "tv_cheb_step": lambda G, x: lib.tv_cheb_step(G, x, N, N, ctypes.c_double(.1), x, N, ctypes.c_double(0.), N, N, ctypes.c_double(.5), ctypes.c_double(.1), x, dp if x else N, x, N),
         "tv_axpby": lambda G, x: lib.tv_axpby(G, ctypes.c_double(1.), x, ctypes.c_double(1.), N, N, x, N, N, N),
         "tv_admm_fused": lambda G, x: lib.tv_admm_fused(G, x, N, N, x, x, x, x, ctypes.c_double(1.), ctypes.c_double(.1), ctypes.c_int32(0),
                                                         ctypes.c_int64(0), ctypes.c_int64(-1), dp, dp, x, N),

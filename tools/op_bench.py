@@ -75,7 +75,7 @@ for scheme in schemes:
         nv.check(lib.tv_cpop_fixup(g.ref, nv.ptr(d), None, None, nv.ptr(o), 1.0 / 17.0, 0, -1, nv.ptr(ws), st))
 
     dots2 = torch.zeros(2, dtype=torch.float64, device=dev)
-    ops.append(("tv_cheb_step", 4, lambda: nv.check(lib.tv_cheb_step(g.ref, nv.ptr(x), None, None, 0.05, nv.ptr(o2), nv.ptr(ne[1:1 + shape[0]]), None, None,
+    ops.append(("tv_cheb_step", 4, lambda: nv.check(lib.tv_cheb_step(g.ref, nv.ptr(x), None, None, 0.05, nv.ptr(o2), nv.ptr(ne[1:1 + shape[0]]), 0.0, None, None,
                                                                      0.8, 0.3, nv.ptr(o), dots2.data_ptr(), nv.ptr(ws), st))))
     if lib.tv_cp_fused_supported(g.ref):
         ops.append(("cp_sweep+fixup", 5 + 2 * nd + wvol, cp_sweep))
