@@ -41,17 +41,34 @@ using NormalArgs = NormalArgsT<float>;
 // epilogue of one site-vector: xm = x, ax = A x there.  CHEB is a TEMPLATE parameter: as a run-time branch in the same kernel the
 // Chebyshev form cost the CG instantiations 35 % (tv_normal_op 0.95 -> 1.30 ms at 64x8x1024x1024: the extra pointers and the
 // branch sit in the hot loop of a kernel that is at its register limit).
+#ifndef TV_NSTREAM_NT
+#define TV_NSTREAM_NT 1          // the streamed-once arrays of the epilogue (out, b, y, add, ref) non-temporal: tv_normal_op -2 - 5 %, Chebyshev ADMM -3 - 4 % (0: plain)
+#endif
+template <typename T, int V> __device__ __forceinline__ void NSTU(T* ubase, unsigned voff, const Vec<T, V>& v) {
+#if TV_NSTREAM_NT
+    stu_s_t<T, V>(ubase, voff, v);
+#else
+    stu_t<T, V>(ubase, voff, v);
+#endif
+}
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> NLDU(const T* ubase, unsigned voff) {
+#if TV_NSTREAM_NT
+    return ldu_s_t<T, V>(ubase, voff);
+#else
+    return ldu_t<T, V>(ubase, voff);
+#endif
+}
 template <typename T, int V, bool CHEB>
 __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long fo, unsigned voff, const Vec<T, V>& xm, const Vec<T, V>& ax,
                                             double& acc0, double& acc1) {
     Vec<T, V> o;
     if constexpr (CHEB) {
-        const Vec<T, V> bv = ldu_t<T, V>(a.b + fo, voff);
+        const Vec<T, V> bv = NLDU<T, V>(a.b + fo, voff);
         Vec<T, V> yv = vsplat<T, V>(T(0)), av = vsplat<T, V>(T(0)), rv = xm;
-        if (a.y != nullptr) yv = ldu_t<T, V>(a.y + fo, voff);            // no y: y = yscale * b (0 after e_0 = 0)
+        if (a.y != nullptr) yv = NLDU<T, V>(a.y + fo, voff);            // no y: y = yscale * b (0 after e_0 = 0)
         else yv = a.yscale * bv;
-        if (a.add != nullptr) av = ldu_t<T, V>(a.add + fo, voff);
-        if (a.ref != nullptr) rv = ldu_t<T, V>(a.ref + fo, voff);
+        if (a.add != nullptr) av = NLDU<T, V>(a.add + fo, voff);
+        if (a.ref != nullptr) rv = NLDU<T, V>(a.ref + fo, voff);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const T res = bv.v[i] - ax.v[i];
@@ -68,16 +85,16 @@ __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long f
             acc1 += (double)xm.v[i] * (double)xm.v[i];
         }
     } else {
-        const Vec<T, V> bv = ldu_t<T, V>(a.b + fo, voff);
+        const Vec<T, V> bv = NLDU<T, V>(a.b + fo, voff);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             o.v[i] = bv.v[i] - ax.v[i];
             acc0 += (double)o.v[i] * (double)o.v[i];
             acc1 += (double)xm.v[i] * (double)xm.v[i];
         }
-        if (a.out2 != nullptr) stu_t<T, V>(a.out2 + fo, voff, o);
+        if (a.out2 != nullptr) NSTU<T, V>(a.out2 + fo, voff, o);
     }
-    stu_t<T, V>(a.out + fo, voff, o);
+    NSTU<T, V>(a.out + fo, voff, o);
 }
 
 constexpr int NS_TWN = 8;
