@@ -75,13 +75,22 @@ __device__ __forceinline__ double sg2_ld(Rsrc r, unsigned off, double) {
     const sg2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
     return __longlong_as_double(((long long)v.y << 32) | (unsigned)v.x);
 }
-__device__ __forceinline__ void sg2_st(Rsrc r, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, (int)off, 0, 0); }
+#ifndef TV_SG2_NT
+#define TV_SG2_NT 0            // 1: EXPERIMENT stores (G / x_out / norms) and x0 loads non-temporal (aux bit 1): 5 - 10 % SLOWER with 4-byte lanes (hybrid loop 7.5 -> 8.1 ms)
+#endif
+constexpr int SG2_AUX_S = TV_SG2_NT ? 2 : 0;
+__device__ __forceinline__ float sg2_ld_s(Rsrc r, unsigned off, float) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, SG2_AUX_S)); }
+__device__ __forceinline__ double sg2_ld_s(Rsrc r, unsigned off, double) {
+    const sg2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, SG2_AUX_S);
+    return __longlong_as_double(((long long)v.y << 32) | (unsigned)v.x);
+}
+__device__ __forceinline__ void sg2_st(Rsrc r, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, (int)off, 0, SG2_AUX_S); }
 __device__ __forceinline__ void sg2_st(Rsrc r, unsigned off, double v) {
     const long long b = __double_as_longlong(v);
     sg2_v2i w;
     w.x = (int)b;
     w.y = (int)(b >> 32);
-    __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)off, 0, SG2_AUX_S);
 }
 template <typename T> __device__ __forceinline__ void pin1(T& a);
 template <> __device__ __forceinline__ void pin1<float>(float& a) { asm volatile("" : "+v"(a)); }
@@ -324,7 +333,7 @@ struct SgCol {
             if (MODE == 1 && TV_SG2_X0_AHEAD) {
                 const Rsrc r0 = sg2_rsrc<T>(sa.x0 + (long long)(zl - 1) * g.s_z + foff_t(0), store && fstore(0), fbytes);
 #pragma unroll
-                for (int i = 0; i < R; ++i) x0q.v[i] = sg2_ld(r0, soff[i], T(0));
+                for (int i = 0; i < R; ++i) x0q.v[i] = sg2_ld_s(r0, soff[i], T(0));
             }
             if (HEADS) {
 #pragma unroll
@@ -625,7 +634,7 @@ struct SgCol {
                         if (!TV_SG2_X0_AHEAD) {
                             const Rsrc r0 = sg2_rsrc<T>(sa.x0 + foff, st, fbytes);
 #pragma unroll
-                            for (int i = 0; i < R; ++i) x0q.v[i] = sg2_ld(r0, soff[i], T(0));
+                            for (int i = 0; i < R; ++i) x0q.v[i] = sg2_ld_s(r0, soff[i], T(0));
                         }
                         T e2 = T(0);
 #pragma unroll
