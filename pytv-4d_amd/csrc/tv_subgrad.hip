@@ -12,13 +12,4 @@ int tv_subgrad_fused(const tv_geom* g, const void* x, const void* x_prev, const 
                         "tv_subgrad_fused on a slab needs two halo planes on each interior side");
 }
 
-int tv_subgrad_fused_norms(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, void* norms,
-                           double* tvout, void* ws, void* stream) {
-    if (G == nullptr || norms == nullptr) return fail(TV_E_ARG, "NULL array");
-    SgHostArgs sa{};
-    sa.norms = norms;
-    return sg_launch<2>(g, x, x_prev, x_next, G, tvout, nullptr, ws, stream, sa,
-                        "tv_subgrad_fused_norms on a slab needs two halo planes on each interior side");
-}
-
 }  // extern "C"
