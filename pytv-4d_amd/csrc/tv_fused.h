@@ -709,6 +709,23 @@ template <typename T> struct FixupArgsT {
 using FixupArgs = FixupArgsT<float>;
 
 // all missing terms of one site-vector; returns its fidelity 1/2 |x_out - x0|^2 (0 if nothing was missing)
+#ifndef TV_FIXUP_NT
+#define TV_FIXUP_NT 1            // the vector streams of the fix-up (q' rows, x_out read-modify-write, x0) non-temporal: 2.92 -> 2.73 ms on the north star (0: plain)
+#endif
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> FXLD(const T* p) {
+#if TV_FIXUP_NT
+    return vload_s<T, V>(p);
+#else
+    return vload<T, V>(p);
+#endif
+}
+template <typename T, int V> __device__ __forceinline__ void FXST(T* p, const Vec<T, V>& a) {
+#if TV_FIXUP_NT
+    vstore_s<T, V>(p, a);
+#else
+    vstore<T, V>(p, a);
+#endif
+}
 // ALG_ADMM: `q` is the array of t', `x_out` the residual r, tau = -rho (r += rho s m), the returned partial is r^2 (no x0)
 template <int S, bool XW, typename T = float, int ALG = ALG_CP>
 __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const FixupArgsT<T>& a, int zchunk, int zl, int t, int y,
@@ -726,8 +743,8 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const 
     const VT zero = vsplat<T, V>(T(0));
     VT m = zero;
     // a missing term counts only where the neighbour's channel is defined (central: interior points of the axis)
-    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + vload<T, V>(qb + (long long)c_ru * g.s_z - g.nx);
-    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - vload<T, V>(qb + (long long)c_rd * g.s_z + g.nx);
+    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + FXLD<T, V>(qb + (long long)c_ru * g.s_z - g.nx);
+    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - FXLD<T, V>(qb + (long long)c_rd * g.s_z + g.nx);
     if (UP && (col0 & CM) == 0 && col0 >= (CEN ? 2 : 1)) m.v[0] += qb[(long long)c_cu * g.s_z - 1];
     if (DN && (col0 & CM) == CM - (V - 1) && col0 + V <= g.nx - (CEN ? 2 : 1)) m.v[V - 1] -= qb[(long long)c_cd * g.s_z + V];
     if (g.za) {
@@ -735,11 +752,11 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const 
         const int zs = (zl / zchunk) * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
         if (UP && zl == zs && gz >= ((CEN && !z_fwd) ? 2 : 1)) {
-            const VT u = (zl >= 1) ? vload<T, V>(qb + (long long)c_zu * g.s_z - g.s_dz) : vload<T, V>(a.qp + inpl);
+            const VT u = (zl >= 1) ? FXLD<T, V>(qb + (long long)c_zu * g.s_z - g.s_dz) : FXLD<T, V>(a.qp + inpl);
             m = m + w.wz * u;
         }
         if (DN && !z_fwd && zl == ze - 1 && gz <= g.nzg - (CEN ? 3 : 2)) {
-            const VT d = (zl + 1 < g.nz) ? vload<T, V>(qb + (long long)c_zd * g.s_z + g.s_dz) : vload<T, V>(a.qn + inpl);
+            const VT d = (zl + 1 < g.nz) ? FXLD<T, V>(qb + (long long)c_zd * g.s_z + g.s_dz) : FXLD<T, V>(a.qn + inpl);
             m = m - w.wz * d;
         }
     }
@@ -747,16 +764,16 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const 
         const int c_tu = g.ch_t, c_td = (S == HYBRID) ? g.ch_t + 1 : g.ch_t;
         const int k = t % CP_TWN;
         VT mt = zero;       // every sample with the per-voxel factor of ITS frame (1 without a weight volume)
-        if (UP && k == 0 && t >= 1) mt = mt + vload<T, V>(qb + (long long)c_tu * g.s_z - g.s_t) * vol_factor<T, V>(g, zl, t - 1, y, col0);
+        if (UP && k == 0 && t >= 1) mt = mt + FXLD<T, V>(qb + (long long)c_tu * g.s_z - g.s_t) * vol_factor<T, V>(g, zl, t - 1, y, col0);
         if (DN && k == CP_TWN - 1 && t <= g.m - (CEN ? 3 : 2))
-            mt = mt - vload<T, V>(qb + (long long)c_td * g.s_z + g.s_t) * vol_factor<T, V>(g, zl, t + 1, y, col0);
+            mt = mt - FXLD<T, V>(qb + (long long)c_td * g.s_z + g.s_t) * vol_factor<T, V>(g, zl, t + 1, y, col0);
         m = m + (w.wt * mt) * mask_factor<T, V>(g, w.sf, y, col0);
     }
     const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : (CEN ? T(0.5) : T(1));
     const long long off = (long long)zl * g.s_z + inpl;
-    const VT xv = vload<T, V>(a.x_out + off);
+    const VT xv = FXLD<T, V>(a.x_out + off);
     VT x0v = zero;
-    if constexpr (ALG == ALG_CP) x0v = vload<T, V>(a.x0 + off);
+    if constexpr (ALG == ALG_CP) x0v = FXLD<T, V>(a.x0 + off);
     VT xo;
     double acc = 0.0;
 #pragma unroll
@@ -765,7 +782,7 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const 
         const double e = (double)xo.v[i] - (double)x0v.v[i];
         acc += (ALG == ALG_CP ? 0.5 : 1.0) * e * e;
     }
-    vstore<T, V>(a.x_out + off, xo);
+    FXST<T, V>(a.x_out + off, xo);
     return acc;
 }
 
