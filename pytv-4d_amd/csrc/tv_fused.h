@@ -1,5 +1,7 @@
 // tv_fused.h -- ONE-SWEEP Chambolle-Pock iteration (README.md:145-157 of the reference) for all four schemes,
-// fp32, 16-byte lanes.
+// fp32 and (round 3) fp64, 16-byte lanes (4 or 2 columns).  The same sweep, with the template parameter ALG, is the dual side of
+// the ADMM outer iteration (ALG_ADMM: tv_admm_fused) and the TV part of Chambolle-Pock with a data-fidelity operator (ALG_CPOP:
+// tv_cpop_fused) -- see the comment at ALG_CP below.
 //
 // The two-kernel form (tv_cp_dual + tv_cp_primal) reads the dual variable q twice and writes it once
 // per iteration: 30 words/voxel at Nd = 8.  Here the primal update of plane z-1 is done in the same
