@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void k_l21(DG g, const T* d, T* norms, double*
         const T* base = d + (long long)c.zl * g.s_dz + inpl;
         Vec<T, V> s = vsplat<T, V>(T(0));
         for (int ch = 0; ch < g.nd; ++ch) {
-            const Vec<T, V> v = vload<T, V>(base + (long long)ch * g.s_z);
+            const Vec<T, V> v = vload_s<T, V>(base + (long long)ch * g.s_z);       // read once: non-temporal (tv_device.h)
             s = s + v * v;
         }
         Vec<T, V> n;
@@ -560,18 +560,35 @@ __global__ __launch_bounds__(256) void k_l21(DG g, const T* d, T* norms, double*
     if (threadIdx.x == 0 && threadIdx.y == 0) partials[linear_block_id()] = acc;
 }
 
+#ifndef TV_CG_NT
+#define TV_CG_NT 1               // the streams of the flat kernels (every array read / written once) non-temporal: k_cgcg -2 % on the CG outer iteration; read-only streams gain most (tv_l21 0.71 -> 0.81 - 0.88 of 8 TB/s with nt loads); 0: plain
+#endif
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> CGLD(const T* p) {
+#if TV_CG_NT
+    return vload_s<T, V>(p);
+#else
+    return vload<T, V>(p);
+#endif
+}
+template <typename T, int V> __device__ __forceinline__ void CGST(T* p, const Vec<T, V>& a) {
+#if TV_CG_NT
+    vstore_s<T, V>(p, a);
+#else
+    vstore<T, V>(p, a);
+#endif
+}
 // =============================================================================================
 // flat streaming kernels (grid-stride, one V-wide 16-byte vector per lane per trip; nv = n / V vectors)
 // =============================================================================================
 template <typename T, int V> __global__ __launch_bounds__(256) void k_sub(long long nv, const T* a, const T* b, T* out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x)
-        vstore<T, V>(out + i * V, vload<T, V>(a + i * V) - vload<T, V>(b + i * V));
+        CGST<T, V>(out + i * V, CGLD<T, V>(a + i * V) - CGLD<T, V>(b + i * V));
 }
 template <typename T, int V> __global__ __launch_bounds__(256) void k_dot(long long nv, const T* a, const T* b, double* partials) {
     __shared__ double sm[16];
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
-        const Vec<T, V> av = vload<T, V>(a + i * V), bv = vload<T, V>(b + i * V);
+        const Vec<T, V> av = CGLD<T, V>(a + i * V), bv = CGLD<T, V>(b + i * V);
 #pragma unroll
         for (int k = 0; k < V; ++k) acc += (double)av.v[k] * (double)bv.v[k];
     }
@@ -587,9 +604,9 @@ __global__ __launch_bounds__(256) void k_cg1(long long nv, T* x, T* r, const T* 
     const T alpha = (den > 0.0) ? (T)(*rs / den) : T(0);
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
-        vstore<T, V>(x + i * V, vload<T, V>(x + i * V) + alpha * vload<T, V>(d + i * V));
-        const Vec<T, V> rn = vload<T, V>(r + i * V) - alpha * vload<T, V>(Ad + i * V);
-        vstore<T, V>(r + i * V, rn);
+        CGST<T, V>(x + i * V, CGLD<T, V>(x + i * V) + alpha * CGLD<T, V>(d + i * V));
+        const Vec<T, V> rn = CGLD<T, V>(r + i * V) - alpha * CGLD<T, V>(Ad + i * V);
+        CGST<T, V>(r + i * V, rn);
 #pragma unroll
         for (int k = 0; k < V; ++k) acc += (double)rn.v[k] * (double)rn.v[k];
     }
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(256) void k_cg2(long long nv, T* d, const T* r, con
     const double den = *rs;
     const T beta = (den > 0.0) ? (T)(*rs_new / den) : T(0);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x)
-        vstore<T, V>(d + i * V, vload<T, V>(r + i * V) + beta * vload<T, V>(d + i * V));
+        CGST<T, V>(d + i * V, CGLD<T, V>(r + i * V) + beta * CGLD<T, V>(d + i * V));
 }
 // single-reduction CG (Chronopoulos-Gear): sc = {gamma = <r,r>, delta = <r,w>, gamma_old, alpha_old}; alpha_old == 0 marks
 // the first step of a solve.  d = r + beta d; s = w + beta s; x += alpha d; r -= alpha s; optional partial 1/2 |x - x0|^2
@@ -612,23 +629,6 @@ __device__ __forceinline__ void cgcg_scalars(const double* sc, double& alpha, do
     beta = (!first && gamma_old > 0.0) ? gamma / gamma_old : 0.0;
     const double den = first ? delta : delta - beta * gamma / alpha_old;
     alpha = (den > 0.0) ? gamma / den : 0.0;
-}
-#ifndef TV_CG_NT
-#define TV_CG_NT 1               // the nine streams of k_cgcg non-temporal: the CG outer iteration -2 % (upwind 28.2 -> 27.5 ms, interleaved; 0: plain)
-#endif
-template <typename T, int V> __device__ __forceinline__ Vec<T, V> CGLD(const T* p) {
-#if TV_CG_NT
-    return vload_s<T, V>(p);
-#else
-    return vload<T, V>(p);
-#endif
-}
-template <typename T, int V> __device__ __forceinline__ void CGST(T* p, const Vec<T, V>& a) {
-#if TV_CG_NT
-    vstore_s<T, V>(p, a);
-#else
-    vstore<T, V>(p, a);
-#endif
 }
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_cgcg(long long nv, T* x, T* r, T* d, T* s, const T* w, const double* sc, const T* x0,
@@ -678,9 +678,9 @@ __global__ __launch_bounds__(256) void k_sub_dot(long long nv, const T* a, const
     __shared__ double sm[16];
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
-        const Vec<T, V> o = vload<T, V>(a + i * V) - vload<T, V>(b + i * V);
-        vstore<T, V>(out + i * V, o);
-        if (out2 != nullptr) vstore<T, V>(out2 + i * V, o);
+        const Vec<T, V> o = CGLD<T, V>(a + i * V) - CGLD<T, V>(b + i * V);
+        CGST<T, V>(out + i * V, o);
+        if (out2 != nullptr) CGST<T, V>(out2 + i * V, o);
 #pragma unroll
         for (int k = 0; k < V; ++k) acc += (double)o.v[k] * (double)o.v[k];
     }
@@ -695,8 +695,8 @@ __global__ __launch_bounds__(256) void k_cheb_combine(long long nv, const T* x, 
     __shared__ double sm[16];
     double acc0 = 0.0, acc1 = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
-        const Vec<T, V> xv = vload<T, V>(x + i * V), ax = vload<T, V>(out + i * V), bv = vload<T, V>(b + i * V);
-        const Vec<T, V> yv = (y != nullptr) ? vload<T, V>(y + i * V) : yscale * bv;
+        const Vec<T, V> xv = CGLD<T, V>(x + i * V), ax = CGLD<T, V>(out + i * V), bv = CGLD<T, V>(b + i * V);
+        const Vec<T, V> yv = (y != nullptr) ? CGLD<T, V>(y + i * V) : yscale * bv;
         Vec<T, V> o;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -704,15 +704,15 @@ __global__ __launch_bounds__(256) void k_cheb_combine(long long nv, const T* x, 
             o.v[k] = (xv.v[k] + alpha * res) + beta * (xv.v[k] - yv.v[k]);
             acc0 += (double)res * (double)res;
         }
-        if (add != nullptr) o = vload<T, V>(add + i * V) + o;
+        if (add != nullptr) o = CGLD<T, V>(add + i * V) + o;
         Vec<T, V> rv = xv;
-        if (ref != nullptr) rv = vload<T, V>(ref + i * V);
+        if (ref != nullptr) rv = CGLD<T, V>(ref + i * V);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             const double e = (ref != nullptr) ? (double)o.v[k] - (double)rv.v[k] : (double)xv.v[k];
             acc1 += e * e;
         }
-        vstore<T, V>(out + i * V, o);
+        CGST<T, V>(out + i * V, o);
     }
     acc0 = block_sum(acc0, sm);
     if (threadIdx.x == 0) part0[blockIdx.x] = acc0;
@@ -725,17 +725,17 @@ __global__ __launch_bounds__(256) void k_axpby(long long nv, T a, const T* x, T 
     __shared__ double sm[16];
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
-        Vec<T, V> o = a * vload<T, V>(x + i * V);
-        if (y != nullptr) o = o + b * vload<T, V>(y + i * V);
+        Vec<T, V> o = a * CGLD<T, V>(x + i * V);
+        if (y != nullptr) o = o + b * CGLD<T, V>(y + i * V);
         if (ref != nullptr) {
-            const Vec<T, V> rv = vload<T, V>(ref + i * V);
+            const Vec<T, V> rv = CGLD<T, V>(ref + i * V);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const double e = (double)o.v[k] - (double)rv.v[k];
                 acc += e * e;
             }
         }
-        vstore<T, V>(out + i * V, o);
+        CGST<T, V>(out + i * V, o);
     }
     if (ref != nullptr) {
         acc = block_sum(acc, sm);
@@ -747,14 +747,14 @@ __global__ __launch_bounds__(256) void k_axpby(long long nv, T a, const T* x, T 
 //   k_cpop_res: r <- Ax - b,  partial 1/2 |r|^2
 template <typename T, int V> __global__ __launch_bounds__(256) void k_cpop_p(long long nv, T* p, const T* r, T sigma, T inv) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x)
-        vstore<T, V>(p + i * V, inv * (vload<T, V>(p + i * V) + sigma * vload<T, V>(r + i * V)));
+        CGST<T, V>(p + i * V, inv * (CGLD<T, V>(p + i * V) + sigma * CGLD<T, V>(r + i * V)));
 }
 template <typename T, int V> __global__ __launch_bounds__(256) void k_cpop_res(long long nv, const T* ax, const T* b, T* r, double* partials) {
     __shared__ double sm[16];
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
-        const Vec<T, V> o = vload<T, V>(ax + i * V) - vload<T, V>(b + i * V);
-        vstore<T, V>(r + i * V, o);
+        const Vec<T, V> o = CGLD<T, V>(ax + i * V) - CGLD<T, V>(b + i * V);
+        CGST<T, V>(r + i * V, o);
 #pragma unroll
         for (int k = 0; k < V; ++k) acc += 0.5 * (double)o.v[k] * (double)o.v[k];
     }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void k_sgstep(long long nv, T* x, const T* x0,
     __shared__ double sm[16];
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
-        const Vec<T, V> xv = vload<T, V>(x + i * V), x0v = vload<T, V>(x0 + i * V), gv = vload<T, V>(G + i * V);
+        const Vec<T, V> xv = CGLD<T, V>(x + i * V), x0v = CGLD<T, V>(x0 + i * V), gv = CGLD<T, V>(G + i * V);
         Vec<T, V> xn;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256) void k_sgstep(long long nv, T* x, const T* x0,
             const double e = (double)xn.v[k] - (double)x0v.v[k];
             acc += 0.5 * e * e;
         }
-        vstore<T, V>(x + i * V, xn);
+        CGST<T, V>(x + i * V, xn);
     }
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
