@@ -188,6 +188,16 @@ __global__ __launch_bounds__(256, LIGHT ? 3 : ((PF || M > 8) ? 2 : 1)) void k_D_
 // State per frame: A = backward-looking z channel one plane below (y^(z-1)), B = the forward-looking
 // channel's centre plane (loaded as "z+1" one step earlier); central keeps (z-1, z) of one channel.
 // =============================================================================================
+#ifndef TV_DT_NT
+#define TV_DT_NT 0               // 1: EXPERIMENT the read-once streams of k_DT_march non-temporal: much SLOWER (tv_DT hybrid 3.6 -> 6.3 ms: the border scalars and row taps of neighbouring threads want those lines in the cache)
+#endif
+__device__ __forceinline__ Vec<float, 4> DTLD(const float* p) {
+#if TV_DT_NT
+    return vload_s<float, 4>(p);
+#else
+    return vload<float, 4>(p);
+#endif
+}
 template <int S, int M, typename Epi>
 __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float* __restrict__ q, const float* __restrict__ qp,
                                                   const float* __restrict__ qn, int zchunk, Epi epi) {
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float
     constexpr bool ZF = (S == DOWNWIND || S == HYBRID || S == CENTRAL);  // some channel looks forwards in z
 
     auto ldq = [&](int zl, int ch, long long off) -> V4 {   // q[zl, ch] at in-plane offset off
-        return vload<float, 4>(q + (long long)zl * g.s_dz + (long long)ch * g.s_z + off);
+        return DTLD(q + (long long)zl * g.s_dz + (long long)ch * g.s_z + off);          // z / time channels: each sample is read once
     };
 
     V4 A[M], B[M];
@@ -256,8 +266,8 @@ __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float
             auto cols = [&](auto mode, int ch) {
                 constexpr int MD = decltype(mode)::value;
                 const float* pch = q + off0 + (long long)ch * g.s_z;
-                const V4 ce = c.ok ? vload<float, 4>(pch) : zero;
-                float left, right;
+                const V4 ce = c.ok ? DTLD(pch) : zero;                 // column channels: the row neighbours of the ROW channels come from
+                float left, right;                                     // the cache (plain loads), everything else is read once
                 col_neighbours<(MD != 1), (MD != 0)>(ce, pch, c.ok, c.lane, c.col0, g.nx, left, right);
                 const V4 lo = shift_right<float, 4>(ce, left);
                 const V4 hi = shift_left<float, 4>(ce, right);
