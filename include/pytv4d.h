@@ -196,9 +196,11 @@ int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* 
  *   *tv = |D x|_{2,1};  *rr = <r, r> over the sites that are already complete (device fp64, local planes)
  * EXCEPT, exactly as in tv_cp_fused, the adjoint terms that cross a wave tile, a z-chunk, a time window or the slab:
  * tv_admm_fixup adds those to r (t_prev / t_next: halo planes of t' as y_prev / y_next in tv_DT) and returns <r, r> of
- * the sites it completed; total = sum of the two.  t (same shape as u) receives t': every sample if full_store != 0
+ * the sites it completed; total = sum of the two.  t (same shape as u) receives t': every sample if bit 0 of full_store is set
  * (then z = t' + u + D x), otherwise only the samples the fix-up and the neighbouring ranks read (the rest of the array is
- * left untouched).  2 Nd + 3 words per voxel where tv_admm_tu + tv_DT_axpy + tv_normal_op2(b) move 4 Nd + 6.
+ * left untouched).  Bit 1 of full_store: *rr = |x - x0|^2 over ALL local sites instead (a solver that needs no <r, r> -- the Chebyshev
+ * x-solve -- gets the fidelity of the iterate for free; tv_admm_fixup's *rr is then meaningless).
+ * 2 Nd + 3 words per voxel where tv_admm_tu + tv_DT_axpy + tv_normal_op2(b) move 4 Nd + 6.
  * Chunk / plane ranges as in tv_cp_fused / tv_cp_fixup.  Replaces: nothing in the reference (README.md:26,135 name ADMM only). */
 int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* u, void* t, const void* x0, void* r,
                   double thresh, double rho, int32_t full_store, int64_t chunk_begin, int64_t chunk_count, double* tv, double* rr,

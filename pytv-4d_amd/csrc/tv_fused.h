@@ -262,7 +262,7 @@ template <typename T> struct FusedArgsT {
     T sigma, inv_lambda, tau, sigma_a, inv_1p_sigma_a;
     double* part_tv;
     double* part_fid;
-    int full_store;       // ALG_ADMM: 1 = every sample of t' is stored (z stays recoverable), 0 = only what the fix-up reads
+    int full_store;       // ALG_ADMM: bit 0 = every sample of t' is stored (z stays recoverable; else only what the fix-up reads), bit 1 = the second partial is |x - x0|^2
 };
 using FusedArgs = FusedArgsT<float>;
 
@@ -390,14 +390,19 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
         if constexpr (ALG == ALG_ADMM) {      // r = (x0 - x) + rho D^T t'
             const VT x0v = ldu_s_t<T, V>(a.x0 + foff, voff);
             VT ro;
-            double r2 = 0.0;
+            double r2 = 0.0, f2 = 0.0;
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                ro.v[i] = (x0v.v[i] - xv.v[i]) + a.tau * (s * racc.v[i]);
+                const T e = x0v.v[i] - xv.v[i];
+                ro.v[i] = e + a.tau * (s * racc.v[i]);
                 r2 += (double)ro.v[i] * (double)ro.v[i];
+                f2 += (double)e * (double)e;
             }
             stu_s_t<T, V>(a.x_out + foff, voff, ro);
-            if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += r2;
+            // second partial: <r, r> over the complete sites (what CG starts from), or -- full_store bit 1, the Chebyshev x-solve, which
+            // needs no <r, r> -- |x - x0|^2 over ALL sites (the fidelity of the iterate: one word less in the solve's last step)
+            if (a.full_store & 2) acc_fid += f2;
+            else if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += r2;
             return;
         }
         if constexpr (ALG == ALG_CPOP) {      // x_out = (x - tau A^T p) - tau D^T q'   (the arithmetic of tv_DT_axpy2)
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
                         constexpr int axis = (S == HYBRID) ? ((k < 4) ? (k & 1) : (k >> 1)) : k;          // 0 rows, 1 cols, 2 z, 3 t
                         constexpr bool up_role = (S != HYBRID) || (k == 0 || k == 1 || k == 4 || k == 6);
                         constexpr bool dn_role = (S != HYBRID) || !up_role;
-                        if (a.full_store || (up_role && st_u[axis]) || (dn_role && st_d[axis]))
+                        if ((a.full_store & 1) || (up_role && st_u[axis]) || (dn_role && st_d[axis]))
 #if TV_ADMM_T_NT
                             stu_s_t<T, V>(tbase + (long long)ch * g.s_z, voff, v[k]);
 #else

@@ -227,7 +227,7 @@ int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const voi
     double* w1 = w0 + sp.nmax + kStage + 16;
     auto sweep = [&]<typename T>() -> int {
         FusedArgsT<T> a{(const T*)x, (const T*)x_prev, (const T*)x_next, (T*)u, (const T*)x0, (T*)t,
-                        (T*)r, (T)thresh, (T)0, (T)rho, (T)0, (T)0, w0, w1, full_store ? 1 : 0};
+                        (T*)r, (T)thresh, (T)0, (T)rho, (T)0, (T)0, w0, w1, (int)(full_store & 3)};
         return tvm::fused_sweep<T, ALG_ADMM>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
     };
     const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();

@@ -789,13 +789,16 @@ class ADMM(_SlabProblem):
             self._cheb_range(v, *args, 0, nz, hp, hn, dots)
 
     def _solve_cheb(self, fid_slot):
-        """x <- x + e_K, e_K = K Chebyshev steps on A e = r (self.r = b - A x); fid_slot <- |x - x0|^2 (local)."""
+        """x <- x + e_K, e_K = K Chebyshev steps on A e = r (self.r = b - A x); fid_slot <- |x - x0|^2 (local), or None if the caller
+        takes the fidelity from the sweep that follows."""
         g, lib, K, coef = self.geo, self.lib, self.n_cg, self._cheb_coef
         bufs = [self.d, self.Ad, self.b]                  # all free between two solves
         a0 = coef[0][0]
+        ref = self.x0 if fid_slot is not None else None
         if K == 1:
-            _nv.check(lib.tv_axpby(g.ref, a0, _nv.ptr(self.r), 1.0, _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(bufs[0]),
-                                   fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
+            _nv.check(lib.tv_axpby(g.ref, a0, _nv.ptr(self.r), 1.0, _nv.ptr(self.x), _nv.ptr(ref), _nv.ptr(bufs[0]),
+                                   fid_slot.data_ptr() if fid_slot is not None else None, _nv.ptr(self.ws) if fid_slot is not None else None,
+                                   self.stream))
             last = 0
         else:
             # e_1 = a0 r is never stored: the first kernel forms e_2 = e_1 + alpha_1 (r - A e_1) + beta_1 e_1 from r alone (x = b = r:
@@ -804,13 +807,14 @@ class ADMM(_SlabProblem):
             ap = al1 * a0
             bp = a0 + al1 + be1 * a0 - 1.0 - ap
             fin = (K == 2)
-            self._cheb_step(self.r, None, 0.0, self.x if fin else None, self.x0 if fin else None, bufs[0], ap, bp, self.dots)
+            self._cheb_step(self.r, None, 0.0, self.x if fin else None, ref if fin else None, bufs[0], ap, bp, self.dots)
             for k in range(2, K):         # e_k lives in bufs[(k - 2) % 3]
                 fin = (k + 1 == K)
                 alpha, beta = coef[k]
                 self._cheb_step(bufs[(k - 2) % 3], bufs[(k - 3) % 3] if k >= 3 else None, a0 if k == 2 else 0.0,
-                                self.x if fin else None, self.x0 if fin else None, bufs[(k - 1) % 3], alpha, beta, self.dots)
-            fid_slot.copy_(self.dots[1:2])
+                                self.x if fin else None, ref if fin else None, bufs[(k - 1) % 3], alpha, beta, self.dots)
+            if fid_slot is not None:
+                fid_slot.copy_(self.dots[1:2])
             last = (K - 2) % 3
         # the new image was written next to the old one: swap the roles (the old x becomes a scratch vector)
         self.x, bufs[last] = bufs[last], self.x
@@ -873,15 +877,18 @@ class ADMM(_SlabProblem):
         _nv.check(lib.tv_sub(code, self.x.numel(), _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(self.r), self.stream))
         _nv.check(lib.tv_dot(g.ref, _nv.ptr(self.r), _nv.ptr(self.r), out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
 
-    def _zu_fused(self, out_tv):
-        """z / u update and r = b - A x of the next solve in one sweep + fix-up; gamma = <r, r> (local) into sc[0]."""
+    def _zu_fused(self, out_tv, out_fid=None):
+        """z / u update and r = b - A x of the next solve in one sweep + fix-up; gamma = <r, r> (local) into sc[0] -- or, with the
+        Chebyshev x-solve (which needs no gamma), |x - x0|^2 of the iterate into out_fid."""
         g, lib, s, nz = self.geo, self.lib, self.slab, self.slab.nz
         hp, hn = self._halo2(self.x)
         xp = hp[1:2] if hp is not None else None      # plane z0-1
         xn = hn[0:1] if hn is not None else None      # plane z0+nz
         _nv.check(lib.tv_admm_fused(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.u), _nv.ptr(self._zt),
-                                    _nv.ptr(self.x0), _nv.ptr(self.r), self.reg / self.rho, self.rho, 1 if self.keep_z else 0,
-                                    0, -1, out_tv.data_ptr(), self.rr[0:1].data_ptr(), _nv.ptr(self.ws), self.stream))
+                                    _nv.ptr(self.x0), _nv.ptr(self.r), self.reg / self.rho, self.rho,
+                                    (1 if self.keep_z else 0) | (2 if out_fid is not None else 0),
+                                    0, -1, out_tv.data_ptr(), (out_fid if out_fid is not None else self.rr[0:1]).data_ptr(),
+                                    _nv.ptr(self.ws), self.stream))
         # the boundary planes of t' travel to the neighbours (as those of t = z - u do in _rhs)
         h = s.exchange(send_prev=self._zt[0, self.ch_fwd] if self.plan.g_send_prev else None,
                        send_next=self._zt[nz - 1, self.ch_back] if self.plan.g_send_next else None,
@@ -890,7 +897,8 @@ class ADMM(_SlabProblem):
         s.wait(h)
         _nv.check(lib.tv_admm_fixup(g.ref, _nv.ptr(self._zt), _nv.ptr(self.wh_prev), _nv.ptr(self.wh_next), _nv.ptr(self.r), self.rho,
                                     0, -1, self.rr[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
-        torch.sum(self.rr, dim=0, keepdim=True, out=self.sc[0:1])
+        if out_fid is None:
+            torch.sum(self.rr, dim=0, keepdim=True, out=self.sc[0:1])
         self._have_r = True
 
     def _step_single(self, out):
@@ -903,10 +911,11 @@ class ADMM(_SlabProblem):
             sc[0:1].copy_(self.dots[0:1])
         # (one-sweep path: r and gamma were left by the sweep that closed the previous outer iteration)
         if self.cheb:
-            self._solve_cheb(out[1:2])
-            if self.fused:
-                self._zu_fused(out[0:1])
+            if self.fused:      # the sweep that follows reads x and x0 anyway: it returns |x - x0|^2, the solve's last step skips x0
+                self._solve_cheb(None)
+                self._zu_fused(out[0:1], out[1:2])
             else:
+                self._solve_cheb(out[1:2])
                 self._zu(out[0:1])
             return
         sc, w, sv = self.sc, self.b, self.Ad          # (b may have been rebound by an earlier Chebyshev solve: take it again)

@@ -78,6 +78,11 @@ def test_admm_fused_calls_match_numpy(nvlib, scheme, shape, zchunk, tvopt):
                 np.testing.assert_allclose(td.cpu().numpy(), t - dx, rtol=0, atol=tol * 10)
             else:
                 assert (td == 7.0).float().mean().item() > 0.3          # most samples are never written
+        # bit 1 of full_store: the second partial is |x - x0|^2 over all sites (what the Chebyshev x-solve asks for)
+        ud = torch.as_tensor(u).cuda()
+        nv.check(lib.tv_admm_fused(g.ref, nv.ptr(xd), None, None, nv.ptr(ud), nv.ptr(td), nv.ptr(x0d), nv.ptr(rd), thresh, rho, 2,
+                                   0, -1, sc[0:1].data_ptr(), sc[1:2].data_ptr(), nv.ptr(ws), st))
+        np.testing.assert_allclose(sc[1].item(), np.sum((x.astype(np.float64) - x0.astype(np.float64)) ** 2), rtol=max(tol, 1e-12) * 10)
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)

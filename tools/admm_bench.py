@@ -29,8 +29,9 @@ for scheme in ("upwind", "downwind", "central", "hybrid"):
         # residual with the copy (4) + n_cg (normal op 2, cg1 6, cg2 3) + z/u (1 + 3 Nd) + fidelity (sub 3 + dot 2);
         # one-sweep: sweep (x, x0 read, r written, u read + written: 2 Nd + 3; + Nd with keep_z) + n_cg (2 + 9) - 1
         # + chebyshev: the x-solve is e_2 from r alone (2), a step with y = a0 r formed on the fly (3), n_cg - 4 steps of 4 (e_k with its
-        # stencil, r, e_{k-1} read; e_{k+1} written) and a last step of 6 (+ x, x0 read; the new x written instead of e): 4 n_cg - 5 words
-        words = {"one-sweep+chebyshev": 2 * nd + 3 + 4 * n_cg - 5, "one-sweep": 2 * nd + 11 * n_cg + 2, "one-sweep keep_z": 3 * nd + 11 * n_cg + 2, "single-reduction": 4 * nd + 11 * n_cg + 5,
+        # stencil, r, e_{k-1} read; e_{k+1} written) and a last step of 5 (+ x read; the new x written instead of e; |x - x0|^2 comes
+        # from the sweep that follows): 4 n_cg - 6 words
+        words = {"one-sweep+chebyshev": 2 * nd + 3 + 4 * n_cg - 6, "one-sweep": 2 * nd + 11 * n_cg + 2, "one-sweep keep_z": 3 * nd + 11 * n_cg + 2, "single-reduction": 4 * nd + 11 * n_cg + 5,
                  "textbook CG": 5 * nd + 11 * n_cg + 12}[name]
         print("%-9s Nd=%d %-19s %.2f ms/outer  %.1f it/s  loss %.6e -> %.6e  | algorithmic %.0f words/voxel -> %.0f GB/s" % (
             scheme, nd, name, dt * 1e3, 1 / dt, loss[0], loss[-1], words, words * 4.0 * V / dt / 1e9))
