@@ -725,7 +725,8 @@ class ADMM(_SlabProblem):
 
     @property
     def z(self):
-        """The split variable z (single_reduction keeps t = z - u: z = t + u; the one-sweep path keeps t' = t - D x)."""
+        """The split variable z (single_reduction keeps t = z - u: z = t + u; the one-sweep path keeps t' = t - D x and recomputes
+        D x -- on a sharded slab that is a halo exchange, so every rank has to ask for z, not just one)."""
         if self.fused and self._have_r:
             if not self.keep_z:
                 raise RuntimeError("ADMM(keep_z=False) stores only the samples of z - u - D x its fix-up reads: z is not available")
