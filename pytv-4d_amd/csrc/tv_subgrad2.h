@@ -78,10 +78,11 @@ __device__ __forceinline__ double sg2_ld(Rsrc r, unsigned off, double) {
 #ifndef TV_SG2_NT
 #define TV_SG2_NT 0            // 1: EXPERIMENT stores (G / x_out / norms) and x0 loads non-temporal (aux bit 1): 5 - 10 % SLOWER with 4-byte lanes (hybrid loop 7.5 -> 8.1 ms)
 #endif
-constexpr int SG2_AUX_S = TV_SG2_NT ? 2 : 0;
-__device__ __forceinline__ float sg2_ld_s(Rsrc r, unsigned off, float) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, SG2_AUX_S)); }
+constexpr int SG2_AUX_S = (TV_SG2_NT == 1) ? 2 : 0;      // stores
+constexpr int SG2_AUX_L = (TV_SG2_NT != 0) ? 2 : 0;      // x0 loads (TV_SG2_NT=2: loads only -- no measurable difference, 6.9 - 7.1 ms either way)
+__device__ __forceinline__ float sg2_ld_s(Rsrc r, unsigned off, float) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, SG2_AUX_L)); }
 __device__ __forceinline__ double sg2_ld_s(Rsrc r, unsigned off, double) {
-    const sg2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, SG2_AUX_S);
+    const sg2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, SG2_AUX_L);
     return __longlong_as_double(((long long)v.y << 32) | (unsigned)v.x);
 }
 __device__ __forceinline__ void sg2_st(Rsrc r, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, (int)off, 0, SG2_AUX_S); }
