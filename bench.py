@@ -124,7 +124,7 @@ def live_traffic(args):
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None, "already running under a profiler"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pmc", "off",
-             "--workload", args.workload, "--scheme", args.scheme] + (["--two-kernel"] if args.two_kernel else [])
+             "--workload", args.workload, "--scheme", args.scheme, "--pitch", args.pitch] + (["--two-kernel"] if args.two_kernel else [])
     sums = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -172,6 +172,72 @@ def live_traffic(args):
     return {k: (v if v > 0 else None) for k, v in out.items()}, note
 
 
+def gpu_state(index=0):
+    """Clocks / power / temperature of GPU `index` read from sysfs (plain file reads: no HIP call, no child process, nothing that
+    talks to the SMU on its own).  Taken right before and right after the timed region so that a run that was clock- or
+    power-limited can be told from one that was not (round-3 verdict: the driver's fresh-box runs were 9 % slower than profiles/)."""
+    import glob
+    out = {}
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    if not cards:
+        # no sysfs view of the GPU (container): one short-lived rocm-smi child instead
+        import shutil, subprocess
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        try:
+            txt = subprocess.run([exe, "-d", str(index), "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True,
+                                 text=True, timeout=20).stdout
+            return {"rocm_smi": json.loads(txt)}
+        except Exception as exc:
+            return {"error": "no /sys/class/drm/card*/device/pp_dpm_sclk and rocm-smi failed: %s" % str(exc)[:120]}
+    dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+
+    def rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except Exception:
+            return None
+
+    def cur(path):          # "0: 132Mhz\n1: 2400Mhz *" -> the starred level (MHz)
+        txt = rd(path)
+        if not txt:
+            return None
+        for line in txt.splitlines():
+            if line.rstrip().endswith("*"):
+                try:
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+                except Exception:
+                    return line.strip()
+        return txt[:60]
+
+    out["sclk_mhz"] = cur(os.path.join(dev, "pp_dpm_sclk"))
+    out["mclk_mhz"] = cur(os.path.join(dev, "pp_dpm_mclk"))
+    out["fclk_mhz"] = cur(os.path.join(dev, "pp_dpm_fclk"))
+    out["socclk_mhz"] = cur(os.path.join(dev, "pp_dpm_socclk"))
+    out["perf_level"] = rd(os.path.join(dev, "power_dpm_force_performance_level"))
+    out["gpu_busy_percent"] = rd(os.path.join(dev, "gpu_busy_percent"))
+    out["mem_busy_percent"] = rd(os.path.join(dev, "mem_busy_percent"))
+    for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+        for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6), ("power1_cap", "power_cap_w", 1e-6),
+                                 ("temp1_input", "temp_edge_c", 1e-3), ("temp2_input", "temp_junction_c", 1e-3), ("temp3_input", "temp_mem_c", 1e-3),
+                                 ("freq1_input", "freq1_mhz", 1e-6), ("freq2_input", "freq2_mhz", 1e-6)):
+            v = rd(os.path.join(hw, name))
+            if v is not None and key not in out:
+                try:
+                    out[key] = round(float(v) * scale, 2)
+                except Exception:
+                    pass
+    return out
+
+
+def series_summary(v):
+    """first 5 / last 5 / min / median / max of a per-iteration series (ms)"""
+    v = [float(a) for a in v]
+    r3 = lambda a: [round(b, 3) for b in a]
+    return {"n": len(v), "first5": r3(v[:5]), "last5": r3(v[-5:]), "min": round(min(v), 3), "median": round(float(np.median(v)), 3),
+            "max": round(max(v), 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +256,9 @@ def main():
                          "off: copy the committed numbers of profiles/traffic.json and label them STATIC")
     ap.add_argument("--prewarm-gb", type=float, default=float(os.environ.get("TV_BENCH_PREWARM_GB", "0")),
                     help="touch and release this many GB of device memory before the volume is allocated (placement experiment)")
+    ap.add_argument("--pitch", default=os.environ.get("TV_BENCH_PITCH", "default"),
+                    help="layout of the solver's private state: default (what solvers.ChambollePock picks), none (dense), auto, or "
+                         "<frame pad in bytes> (rows rounded up to 128 B, frames padded by that many bytes)")
     ap.add_argument("--phases", action="store_true", help="per-phase HIP-event times of the schedule in the JSON line (always on at N > 1)")
     args = ap.parse_args()
     # must be in the environment BEFORE the HIP runtime starts (the pool's driver only supports dmabuf IPC; RCCL's
@@ -266,8 +335,17 @@ def main():
         sys.stderr.flush()
         os._exit(3)                       # every rank that fails exits non-zero at once (no destructor tries the dead communicator)
     x0 = synth_slab(shape, slab.z0, slab.nz, device)
+    pkw = {}
+    if args.pitch == "none":
+        pkw["pitch"] = None
+    elif args.pitch == "auto":
+        pkw["pitch"] = "auto"
+    elif args.pitch != "default":
+        pkw["pitch"] = pytv.solvers.auto_pitch(shape[2], shape[3], torch.float32, frame_pad_bytes=int(args.pitch))
     cp = pytv.solvers.ChambollePock(x0, 25.0, scheme=args.scheme, reg_z_over_reg=wl["reg_z"], reg_time=wl["reg_time"],
-                                    slab=slab, overlap=not args.no_overlap, fused=False if args.two_kernel else None)
+                                    slab=slab, overlap=not args.no_overlap, fused=False if args.two_kernel else None, **pkw)
+    state_layout = {"row_pitch_elems": cp.geo.row_pitch, "frame_pitch_elems": cp.geo.frame_pitch,
+                    "frame_pad_bytes": 4 * (cp.geo.frame_pitch - shape[2] * cp.geo.row_pitch), "pitched": bool(cp.geo.pitched)}
     nd = cp.geo.nd
     K, W = args.steps, args.warmup
     hist = torch.zeros((K + W, cp.SLOTS), dtype=torch.float64, device=device)
@@ -283,20 +361,29 @@ def main():
     # per-kernel HIP events on the launch stream (torch's current stream == the stream the C-ABI enqueues on)
     cp.timing = []
     want_phases = args.phases or world > 1
-    if want_phases:
-        cp.phase_timing = []      # one event per phase boundary of the schedule (interior / wait / edges ...), see solvers.py
 
     barrier()
+    state_before = gpu_state(local_rank) if rank == 0 else None
     t0 = time.perf_counter()
     for it in range(K):
         cp.step(hist[W + it])
     barrier()
     elapsed = time.perf_counter() - t0
+    state_after = gpu_state(local_rank) if rank == 0 else None
     ev = cp.timing[:K]
     cp.timing = None
     phases = None
     if want_phases:
-        pm = pytv.solvers.ChambollePock.phase_means_ms(cp.phase_timing[:K])
+        # per-phase events in a SEPARATE short pass after the timed region: the headline ms_per_step carries the same (three events
+        # per step) instrumentation at every N, so the 1 -> N ratio is not biased by ~8 extra event records per step (round-3 advice)
+        cp.phase_timing = []      # one event per phase boundary of the schedule (interior / wait / edges ...), see solvers.py
+        scratch = torch.zeros((cp.SLOTS,), dtype=torch.float64, device=device)
+        n_ph = max(2, min(K, 6))
+        n_ph += n_ph & 1                                  # even: the x ping-pong ends where the timed loop left it
+        for it in range(n_ph):
+            cp.step(scratch)
+        barrier()
+        pm = pytv.solvers.ChambollePock.phase_means_ms(cp.phase_timing[:n_ph])
         cp.phase_timing = None
         names = list(pm)
         pt = torch.tensor([pm[k] for k in names], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -307,7 +394,9 @@ def main():
         phases = {"unit": "ms per step", "max_over_ranks": {k: float(v) for k, v in zip(names, pmax.tolist())},
                   "mean_over_ranks": {k: float(v) / world for k, v in zip(names, psum.tolist())},
                   "rank0": pm,
-                  "note": "HIP events on the launch stream at every phase boundary of the schedule (pytv/solvers.py _step_fused / step); "
+                  "steps": n_ph,
+                  "note": "collected in a separate pass of `steps` iterations AFTER the timed region (the timed loop carries no phase events); "
+                          "HIP events on the launch stream at every phase boundary of the schedule (pytv/solvers.py _step_fused / step); "
                           "*_halo_wait_exposed = time the launch stream sat in wait(handle) with nothing left to overlap (0 when the "
                           "transfer finished behind the interior work); the per-rank sums need not equal ms_per_step (max over ranks of the whole run)"}
 
@@ -340,6 +429,7 @@ def main():
                                "two_kernel_(6+3Nd)_words": bytes_iter_fused * it_s / 1e9 / world,
                                "one_sweep_(5+2Nd)_words": 4.0 * (5 + 2 * nd) * V * it_s / 1e9 / world, "per": "GPU"},
         "loss_first_last": [float(loss[W]), float(loss[-1])],
+        "state_layout": state_layout,
         "rccl_ranks": rccl_ranks, "comm": comm_name,        # rccl_ranks: size of the RCCL communicator the run used (0: no process group / test backend)
         "halo": {"backend": (dist.get_backend() if dist.is_initialized() else None), "planes_per_exchange": 1,
                  "bytes_per_plane": 4 * shape[1] * shape[2] * shape[3], "exchanges_per_iteration": 2 if world > 1 else 0},
@@ -352,8 +442,16 @@ def main():
     except Exception:
         pass
     torch.cuda.synchronize()
-    t_k1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
-    t_k2 = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    s_k1 = [e[0].elapsed_time(e[1]) for e in ev]
+    s_k2 = [e[1].elapsed_time(e[2]) for e in ev]
+    t_k1 = float(np.mean(s_k1)) * 1e-3
+    t_k2 = float(np.mean(s_k2)) * 1e-3
+    # per-iteration series of the timed region (HIP events on the launch stream) and the GPU's clocks / power right before and right
+    # after it: a drift (clock ramp, throttling) shows in first5 vs last5, a constant offset (placement) does not
+    out["series_ms"] = {"kernel1": series_summary(s_k1), "kernel2": series_summary(s_k2),
+                        "step": series_summary([a.elapsed_time(b) for (a, _, _), (b, _, _) in zip(ev[:-1], ev[1:])]) if len(ev) > 1 else None,
+                        "note": "kernel1 = sweep (or dual), kernel2 = fix-up (or primal), step = start of iteration k to start of k+1"}
+    out["gpu_state"] = {"before": state_before, "after": state_after, "source": "sysfs (pp_dpm_*, hwmon) read by rank 0 outside the timed region"}
     cp_fused = bool(cp.fused)
     if want_live:
         # AFTER the timed region, with this process's device memory handed back: the child passes need the HBM for the same

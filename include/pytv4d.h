@@ -46,11 +46,12 @@ extern "C" {
  * (pytv/tv_operators_GPU.py:134,253,362,471,583,719,828,938; pytv/tv_GPU.py:47,142,217,290). */
 /* Version of the binary interface declared in this header: bumped whenever tv_geom, the workspace layout or the
  * meaning of an entry point's arguments changes incompatibly (round 1: 1; round 2 added the three weight-volume
- * pointers and a second partial-sum array in the workspace: 2; round 3 added the two leading fields below: 3).
+ * pointers and a second partial-sum array in the workspace: 2; round 3 added the two leading fields below: 3;
+ * round 4 added row_pitch / frame_pitch at the end: 4).
  * Every entry point that takes a tv_geom rejects a struct whose struct_size / abi_version are not the library's own
  * with TV_E_ARG -- a host built against an older header fails loudly instead of having its trailing fields read as
  * garbage.  tv_geom_init() fills the two fields in. */
-#define TV_ABI_VERSION 3
+#define TV_ABI_VERSION 4
 
 typedef struct tv_geom {
     uint32_t struct_size;       /* sizeof(tv_geom) of the header the HOST was compiled against   */
@@ -82,6 +83,22 @@ typedef struct tv_geom {
                                  * tv_subgrad_fused_supported answer 0): the one-site-per-thread kernels do the work */
     const void* time_weight_prev;/* plane z0-1 / z0+nz of the same volume (m*ny*nx elements each) or NULL: only the          */
     const void* time_weight_next;/* ghost-plane norms of tv_subgrad on a slab read them                                       */
+    /* PITCHED arrays (round 4; 0 = dense, the reference's layout).  Every image-like array of a call (x, x0, p, G, norms, halo
+     * planes, a weight volume) and every gradient-like array (d, q, z, u: one image per channel) shares them:
+     *   row_pitch   : elements from one row of a frame to the next  (>= nx; a multiple of 16 bytes)
+     *   frame_pitch : elements from one frame to the next           (>= ny * row_pitch; a multiple of 16 bytes)
+     * element (z, [c,] t, y, x) lives at ((z [* nd + c]) * m + t) * frame_pitch + y * row_pitch + x.  mask_static / time_factor stay
+     * dense (ny * nx).  Why: (i) frames whose rows are not multiples of 128 bytes -- the reference's own shapes, pytv/tests.py:48
+     * N = 100, README.md:76-79 rand(20, 4, 100, 100) -- straddle cache lines and write sectors (1000-column frames ran at 0.55 x the
+     * rate of 1024-column ones in round 3); (ii) the one-sweep kernels read ~20 streams per block that are congruent modulo the
+     * frame size: a frame pitch that is not a power of two spreads them over the HBM channels.
+     * The PAD elements (columns >= nx of a row, the tail of a frame) belong to the library's caller but must hold ZEROS on entry
+     * wherever an array is read; every pitch-aware entry point leaves them zero (or untouched).  An entry point that does not
+     * take pitched arrays refuses them with TV_E_ARG (tv_last_error names it) -- nothing reads a pitched array as a dense one.
+     * nx need not be a multiple of the 16-byte lane (4 floats / 2 doubles) when row_pitch is: the vector kernels then own the pad
+     * columns of the last lane (this is how 1001-column frames leave the scalar kernels). */
+    int64_t row_pitch;
+    int64_t frame_pitch;
 } tv_geom;
 
 /* zero a tv_geom and stamp it with the header's struct size and interface version */

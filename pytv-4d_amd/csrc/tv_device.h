@@ -22,9 +22,11 @@ struct DG {
     int z_two, t_two;      // central scheme: axis has exactly two points -> forward stencil
     int vl;                // columns per 16-byte lane of the image dtype: 4 (fp32) / 2 (fp64)
     int ch_z, ch_t;        // first channel of the z / time axis
-    long long s_t;         // frame stride            ny*nx
-    long long s_z;         // image plane stride      m*ny*nx   (== gradient channel stride)
-    long long s_dz;        // gradient plane stride   nd*m*ny*nx
+    int rp;                // row pitch in elements (tv_geom::row_pitch; == nx for dense arrays): rows of every image-like array
+    int pitched;           // 1: row_pitch / frame_pitch given (pads exist and hold zeros); 0: the reference's dense layout
+    long long s_t;         // frame stride            tv_geom::frame_pitch, dense: ny*nx
+    long long s_z;         // image plane stride      m*s_t   (== gradient channel stride)
+    long long s_dz;        // gradient plane stride   nd*m*s_t
     const uint8_t* mask;   // ny*nx or nullptr
     const void* tf;        // ny*nx elements of the image dtype (per-pixel time-channel factor) or nullptr
     const void* wv;        // nz*m*ny*nx elements of the image dtype (per-VOXEL time-channel factor, local planes) or nullptr
@@ -201,11 +203,11 @@ template <typename T, int V>
 __device__ __forceinline__ Vec<T, V> vol_factor(const DG& g, int zl, int t, int y, int col0) {
     const T* pl = vol_plane<T>(g, zl, t);
     if (pl == nullptr) return vsplat<T, V>(T(1));
-    return vload<T, V>(pl + (long long)y * g.nx + col0);
+    return vload<T, V>(pl + (long long)y * g.rp + col0);
 }
 template <typename T> __device__ __forceinline__ T vol_factor1(const DG& g, int zl, int t, int y, int col) {
     const T* pl = vol_plane<T>(g, zl, t);
-    return pl != nullptr ? pl[(long long)y * g.nx + col] : T(1);
+    return pl != nullptr ? pl[(long long)y * g.rp + col] : T(1);
 }
 // the same for one pixel
 template <typename T> __device__ __forceinline__ T mask_factor1(const DG& g, T sf, int y, int col) {

@@ -86,7 +86,7 @@ __device__ __forceinline__ FusedCoord fused_coord(const DG& g, int zchunk, int c
     c.ok = (c.col0 < g.nx) && (c.y < g.ny);
     c.zs = ((int)blockIdx.y + chunk0) * zchunk;
     c.ze = (c.zs + zchunk < g.nz) ? c.zs + zchunk : g.nz;
-    c.inpl = (long long)c.y * g.nx + c.col0;
+    c.inpl = (long long)c.y * g.rp + c.col0;
     return c;
 }
 
@@ -105,7 +105,7 @@ template <int V = 4> __device__ __forceinline__ FusedCoord cp_coord(const DG& g,
     c.ok = (c.col0 < g.nx) && (c.y < g.ny);
     c.zs = ((int)blockIdx.y + chunk0) * zchunk;
     c.ze = (c.zs + zchunk < g.nz) ? c.zs + zchunk : g.nz;
-    c.inpl = (long long)c.y * g.nx + c.col0;
+    c.inpl = (long long)c.y * g.rp + c.col0;
     return c;
 }
 
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
     const int t0 = TWIN ? (int)blockIdx.z * CP_TWN : 0;       // first frame of this block's window
     const int Mg = TWIN ? g.m : M;                             // frames of the volume
     const unsigned voff = (unsigned)c.inpl * (unsigned)sizeof(T);          // byte offset of this lane's vector inside a frame (frames <= 2^30 px)
-    const unsigned row_bytes = (unsigned)g.nx * (unsigned)sizeof(T);
+    const unsigned row_bytes = (unsigned)g.rp * (unsigned)sizeof(T);
     // UP: some channel's adjoint takes y^(p-e) (forward differences; central: every channel); DN: ... y^(p+e).
     // CEN: central -- ONE channel per axis plays both roles, has no own-site term and is defined on interior
     // points only; its two-point z / t axes (z_fwd / t_fwd) behave like upwind axes.
@@ -745,13 +745,13 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const 
     const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
     const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
     const bool z_fwd = CEN && g.z_two;
-    const long long inpl = (long long)t * g.s_t + (long long)y * g.nx + col0;
+    const long long inpl = (long long)t * g.s_t + (long long)y * g.rp + col0;
     const T* qb = a.q + (long long)zl * g.s_dz + inpl;
     const VT zero = vsplat<T, V>(T(0));
     VT m = zero;
     // a missing term counts only where the neighbour's channel is defined (central: interior points of the axis)
-    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + FXLD<T, V>(qb + (long long)c_ru * g.s_z - g.nx);
-    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - FXLD<T, V>(qb + (long long)c_rd * g.s_z + g.nx);
+    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + FXLD<T, V>(qb + (long long)c_ru * g.s_z - g.rp);
+    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - FXLD<T, V>(qb + (long long)c_rd * g.s_z + g.rp);
     if (UP && (col0 & CM) == 0 && col0 >= (CEN ? 2 : 1)) m.v[0] += qb[(long long)c_cu * g.s_z - 1];
     if (DN && (col0 & CM) == CM - (V - 1) && col0 + V <= g.nx - (CEN ? 2 : 1)) m.v[V - 1] -= qb[(long long)c_cd * g.s_z + V];
     if (g.za) {
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256, 2) void k_subgrad_march(DG g, WT<float> w, con
         const bool want_up = (c.row == 0) && c.ok && (c.y > 0);
         const bool want_dn = (c.row == 3) && c.ok && (c.y + 1 < g.ny);
         F4 halo = zero;
-        if (want_up || want_dn) halo = vload<float, 4>(plane_c + off + (want_up ? -(long long)g.nx : (long long)g.nx));
+        if (want_up || want_dn) halo = vload<float, 4>(plane_c + off + (want_up ? -(long long)g.rp : (long long)g.rp));
         n.h_nr = c.ok && (c.y + 1 < g.ny);
         n.h_pr = c.ok && (c.y > 0);
         const F4 sdn = shfl_down16(cv), sup = shfl_up16(cv);

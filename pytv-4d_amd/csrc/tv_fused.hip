@@ -130,17 +130,17 @@ extern "C" {
 
 int tv_cp_fused_supported(const tv_geom* g) {
     DG d;
-    if (make_dg(g, d)) return 0;
+    if (make_dg(g, d, true)) return 0;
     if (d.nx % d.vl != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;          // fp32, and fp64 since round 3 (2 columns per lane)
     if (d.m > CP_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
-    if ((long long)d.ny * d.nx * (16 / d.vl) > (1ll << 32)) return 0;         // 32-bit per-lane byte offsets inside a frame
+    if (d.s_t * (16 / d.vl) > (1ll << 32)) return 0;                          // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_FUSED", 0)) return 0;
     return 1;
 }
 
 int tv_cp_zchunk(const tv_geom* g) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     return fused_zchunk(d);
 }
 
@@ -148,7 +148,7 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
                 void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int64_t chunk_begin,
                 int64_t chunk_count, double* tvout, double* fid, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!x_in || !q || !x0 || !p || !x_out || !tvout || !fid || !ws) return fail(TV_E_ARG, "NULL array");
     if (x_in == x_out) return fail(TV_E_ARG, "x_in and x_out must be different buffers (ping-pong)");
     if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
@@ -179,7 +179,7 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
 int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
                 double tau, int64_t z_begin, int64_t z_count, double* fid, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!q || !x_out || !x0 || !fid || !ws) return fail(TV_E_ARG, "NULL array");
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
     if (!aligned16({q, q_prev, q_next, x_out, x0})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
@@ -207,7 +207,7 @@ int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const voi
                   double thresh, double rho, int32_t full_store, int64_t chunk_begin, int64_t chunk_count, double* tvout, double* rr, void* ws,
                   void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!x || !u || !t || !x0 || !r || !tvout || !rr || !ws) return fail(TV_E_ARG, "NULL array");
     if (x == r || x0 == r) return fail(TV_E_ARG, "r must not alias x or x0");
     if (u == t) return fail(TV_E_ARG, "u and t must be different arrays");
@@ -239,7 +239,7 @@ int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const voi
 int tv_admm_fixup(const tv_geom* g, const void* t, const void* t_prev, const void* t_next, void* r, double rho, int64_t z_begin,
                   int64_t z_count, double* rr, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!t || !r || !rr || !ws) return fail(TV_E_ARG, "NULL array");
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
     if (!aligned16({t, t_prev, t_next, r})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
@@ -266,7 +266,7 @@ int tv_admm_fixup(const tv_geom* g, const void* t, const void* t_prev, const voi
 int tv_cpop_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* atp, void* x_out,
                   double sigma_D, double lambda, double tau, int64_t chunk_begin, int64_t chunk_count, double* tvout, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!x_in || !q || !atp || !x_out || !tvout || !ws) return fail(TV_E_ARG, "NULL array");
     if (x_in == x_out || atp == x_out) return fail(TV_E_ARG, "x_out must be a buffer of its own (ping-pong)");
     if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
@@ -296,7 +296,7 @@ int tv_cpop_fused(const tv_geom* g, const void* x_in, const void* x_prev, const 
 int tv_cpop_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, double tau, int64_t z_begin,
                   int64_t z_count, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (ws == nullptr) return fail(TV_E_ARG, "NULL array");
     // the fix-up's reduction (unused here) goes to the last word of the workspace: the pad behind the second partial array, which
     // this call does not use

@@ -34,7 +34,9 @@ inline int hipfail(hipError_t e, const char* where) {
         if (e__ != hipSuccess) return hipfail(e__, #call);    \
     } while (0)
 
-inline int make_dg(const tv_geom* g, DG& d) {
+// pitch_ok: does the calling entry point take pitched arrays (tv_geom::row_pitch / frame_pitch)?  One that does not refuses
+// them here -- nothing reads a pitched array as a dense one.
+inline int make_dg(const tv_geom* g, DG& d, bool pitch_ok = false) {
     if (g == nullptr) return fail(TV_E_ARG, "tv_geom is NULL");
     if (g->struct_size != (uint32_t)sizeof(tv_geom) || g->abi_version != TV_ABI_VERSION)
         return fail(TV_E_ARG, "tv_geom was built against another version of pytv4d.h (struct_size / abi_version mismatch): "
@@ -60,7 +62,21 @@ inline int make_dg(const tv_geom* g, DG& d) {
     d.vl = (g->dtype == TV_F32) ? 4 : 2;
     d.z_two = (g->scheme == TV_CENTRAL && g->nz_global == 2) ? 1 : 0;
     d.t_two = (g->scheme == TV_CENTRAL && g->m == 2) ? 1 : 0;
+    d.rp = (int)g->nx;
+    d.pitched = 0;
     d.s_t = (long long)g->ny * g->nx;
+    if (g->row_pitch != 0 || g->frame_pitch != 0) {
+        const long long lane = (g->dtype == TV_F32) ? 4 : 2;                // elements per 16 bytes
+        const long long rp = g->row_pitch != 0 ? g->row_pitch : g->nx;
+        const long long fp = g->frame_pitch != 0 ? g->frame_pitch : (long long)g->ny * rp;
+        if (rp < g->nx || rp > (1 << 24) || rp % lane != 0) return fail(TV_E_ARG, "row_pitch must be >= nx and a multiple of 16 bytes");
+        if (fp < (long long)g->ny * rp || fp % lane != 0 || fp > (1ll << 31))
+            return fail(TV_E_ARG, "frame_pitch must be >= ny * row_pitch, a multiple of 16 bytes and <= 2^31 elements");
+        if (!pitch_ok) return fail(TV_E_ARG, "this entry point does not take pitched arrays (tv_geom::row_pitch / frame_pitch must be 0)");
+        d.rp = (int)rp;
+        d.s_t = fp;
+        d.pitched = 1;
+    }
     d.s_z = d.s_t * g->m;
     d.s_dz = d.s_z * d.nd;
     d.mask = g->mask_static;

@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void k_reduce(const double* in, long long n, d
 extern "C" {
 
 const char* tv_last_error(void) { return g_err.c_str(); }
-int tv_version(void) { return 301; }
+int tv_version(void) { return 400; }
 int tv_abi_version(void) { return TV_ABI_VERSION; }
 
 int tv_set_option(const char* name, int value) {
@@ -818,13 +818,13 @@ int tv_get_option(const char* name, int dflt) { return (name != nullptr) ? env_i
 
 int tv_num_channels(const tv_geom* g) {
     DG d;
-    int rc = make_dg(g, d);
+    int rc = make_dg(g, d, true);
     return rc ? rc : d.nd;
 }
 
 size_t tv_workspace_bytes(const tv_geom* g) {
     DG d;
-    if (make_dg(g, d)) return 0;
+    if (make_dg(g, d, true)) return 0;
     return (size_t)(2 * (max_partials(d) + kStage + 16)) * sizeof(double);    // two independent partial arrays
 }
 

@@ -36,10 +36,11 @@ class TvGeom(ctypes.Structure):
         ("time_weight_vol", ctypes.c_void_p),
         ("time_weight_prev", ctypes.c_void_p),
         ("time_weight_next", ctypes.c_void_p),
+        ("row_pitch", ctypes.c_int64), ("frame_pitch", ctypes.c_int64),
     ]
 
 
-ABI_VERSION = 3      # TV_ABI_VERSION of include/pytv4d.h this binding was written against
+ABI_VERSION = 4      # TV_ABI_VERSION of include/pytv4d.h this binding was written against
 
 
 def new_geom():
@@ -175,14 +176,17 @@ class Geometry:
     """Python-side owner of a ``tv_geom``: keeps the device mask alive and caches the workspace."""
 
     def __init__(self, shape, scheme, dtype, device, reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
-                 factor_reg_static=0.0, nz_global=None, z0=0, weight_halo=None, weight_dev=None):
+                 factor_reg_static=0.0, nz_global=None, z0=0, weight_halo=None, weight_dev=None, row_pitch=0, frame_pitch=0):
         """mask_static: ``False``, a boolean mask broadcastable from (1, 1, Ny, Nx) (the reference's form, with
         ``factor_reg_static``), or a FLOAT array of weights on the time regularisation -- per pixel (broadcastable from
         (1, 1, Ny, Nx)) or per voxel (broadcastable to (Nz, M, Ny, Nx): the reference's to-do "weight matrix of size
         Nz x M x N x N", README.md:258).  The time channels are multiplied by sqrt(weight).
         weight_halo: (plane z0-1, plane z0+nz) of a per-voxel weight on a z-slab, each (M, Ny, Nx) or None (only the
         sub-gradient on a slab needs them).  weight_dev: internal -- (vol, prev, next) device tensors that already hold
-        sqrt(weight) for exactly these planes (sub-slab geometries of the solvers)."""
+        sqrt(weight) for exactly these planes (sub-slab geometries of the solvers).
+        row_pitch / frame_pitch (elements, 0 = dense): the arrays of this geometry are PITCHED (tv_geom::row_pitch / frame_pitch of
+        include/pytv4d.h; pads hold zeros) -- allocate them with ``new_image`` / ``new_grad``, which return (Nz, M, Ny, Nx) /
+        (Nz, Nd, M, Ny, Nx) VIEWS of zero-filled padded storage."""
         if scheme not in SCHEMES:
             raise ValueError("unknown TV scheme %r" % (scheme,))
         if len(shape) != 4:
@@ -237,11 +241,19 @@ class Geometry:
         g.factor_reg_static = float(factor_reg_static)
         g.mask_static = ptr(self.mask_dev)
         g.time_factor = ptr(self.factor_dev)
+        g.row_pitch, g.frame_pitch = int(row_pitch), int(frame_pitch)
+        self.row_pitch = int(row_pitch) if row_pitch else nx
+        self.frame_pitch = int(frame_pitch) if frame_pitch else ny * self.row_pitch
+        self.pitched = bool(row_pitch or frame_pitch)
         if weight_dev is not None:
             self.weight_vol = weight_dev
         if self.weight_vol is not None:
             if tuple(self.weight_vol[0].shape) != (nz, m, ny, nx):
                 raise ValueError("weight volume has shape %s, the image %s" % (tuple(self.weight_vol[0].shape), (nz, m, ny, nx)))
+            if self.pitched and not self.has_layout(self.weight_vol[0]):
+                w = self.new_image()
+                w.copy_(self.weight_vol[0])
+                self.weight_vol = (w,) + tuple(self._plane_like(h) for h in self.weight_vol[1:])
             g.time_weight_vol = ptr(self.weight_vol[0])
             g.time_weight_prev = ptr(self.weight_vol[1])
             g.time_weight_next = ptr(self.weight_vol[2])
@@ -267,6 +279,42 @@ class Geometry:
     @property
     def plane(self):
         return self.shape[1] * self.shape[2] * self.shape[3]
+
+    # ---- pitched storage (tv_geom::row_pitch / frame_pitch) --------------------------------------------------------------
+    def image_strides(self):
+        return (self.shape[1] * self.frame_pitch, self.frame_pitch, self.row_pitch, 1)
+
+    def new_image(self, planes=None, dtype=None):
+        """(planes, M, Ny, Nx) view of ZERO-filled storage with this geometry's pitches (dense geometry: a plain zeros tensor)."""
+        nz, m, ny, nx = self.shape
+        n = nz if planes is None else int(planes)
+        dt = self.dtype if dtype is None else dtype
+        if not self.pitched:
+            return torch.zeros((n, m, ny, nx), dtype=dt, device=self.device)
+        buf = torch.zeros(n * m * self.frame_pitch, dtype=dt, device=self.device)
+        return buf.as_strided((n, m, ny, nx), self.image_strides())
+
+    def new_grad(self, planes=None):
+        """(planes, Nd, M, Ny, Nx) view of zero-filled storage: one image per channel, channels between z and time."""
+        nz, m, ny, nx = self.shape
+        n = nz if planes is None else int(planes)
+        if not self.pitched:
+            return torch.zeros((n, self.nd, m, ny, nx), dtype=self.dtype, device=self.device)
+        fp, rp = self.frame_pitch, self.row_pitch
+        buf = torch.zeros(n * self.nd * m * fp, dtype=self.dtype, device=self.device)
+        return buf.as_strided((n, self.nd, m, ny, nx), (self.nd * m * fp, m * fp, fp, rp, 1))
+
+    def has_layout(self, t):
+        """does the image-like tensor t (…, M, Ny, Nx) already have this geometry's pitches?"""
+        want = self.image_strides()
+        return tuple(t.stride()[-3:]) == want[-3:] and (t.dim() < 4 or t.shape[0] == 1 or t.stride(0) == want[0])
+
+    def _plane_like(self, h):
+        if h is None or not self.pitched:
+            return h
+        w = self.new_image(1)[0]
+        w.copy_(h)
+        return w
 
     def workspace(self):
         if self._ws is None:

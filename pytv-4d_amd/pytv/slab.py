@@ -80,6 +80,14 @@ class NativeComm:
             self.ctx = ctypes.c_void_p()
 
 
+def _span(t):
+    """t itself if it is contiguous (or None), else the flat view of the storage span it covers"""
+    if t is None or t.is_contiguous():
+        return t
+    n = 1 + sum((int(sz) - 1) * int(st) for sz, st in zip(t.shape, t.stride()))
+    return t.as_strided((n,), (1,))
+
+
 def partition(nz_global, world):
     """Contiguous, balanced split of nz_global planes: list of (z0, nz) per rank."""
     base, rem = divmod(int(nz_global), int(world))
@@ -128,6 +136,9 @@ class Slab:
         (``wait()`` orders the current stream behind the transfer on RCCL; it blocks on gloo)."""
         if not self.sharded:
             return []
+        # planes of PITCHED arrays (tv_geom::row_pitch / frame_pitch) are strided views of one contiguous span of storage:
+        # the span travels (its pads are zeros on both sides)
+        send_prev, send_next, recv_prev, recv_next = (_span(t) for t in (send_prev, send_next, recv_prev, recv_next))
         if self.native is not None:
             return self.native.exchange(self.prev, self.next, send_prev if self.prev is not None else None,
                                         send_next if self.next is not None else None,

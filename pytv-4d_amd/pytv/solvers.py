@@ -24,7 +24,7 @@ import torch
 from . import _native as _nv
 from .slab import HaloPlan, Slab
 
-__all__ = ["ChambollePock", "ChambollePockOperator", "ADMM", "SubgradientDescent", "cp_step_size"]
+__all__ = ["ChambollePock", "ChambollePockOperator", "ADMM", "SubgradientDescent", "cp_step_size", "auto_pitch"]
 
 
 def cp_step_size(nz_global, m, reg_z_over_reg, reg_time, time_weight_max=1.0):
@@ -62,15 +62,37 @@ def chebyshev_coefficients(lmax, n):
     return out[:n]
 
 
+def auto_pitch(ny, nx, dtype, frame_pad_bytes=None):
+    """(row_pitch, frame_pitch) in elements for a solver's private state: rows rounded up to 128 bytes (a frame whose rows are
+    not whole cache lines has every row segment straddle lines and 64-byte write sectors: 1000-column frames ran at 0.55 x of
+    1024-column ones in round 3), frames padded so that the frame pitch is NOT a multiple of a large power of two -- the ~20
+    streams a one-sweep block reads are one frame pitch apart."""
+    es = 4 if dtype == torch.float32 else 8
+    rp = ((int(nx) * es + 127) // 128 * 128) // es
+    pad = AUTO_FRAME_PAD_BYTES if frame_pad_bytes is None else int(frame_pad_bytes)
+    return rp, int(ny) * rp + pad // es
+
+
+AUTO_FRAME_PAD_BYTES = 4352      # 4 KiB + 256 B (placeholder until the round-4 measurement picks it)
+
+
 class _SlabProblem:
     """Common state: local slab geometry (and sub-slab geometries for interior / edge launches)."""
 
-    def __init__(self, x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab):
+    def __init__(self, x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=None):
+        """pitch: None = the solver's state is dense like the caller's x0; (row_pitch, frame_pitch) in elements = every array of
+        the solver's state (x0 is COPIED into such storage) is pitched (include/pytv4d.h, tv_geom::row_pitch / frame_pitch);
+        "auto" = ``auto_pitch``.  Results (``result()``, ``x``) are then (Nz, M, Ny, Nx) VIEWS of padded storage."""
         if not isinstance(x0, torch.Tensor) or not x0.is_cuda:
             raise ValueError("x0 must be a device tensor (this rank's z-slab of the volume)")
         if x0.dim() != 4:
             raise ValueError("x0 must be 4-D (Nz_local, M, N, N)")
-        self.x0 = x0.contiguous()
+        if isinstance(pitch, str):
+            if pitch != "auto":
+                raise ValueError("pitch must be None, 'auto' or (row_pitch, frame_pitch)")
+            pitch = auto_pitch(x0.shape[2], x0.shape[3], x0.dtype)
+        self.pitch = (0, 0) if pitch is None else (int(pitch[0]), int(pitch[1]))
+        self.x0 = x0.contiguous() if self.pitch == (0, 0) else x0
         self.device = x0.device
         self.dtype = x0.dtype
         self.scheme = scheme
@@ -82,15 +104,20 @@ class _SlabProblem:
         self._geoms = {}
         self.lib = _nv.lib()
         nz, m, ny, nx = self.x0.shape
+        self._pkw = dict(row_pitch=self.pitch[0], frame_pitch=self.pitch[1])
         geo = _nv.Geometry((nz, m, ny, nx), scheme, self.dtype, self.device, nz_global=self.slab.nz_global, z0=self.slab.z0,
-                           **self.kw)
+                           **self.kw, **self._pkw)
+        if geo.pitched:
+            x0p = geo.new_image()
+            x0p.copy_(x0)
+            self.x0 = x0p
         self._wvol = None
         if geo.weight_vol is not None:
             # per-voxel weights on the time regularisation (mask_static = float array of this rank's slab shape): the
             # neighbours' boundary planes of the weight are fetched ONCE (the sub-gradient's ghost-plane norms read them)
             wv = geo.weight_vol[0]
-            gp = self.new_plane() if self.slab.prev is not None else None
-            gn = self.new_plane() if self.slab.next is not None else None
+            gp = geo.new_image(1) if self.slab.prev is not None else None
+            gn = geo.new_image(1) if self.slab.next is not None else None
             self.slab.wait(self.slab.exchange(send_prev=wv[0:1] if self.slab.prev is not None else None,
                                               send_next=wv[nz - 1:nz] if self.slab.next is not None else None,
                                               recv_prev=gp, recv_next=gn))
@@ -110,14 +137,14 @@ class _SlabProblem:
             nz, m, ny, nx = self.x0.shape
             if self._wvol is None:
                 self._geoms[key] = _nv.Geometry((b - a, m, ny, nx), self.scheme, self.dtype, self.device,
-                                                nz_global=self.slab.nz_global, z0=self.slab.z0 + a, **self.kw)
+                                                nz_global=self.slab.nz_global, z0=self.slab.z0 + a, **self.kw, **self._pkw)
             else:
                 wv, gp, gn = self._wvol
                 kw = dict(self.kw, mask_static=False, factor_reg_static=0)
                 dev = (wv[a:b], wv[a - 1] if a > 0 else (gp[0] if gp is not None else None),
                        wv[b] if b < nz else (gn[0] if gn is not None else None))
                 g = _nv.Geometry((b - a, m, ny, nx), self.scheme, self.dtype, self.device, nz_global=self.slab.nz_global,
-                                 z0=self.slab.z0 + a, weight_dev=dev, **kw)
+                                 z0=self.slab.z0 + a, weight_dev=dev, **kw, **self._pkw)
                 g.time_weight_max = self._twmax
                 self._geoms[key] = g
         return self._geoms[key]
@@ -127,8 +154,26 @@ class _SlabProblem:
         return _nv.current_stream(self.device)
 
     def new_plane(self, n=1):
+        """n image planes (halo buffers) with the state's pitches"""
         _, m, ny, nx = self.x0.shape
+        if self.pitch != (0, 0):
+            return self.geo.new_image(n)
         return torch.empty((n, m, ny, nx), dtype=self.dtype, device=self.device)
+
+    def new_image(self, zero=True):
+        """an array like x0 (this rank's planes) with the state's pitches; pads always zero"""
+        if self.pitch != (0, 0):
+            return self.geo.new_image()
+        return torch.zeros_like(self.x0) if zero else torch.empty_like(self.x0)
+
+    def new_grad(self):
+        """a zeroed gradient-like array (nz, Nd, M, Ny, Nx) with the state's pitches"""
+        return self.geo.new_grad()
+
+    def image_copy(self, src):
+        out = self.new_image(zero=False)
+        out.copy_(src)
+        return out
 
 
 # =================================================================================================
@@ -150,17 +195,18 @@ class ChambollePock(_SlabProblem):
         return h[:, cls.F:cls.SLOTS].sum(axis=1) + regularization * h[:, 0:cls.F].sum(axis=1)
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
-                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None):
+                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch=None):
         """fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
-        iteration) whenever the geometry supports it, False = always the dual + primal kernel pair."""
-        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
+        iteration) whenever the geometry supports it, False = always the dual + primal kernel pair.
+        pitch: see ``_SlabProblem`` (None: dense state; "auto" / (row_pitch, frame_pitch): padded state)."""
+        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
         self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time,
                                                                     self.geo.time_weight_max)
-        self.x = self.x0.clone()
-        self.p = torch.zeros_like(self.x0)
-        self.q = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)
+        self.x = self.image_copy(self.x0)
+        self.p = self.new_image()
+        self.q = self.new_grad()
         self.ws = self.geo.workspace()
         self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
         pl = self.plan
@@ -183,7 +229,7 @@ class ChambollePock(_SlabProblem):
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
             raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry (tv_cp_fused_supported: "
                              "fp32, Nx % 4 == 0, Nx >= 64, Ny * Nx <= 2^30; any number of frames)")
-        self.x_alt = torch.empty_like(self.x) if self.fused else None      # ping-pong partner of x
+        self.x_alt = self.new_image() if self.fused else None      # ping-pong partner of x
         self.overlap = bool(overlap) and sh and self.slab.nz >= 3 and not self.fused
         self.hist = None
         self.it = 0

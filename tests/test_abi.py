@@ -40,8 +40,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from pytv import _native as nv
-    # 2 x uint32 (struct_size, abi_version) + 6 x int64 + 2 x int32 + 3 x double + 5 pointers, no padding surprises
-    assert ctypes.sizeof(nv.TvGeom) == 8 + 6 * 8 + 2 * 4 + 3 * 8 + 8 + 8 + 3 * 8
+    # 2 x uint32 (struct_size, abi_version) + 6 x int64 + 2 x int32 + 3 x double + 5 pointers + 2 x int64 (row_pitch, frame_pitch:
+    # interface version 4), no padding surprises
+    assert ctypes.sizeof(nv.TvGeom) == 8 + 6 * 8 + 2 * 4 + 3 * 8 + 8 + 8 + 3 * 8 + 2 * 8
+    assert nv.TvGeom.row_pitch.offset == 128 and nv.TvGeom.frame_pitch.offset == 136 and nv.ABI_VERSION == 4
     assert nv.TvGeom.struct_size.offset == 0 and nv.TvGeom.abi_version.offset == 4 and nv.TvGeom.nz.offset == 8
     assert nv.TvGeom.scheme.offset == 56 and nv.TvGeom.reg_z_over_reg.offset == 64 and nv.TvGeom.mask_static.offset == 88 and nv.TvGeom.time_factor.offset == 96 and nv.TvGeom.time_weight_vol.offset == 104 and nv.TvGeom.time_weight_next.offset == 120
 

@@ -17,12 +17,13 @@ class TvGeom(ctypes.Structure):
                 ("nz_global", ctypes.c_int64), ("z0", ctypes.c_int64), ("scheme", ctypes.c_int32), ("dtype", ctypes.c_int32),
                 ("reg_z_over_reg", ctypes.c_double), ("reg_time", ctypes.c_double), ("factor_reg_static", ctypes.c_double),
                 ("mask_static", ctypes.c_void_p), ("time_factor", ctypes.c_void_p), ("time_weight_vol", ctypes.c_void_p),
-                ("time_weight_prev", ctypes.c_void_p), ("time_weight_next", ctypes.c_void_p)]
+                ("time_weight_prev", ctypes.c_void_p), ("time_weight_next", ctypes.c_void_p),
+                ("row_pitch", ctypes.c_int64), ("frame_pitch", ctypes.c_int64)]
 
 
 def geom(nz=4, m=3, ny=8, nx=16, scheme=3, dtype=0, nzg=None, z0=0, lz=1.0, mu=1.0, factor=0.0):
     g = TvGeom()
-    g.struct_size, g.abi_version = ctypes.sizeof(TvGeom), 3
+    g.struct_size, g.abi_version = ctypes.sizeof(TvGeom), 4
     g.nz, g.m, g.ny, g.nx, g.nz_global, g.z0 = nz, m, ny, nx, (nz if nzg is None else nzg), z0
     g.scheme, g.dtype, g.reg_z_over_reg, g.reg_time, g.factor_reg_static = scheme, dtype, lz, mu, factor
     return g
@@ -42,7 +43,7 @@ def main():
         assert rc < 0, "%s: expected an argument error, got %d" % (what, rc)
         assert msg and len(msg) > 3, what
 
-    assert lib.tv_version() >= 300 and lib.tv_abi_version() == 3
+    assert lib.tv_version() >= 300 and lib.tv_abi_version() == 4
     # ---- geometry rules: channel counts and workspace for many shapes / schemes / weights
     for nz, m, ny, nx, scheme, dtype, lz, mu in itertools.product((1, 2, 7, 300), (1, 2, 9, 16), (1, 5, 1024), (2, 64, 1028),
                                                                   range(4), (0, 1), (0.0, 1.5), (0.0, 0.3)):
