@@ -144,13 +144,23 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> shift_right(co
     return r;
 }
 
+// the last lane of a ragged PITCHED row (tv_geom::row_pitch; nx not a multiple of V) holds pad columns: results there are
+// forced to zero before they are stored, so that "pads hold zeros" survives every kernel (V == 1 / whole lanes: nothing to do)
+template <typename T, int V> __device__ __forceinline__ void zero_pad_cols(const DG& g, int col0, Vec<T, V>& r) {
+    if (V > 1 && col0 + V > g.nx) {
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+            if (col0 + i >= g.nx) r.v[i] = T(0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // thread -> voxel-vector mapping.  grid = (tiles_x * tiles_y, m, planes); block = (BX, BY)
 // ------------------------------------------------------------------------------------------
 struct Coord { int zl, t, y, col0; bool ok; };
 
 template <int V> __device__ __forceinline__ Coord thread_coord(const DG& g, int z_first) {
-    const int nxv = g.nx / V;
+    const int nxv = (g.nx + V - 1) / V;      // (a last lane with pad columns exists only on pitched rows: tv_geom::row_pitch)
     const int tiles_x = (nxv + (int)blockDim.x - 1) / (int)blockDim.x;
     const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
     Coord c;
@@ -179,15 +189,16 @@ __device__ __forceinline__ const T* zplane(const DG& g, const T* x, const T* xp,
 template <typename T, int V>
 __device__ __forceinline__ Vec<T, V> mask_factor(const DG& g, T sf, int y, int col0) {
     Vec<T, V> r = vsplat<T, V>(T(1));
+    // mask / factor maps are DENSE (ny * nx); the last lane of a ragged pitched row must not read past the row (V == 1: no test)
     if (g.mask != nullptr) {
         const uint8_t* mp = g.mask + (long long)y * g.nx + col0;
 #pragma unroll
-        for (int i = 0; i < V; ++i) r.v[i] = mp[i] ? sf : T(1);
+        for (int i = 0; i < V; ++i) r.v[i] = (V == 1 || col0 + i < g.nx) ? (mp[i] ? sf : T(1)) : T(1);
     }
     if (g.tf != nullptr) {
         const T* fp = static_cast<const T*>(g.tf) + (long long)y * g.nx + col0;
 #pragma unroll
-        for (int i = 0; i < V; ++i) r.v[i] *= fp[i];
+        for (int i = 0; i < V; ++i) r.v[i] *= (V == 1 || col0 + i < g.nx) ? fp[i] : T(1);
     }
     return r;
 }

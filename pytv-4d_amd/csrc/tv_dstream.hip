@@ -6,6 +6,7 @@
 namespace tvm {
 
 bool D_stream_ok(const tv_geom* g, const DG& d, bool vec) {
+    if (d.pitched) return false;                // pitched arrays: not yet in this kernel
     if (!vec || d.nx < 64) return false;        // fp32 and (round 3) fp64; a weight volume is one more read stream (round 3)
     if ((long long)d.ny * d.nx * (g->dtype == TV_F32 ? 4 : 8) > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
     return true;

@@ -97,7 +97,7 @@ template <int V = 4> __device__ __forceinline__ FusedCoord cp_coord(const DG& g,
     c.lane = (int)threadIdx.x;
     c.row = c.lane >> CP_LSH;
     c.lx = c.lane & (CP_TL - 1);
-    const int nxv = g.nx / V;
+    const int nxv = (g.nx + V - 1) / V;
     const int tiles_x = (nxv + CP_NW * CP_TL - 1) / (CP_NW * CP_TL);
     const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
     c.col0 = (bx * CP_NW * CP_TL + (int)threadIdx.y * CP_TL + c.lx) * V;
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void k_cp_fixup(DG g, WT<T> w, FixupArgsT<T> a
     // the call covers local planes [zb, zb + zn): classes 0 and 2 have grid z = zn; class 1 has two grid-z
     // slots (first / last plane) per z-chunk intersecting the range, starting at chunk a.chunk0
     __shared__ double sm[16];
-    const int nxv = g.nx / V;
+    const int nxv = (g.nx + V - 1) / V;
     const int tiles_x = (nxv + 63) / 64;
     double acc = 0.0;
     if (CLS == 0) {

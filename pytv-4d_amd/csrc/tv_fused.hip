@@ -14,7 +14,7 @@ static bool fused_m_ok(int m) { return m >= 1; }
 static int fused_zchunk(const DG& d) {
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
-        const long long tiles = (long long)((d.nx / d.vl + CP_NW * CP_TL - 1) / (CP_NW * CP_TL)) * ((d.ny + CP_TR - 1) / CP_TR);
+        const long long tiles = (long long)(((d.nx + d.vl - 1) / d.vl + CP_NW * CP_TL - 1) / (CP_NW * CP_TL)) * ((d.ny + CP_TR - 1) / CP_TR);
         const long long want = (1024 + tiles - 1) / (tiles > 0 ? tiles : 1);
         zc = (int)(d.nz / (want > 0 ? want : 1));
         if (zc > 32) zc = 32;
@@ -69,7 +69,7 @@ static int sweep_plan(const tv_geom* g, const DG& d, const void* x_in, const voi
     LC& lc = sp.lc;
     lc = march_cfg(d, zc);
     {   // block tile of the sweep: CP_TR rows x CP_BC columns (tv_fused.h)
-        const long long tx = (d.nx / d.vl + CP_NW * CP_TL - 1) / (CP_NW * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
+        const long long tx = ((d.nx + d.vl - 1) / d.vl + CP_NW * CP_TL - 1) / (CP_NW * CP_TL), ty = (d.ny + CP_TR - 1) / CP_TR;
         lc.grid.x = (unsigned)(tx * ty);
         lc.block = dim3(64, CP_NW, 1);
         lc.nblocks = tx * ty * lc.grid.y;
@@ -106,7 +106,7 @@ static int fixup_plan(const tv_geom* g, const DG& d, const void* q, const void* 
     if (int rc = check_y_halos(g, d, (z_begin == 0) ? q_prev : q, (z_begin + z_count == d.nz) ? q_next : q)) return rc;
     const int zb = (int)z_begin, zn = (int)z_count;
     const int chunk_lo = zb / zc, chunk_hi = (zb + zn - 1) / zc;           // chunks intersecting the plane range
-    const long long tiles_x = (d.nx / d.vl + 63) / 64, tiles_y = (d.ny + 3) / 4;
+    const long long tiles_x = ((d.nx + d.vl - 1) / d.vl + 63) / 64, tiles_y = (d.ny + 3) / 4;
     const long long ngrp = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL) ? (d.ny + 2 * CP_TR - 1) / (2 * CP_TR)
                                                                                 : (d.ny + 4 * CP_TR - 1) / (4 * CP_TR);
     const bool xw = env_int("TV_FUSED_XW", 1) != 0;
@@ -131,7 +131,9 @@ extern "C" {
 int tv_cp_fused_supported(const tv_geom* g) {
     DG d;
     if (make_dg(g, d, true)) return 0;
-    if (d.nx % d.vl != 0 || d.nx < 64 || !fused_m_ok(d.m)) return 0;          // fp32, and fp64 since round 3 (2 columns per lane)
+    // fp32, and fp64 since round 3 (2 columns per lane); a dense array needs whole lanes, a pitched one has them by construction
+    // (the last lane of a ragged row holds pad columns: zeros in, zeros out -- round 4)
+    if ((!d.pitched && d.nx % d.vl != 0) || d.nx < 64 || !fused_m_ok(d.m)) return 0;
     if (d.m > CP_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
     if (d.s_t * (16 / d.vl) > (1ll << 32)) return 0;                          // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_FUSED", 0)) return 0;

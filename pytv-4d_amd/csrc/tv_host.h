@@ -97,7 +97,7 @@ template <typename T> inline WT<T> make_w(const tv_geom* g) {
 
 struct LC { dim3 grid, block; long long nblocks; };
 inline LC launch_cfg(const DG& d, int V, int planes) {
-    const int nxv = d.nx / V;
+    const int nxv = (d.nx + V - 1) / V;
     int bx = 1;
     while (bx < nxv && bx < 64) bx <<= 1;
     const int by = 256 / bx;
@@ -117,7 +117,7 @@ inline long long max_partials(const DG& d) {
     LC lc = launch_cfg(d, 1, d.nz + 2);
     // the one-sweep fix-up launches up to four classes whose block counts add up to ~3 x (256-column tiles) x (4-row
     // groups) x m x nz when the z-chunks are short and the frame is narrow: bound them explicitly
-    const long long tiles = (long long)((d.nx / (d.vl > 0 ? d.vl : 4) + 63) / 64 + 1) * ((d.ny + 3) / 4 + 1);
+    const long long tiles = (long long)(((d.nx + 3) / (d.vl > 0 ? d.vl : 4) + 63) / 64 + 1) * ((d.ny + 3) / 4 + 1);
     long long n = 4 * tiles * (d.m + 2) * (d.nz + 2) + 4096;
     if (lc.nblocks > n) n = lc.nblocks;
     return n > kFlatBlocks ? n : kFlatBlocks;
@@ -145,6 +145,9 @@ inline bool aligned16(std::initializer_list<const void*> ps) {
 // lanes of a 16-byte vector for this dtype: `vec` at the call sites means "Nx is a multiple of it and every
 // pointer is 16-byte aligned"
 inline int vec_lanes(const tv_geom* g) { return g->dtype == TV_F32 ? 4 : 2; }
+// may the 16-byte-lane instantiations run on this geometry?  Dense arrays: Nx must be a multiple of the lane; pitched arrays:
+// the row pitch is one by construction (make_dg), the last lane of a row then holds pad columns (zeros in, zeros out)
+inline bool rows_vectorisable(const tv_geom* g, const DG& d) { return d.pitched || d.nx % vec_lanes(g) == 0; }
 
 template <typename F> inline int dispatch(int scheme, int dtype, bool vec, F&& f) {
 #define TV_CASE(SC)                                                                  \
@@ -193,6 +196,7 @@ inline int env_int(const char* name, int dflt) {
 inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
     if (g->dtype != TV_F32 || !vec || d.nx < 128) return false;
     if (d.wv != nullptr) return false;                    // weight volume: one-site-per-thread kernels
+    if (d.pitched) return false;                          // pitched arrays (interface version 4): streaming / one-sweep / one-site kernels
     if (env_int("TV_NO_MARCH", 0)) return false;
     // small planes (z/t neighbours one plane away stay L2-resident) are served better by the
     // one-site-per-thread kernels: measured on 512x512xM=1 (BASELINE config 1)

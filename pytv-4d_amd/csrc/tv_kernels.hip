@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_DT(DG g, WT<T> w, Src src, Epi epi) {
     double acc = 0.0;
     if (c.ok) {
         const Vec<T, V> zero = vsplat<T, V>(T(0));
-        const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;   // offset inside a plane
+        const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;   // offset inside a plane
         const long long offd = (long long)c.zl * g.s_dz + inpl;                          // channel 0 of this voxel
         const int gz = g.z0 + c.zl;
         Vec<T, V> r = zero, rt = zero;
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void k_DT(DG g, WT<T> w, Src src, Epi epi) {
         auto rows = [&](auto mode, int ch) {
             constexpr int M = decltype(mode)::value;
             const long long o = offd + (long long)ch * g.s_z;
-            const Vec<T, V> lo = (c.y >= 1 && M != 1) ? src.ld(o - g.nx) : zero;
+            const Vec<T, V> lo = (c.y >= 1 && M != 1) ? src.ld(o - g.rp) : zero;
             const Vec<T, V> ce = (M != 2) ? src.ld(o) : zero;
-            const Vec<T, V> hi = (c.y + 1 < g.ny && M != 0) ? src.ld(o + g.nx) : zero;
+            const Vec<T, V> hi = (c.y + 1 < g.ny && M != 0) ? src.ld(o + g.rp) : zero;
             r = r + adj_axis<M, T, V>(c.y, g.ny, lo, ce, hi);
         };
         auto cols = [&](auto mode, int ch) {
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_DT(DG g, WT<T> w, Src src, Epi epi) {
         }
         if (S == HYBRID) r = Consts<T>::inv_sqrt2() * r;
         if (S == CENTRAL) r = T(0.5) * r;
+        zero_pad_cols<T, V>(g, c.col0, r);
         acc = epi((long long)c.zl * g.s_z + inpl, r);
     }
     if (Epi::REDUCES) {
@@ -166,7 +167,7 @@ template <typename T> struct XA {
     }
     __device__ __forceinline__ T at(int zl, int t, int y, int c) const {
         const T* p = zplane<T>(g, x, xp, xn, hp, zl);
-        return p ? p[(long long)t * g.s_t + (long long)y * g.nx + c] : T(0);
+        return p ? p[(long long)t * g.s_t + (long long)y * g.rp + c] : T(0);
     }
 };
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gather(XA<T> X, WT<T> w, const T* norms
             if (!X.in(qz, qt, qy, qc)) return T(0);
             const T d = dval<S, T>(X, w, axis, type, qz, qt, qy, qc);
             if (MODE == 0) {
-                const T n = norms_ext[(long long)(qz + 1) * g.s_z + (long long)qt * g.s_t + (long long)qy * g.nx + qc];
+                const T n = norms_ext[(long long)(qz + 1) * g.s_z + (long long)qt * g.s_t + (long long)qy * g.rp + qc];
                 return d * n;           // n = 1/|Dx| from pass 1 (0 where |Dx| == 0)
             }
             // D^T D: the adjoint scales the time sample of voxel q by q's own weight-volume factor
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void k_gather(XA<T> X, WT<T> w, const T* norms
         r += rt;
         if (S == HYBRID) r *= Consts<T>::inv_sqrt2();
         if (S == CENTRAL) r *= T(0.5);
-        const long long off = (long long)zl * g.s_z + (long long)t * g.s_t + (long long)y * g.nx + col;
+        const long long off = (long long)zl * g.s_z + (long long)t * g.s_t + (long long)y * g.rp + col;
         if (MODE == 0) {
             out[off] = r;
         } else {
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void k_subgrad_vec(DG g, WT<T> w, const T* x, 
     } else {
         r = subgrad_site<S, T, V>(g, w, xs, ns, mf2);
     }
-    vstore<T, V>(G + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, r);
+    vstore<T, V>(G + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0, r);
 }
 
 template <int S, typename T, int V>
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void k_normal_vec(DG g, WT<T> w, const T* x, c
                 r = r + ((w.wt * w.wt) * tt) * (mf * mf);
             }
         }
-        const long long off = (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+        const long long off = (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
         Vec<T, V> o;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void k_normal_central_vec(DG g, WT<T> w, const
     double acc = 0.0;
     if (c.ok) {
         const Vec<T, V> zero = vsplat<T, V>(T(0));
-        const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+        const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
         const T* pc = zplane<T>(g, x, xp, xn, 2, c.zl) + inpl;
         const Vec<T, V> xc = vload<T, V>(pc);
         Vec<T, V> r = zero;
@@ -367,8 +368,8 @@ __global__ __launch_bounds__(256) void k_normal_central_vec(DG g, WT<T> w, const
             return a;
         };
         // rows
-        r = r + axis2(c.y, g.ny, (c.y >= 2) ? vload<T, V>(pc - 2 * (long long)g.nx) : zero,
-                      (c.y + 2 < g.ny) ? vload<T, V>(pc + 2 * (long long)g.nx) : zero);
+        r = r + axis2(c.y, g.ny, (c.y >= 2) ? vload<T, V>(pc - 2 * (long long)g.rp) : zero,
+                      (c.y + 2 < g.ny) ? vload<T, V>(pc + 2 * (long long)g.rp) : zero);
         // columns (per element)
         {
             const Vec<T, V> lv = (c.col0 >= V) ? vload<T, V>(pc - V) : zero, rv = (c.col0 + 2 * V <= g.nx) ? vload<T, V>(pc + V) : zero;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
     const Coord c = thread_coord<V>(g, 0);
     if (!c.ok) return;
     const Vec<T, V> zero = vsplat<T, V>(T(0));
-    const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+    const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
     const T* pc = zplane<T>(g, x, xp, xn, 2, c.zl) + inpl;
     const T* nc = norms_ext + (long long)(c.zl + 1) * g.s_z + inpl;
     const Vec<T, V> xc = vload<T, V>(pc);
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
             for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] * n0.v[i];
         }
     };
-    const long long nx = g.nx;
+    const long long nx = g.rp;      // row pitch
     cen(c.y, g.ny, (c.y >= 2) ? vload<T, V>(pc - 2 * nx) : zero, (c.y + 2 < g.ny) ? vload<T, V>(pc + 2 * nx) : zero,
         (c.y >= 1) ? vload<T, V>(nc - nx) : zero, (c.y + 1 < g.ny) ? vload<T, V>(nc + nx) : zero, T(1), false, false);
     {   // columns, per element
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256) void k_l21(DG g, const T* d, T* norms, double*
     const Coord c = thread_coord<V>(g, 0);
     double acc = 0.0;
     if (c.ok) {
-        const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+        const long long inpl = (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
         const T* base = d + (long long)c.zl * g.s_dz + inpl;
         Vec<T, V> s = vsplat<T, V>(T(0));
         for (int ch = 0; ch < g.nd; ++ch) {
@@ -831,10 +832,10 @@ size_t tv_workspace_bytes(const tv_geom* g) {
 // ---------------------------------------------------------------------------------------------
 int tv_D(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* dout, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (x == nullptr || dout == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, dout, d.wv, d.wvp, d.wvn});
+    const bool vec = rows_vectorisable(g, d) && aligned16({x, x_prev, x_next, dout, d.wv, d.wvp, d.wvn});
     hipStream_t st = (hipStream_t)stream;
     // TV_D_KERNEL: 0 = one site per thread (k_D), 1 = plane-marching with an LDS tile (k_D_march), 2 = streaming
     // (k_D_stream: no tile, no barrier, x read once).  Default: streaming for planes of at least TV_MARCH_MIN_PLANE_KB
@@ -871,10 +872,10 @@ int tv_DT_axpy(const tv_geom* g, const void* a, const void* b, const void* ab_pr
 int tv_DT_axpy2(const tv_geom* g, const void* a, const void* b, const void* ab_prev, const void* ab_next,
                 const void* base, const void* base2, double beta, double alpha, void* out, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (a == nullptr || out == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_y_halos(g, d, ab_prev, ab_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({a, b, ab_prev, ab_next, base, base2, out, d.wv});
+    const bool vec = rows_vectorisable(g, d) && aligned16({a, b, ab_prev, ab_next, base, base2, out, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const bool plain_store = (base == nullptr && base2 == nullptr && alpha == 1.0);
     if (b == nullptr && march_ok(g, d, vec)) {
@@ -906,13 +907,13 @@ int tv_DT_axpy2(const tv_geom* g, const void* a, const void* b, const void* ab_p
 
 int tv_l21(const tv_geom* g, const void* dimg, int32_t nd, void* norms, double* result, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (dimg == nullptr || result == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (nd < 1) return fail(TV_E_CHANNELS, "nd must be >= 1");
     // the l2,1 norm does not care which scheme produced the channels: honour the caller's nd
     d.nd = nd;
     d.s_dz = d.s_z * nd;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({dimg, norms});
+    const bool vec = rows_vectorisable(g, d) && aligned16({dimg, norms});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     return dispatch(0, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
@@ -927,7 +928,7 @@ int tv_l21(const tv_geom* g, const void* dimg, int32_t nd, void* norms, double* 
 int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, void* norms_ext,
                double* tvout, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (x == nullptr || G == nullptr || norms_ext == nullptr || tvout == nullptr || ws == nullptr)
         return fail(TV_E_ARG, "NULL array");
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
@@ -935,7 +936,7 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
         return fail(TV_E_HALO, "tv_subgrad on a slab needs two halo planes on each interior side");
     if (d.za && d.ta && d.wv != nullptr && ((e_lo && d.wvp == nullptr) || (e_hi && d.wvn == nullptr)))
         return fail(TV_E_HALO, "tv_subgrad on a slab with a weight volume needs time_weight_prev / time_weight_next");
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, norms_ext, d.wv, d.wvp, d.wvn});
+    const bool vec = rows_vectorisable(g, d) && aligned16({x, x_prev, x_next, norms_ext, d.wv, d.wvp, d.wvn});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec && aligned16({G})) && !env_int("TV_NO_MARCH_SUBGRAD", 0)) {
@@ -1015,14 +1016,14 @@ int tv_subgrad(const tv_geom* g, const void* x, const void* x_prev, const void* 
 int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, void* out,
                  double* dot, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (x == nullptr || out == nullptr || dot == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
     if (d.za && ((e_lo && x_prev == nullptr) || (e_hi && x_next == nullptr)))
         return fail(TV_E_HALO, "tv_normal_op on a slab needs two halo planes on each interior side");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out, d.wv});
+    const bool vec = rows_vectorisable(g, d) && aligned16({x, x_prev, x_next, out, d.wv});
     // TV_NORMAL_KERNEL: 2 = streaming (k_normal_stream: default for fp32 planes >= TV_MARCH_MIN_PLANE_KB, radius-1 schemes,
     // any M), 1 = the marching LIGHT kernel of round 1 (M <= 8), 0 = one site per thread
     const int nkern = env_int("TV_NORMAL_KERNEL", 2);
@@ -1063,11 +1064,11 @@ int tv_normal_op(const tv_geom* g, const void* x, const void* x_prev, const void
 int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* q, double sigma_D,
                double lambda, double* tvout, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (x == nullptr || q == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, q, d.wv});
+    const bool vec = rows_vectorisable(g, d) && aligned16({x, x_prev, x_next, q, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
@@ -1089,11 +1090,11 @@ int tv_cp_dual(const tv_geom* g, const void* x, const void* x_prev, const void* 
 int tv_cp_primal(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x, const void* x0,
                  void* p, double tau, double sigma_A, double* fid, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (q == nullptr || x == nullptr || x0 == nullptr || p == nullptr || fid == nullptr || ws == nullptr)
         return fail(TV_E_ARG, "NULL array");
     if (int rc = check_y_halos(g, d, q_prev, q_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({q, q_prev, q_next, x, x0, p, d.wv});
+    const bool vec = rows_vectorisable(g, d) && aligned16({q, q_prev, q_next, x, x0, p, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
@@ -1125,10 +1126,10 @@ int tv_admm_tu(const tv_geom* g, const void* x, const void* x_prev, const void* 
 static int admm_zu_impl(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* z, void* u,
                         double thresh, double* tvout, void* ws, void* stream, int tform) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (x == nullptr || z == nullptr || u == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (int rc = check_x_halos(g, d, x_prev, x_next)) return rc;
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, z, u, d.wv});
+    const bool vec = rows_vectorisable(g, d) && aligned16({x, x_prev, x_next, z, u, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
     if (march_ok(g, d, vec)) {
@@ -1203,7 +1204,7 @@ int tv_cpop_residual(int32_t dtype, int64_t n, const void* ax, const void* b, vo
 
 int tv_dot(const tv_geom* g, const void* a, const void* b, double* result, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (a == nullptr || b == nullptr || result == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     hipStream_t st = (hipStream_t)stream;
     TV_FLAT_LAUNCH(k_dot, g->dtype, nvox(d), ({a, b}), (const T*)a, (const T*)b, (double*)ws);
@@ -1214,7 +1215,7 @@ int tv_dot(const tv_geom* g, const void* a, const void* b, double* result, void*
 int tv_cg_step1(const tv_geom* g, void* x, void* r, const void* dvec, const void* Ad, const double* rs, const double* dAd,
                 double* rs_new, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!x || !r || !dvec || !Ad || !rs || !dAd || !rs_new || !ws) return fail(TV_E_ARG, "NULL array");
     hipStream_t st = (hipStream_t)stream;
     TV_FLAT_LAUNCH(k_cg1, g->dtype, nvox(d), ({x, r, dvec, Ad}), (T*)x, (T*)r, (const T*)dvec, (const T*)Ad, rs, dAd, (double*)ws);
@@ -1224,7 +1225,7 @@ int tv_cg_step1(const tv_geom* g, void* x, void* r, const void* dvec, const void
 
 int tv_cg_step2(const tv_geom* g, void* dvec, const void* r, const double* rs_new, const double* rs, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!dvec || !r || !rs_new || !rs) return fail(TV_E_ARG, "NULL array");
     hipStream_t st = (hipStream_t)stream;
     TV_FLAT_LAUNCH(k_cg2, g->dtype, nvox(d), ({dvec, r}), (T*)dvec, (const T*)r, rs_new, rs);
@@ -1235,7 +1236,7 @@ int tv_cg_step2(const tv_geom* g, void* dvec, const void* r, const double* rs_ne
 int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, double step, double lambda, double* fid,
                     void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!x || !x0 || !G || !fid || !ws) return fail(TV_E_ARG, "NULL array");
     hipStream_t st = (hipStream_t)stream;
     TV_FLAT_LAUNCH(k_sgstep, g->dtype, nvox(d), ({x, x0, G}), (T*)x, (const T*)x0, (const T*)G, (T)step, (T)lambda, (double*)ws);
@@ -1248,7 +1249,7 @@ int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, do
 int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, const void* b, void* out,
                   void* out2, double* dots, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (x == nullptr || out == nullptr || dots == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (out2 != nullptr && b == nullptr) return fail(TV_E_ARG, "out2 is the copy of the residual: it needs b");
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
@@ -1256,7 +1257,7 @@ int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const voi
         return fail(TV_E_HALO, "tv_normal_op2 on a slab needs two halo planes on each interior side");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out, out2, b, d.wv});
+    const bool vec = rows_vectorisable(g, d) && aligned16({x, x_prev, x_next, out, out2, b, d.wv});
     if (env_int("TV_NORMAL_KERNEL", 2) == 2 && tvm::N_stream_ok(g, d, vec)) {
         long long nb;
         double* w0 = (double*)ws;
@@ -1282,7 +1283,7 @@ int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const voi
 int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, const void* b, const void* y,
                  double yscale, const void* add, const void* ref, double alpha, double beta, void* out, double* dots, void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (x == nullptr || b == nullptr || out == nullptr || dots == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (out == x || out == y || out == b || out == add || out == ref) return fail(TV_E_ARG, "out must not alias an input");
     if (y != nullptr && yscale != 0.0) return fail(TV_E_ARG, "yscale is the stand-in for a missing y (y = yscale * b)");
@@ -1291,7 +1292,7 @@ int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void
         return fail(TV_E_HALO, "tv_cheb_step on a slab needs two halo planes on each interior side");
     hipStream_t st = (hipStream_t)stream;
     const long long nmax = max_partials(d);
-    const bool vec = (d.nx % vec_lanes(g) == 0) && aligned16({x, x_prev, x_next, out, b, y, add, ref, d.wv});
+    const bool vec = rows_vectorisable(g, d) && aligned16({x, x_prev, x_next, out, b, y, add, ref, d.wv});
     double* w0 = (double*)ws;
     double* w1 = w0 + nmax + kStage + 16;
     if (env_int("TV_NORMAL_KERNEL", 2) == 2 && tvm::N_stream_ok(g, d, vec)) {
@@ -1314,7 +1315,7 @@ int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void
 int tv_axpby(const tv_geom* g, double a, const void* x, double b, const void* y, const void* ref, void* out, double* dist2, void* ws,
              void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (x == nullptr || out == nullptr) return fail(TV_E_ARG, "NULL array");
     if ((ref != nullptr) != (dist2 != nullptr) || (ref != nullptr && ws == nullptr)) return fail(TV_E_ARG, "ref, dist2 and ws go together");
     hipStream_t st = (hipStream_t)stream;
@@ -1328,7 +1329,7 @@ int tv_axpby(const tv_geom* g, double a, const void* x, double b, const void* y,
 int tv_cg_update(const tv_geom* g, void* x, void* r, void* dvec, void* s, const void* w, double* sc, const void* x0, double* fid,
                  void* ws, void* stream) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;
     if (!x || !r || !dvec || !s || !w || !sc || !ws) return fail(TV_E_ARG, "NULL array");
     if (x0 != nullptr && fid == nullptr) return fail(TV_E_ARG, "x0 without a place for the fidelity");
     hipStream_t st = (hipStream_t)stream;

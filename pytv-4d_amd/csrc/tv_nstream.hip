@@ -9,6 +9,7 @@
 namespace tvm {
 
 bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
+    if (d.pitched) return false;                // pitched arrays: not yet in this kernel
     if (!vec || d.nx < 64 || d.wv != nullptr) return false;
     if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL) return false;                          // fp64 (round 3): the radius-1 kernel only
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return false;   // two-point axes: forward stencil

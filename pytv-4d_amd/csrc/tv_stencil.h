@@ -28,7 +28,7 @@ template <typename T, int V> struct XN {
 template <typename T, int V, bool NEXT, bool PREV>
 __device__ __forceinline__ void load_xn(const DG& g, const T* plane_c, const T* plane_p, const T* plane_n,
                                         const Coord& c, XN<T, V>& o) {
-    const long long off = (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+    const long long off = (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
     const T* p = plane_c + off;
     o.c = vload<T, V>(p);
     o.col0 = c.col0;
@@ -37,7 +37,7 @@ __device__ __forceinline__ void load_xn(const DG& g, const T* plane_c, const T* 
     o.h_nr = o.h_pr = o.h_nz = o.h_pz = o.h_nt = o.h_pt = false;
     if (NEXT) {
         o.h_nr = (c.y + 1 < g.ny);
-        if (o.h_nr) o.nr = vload<T, V>(p + g.nx);
+        if (o.h_nr) o.nr = vload<T, V>(p + g.rp);
         const T tail = (c.col0 + V < g.nx) ? p[V] : T(0);
         o.nc = shift_left<T, V>(o.c, tail);
         if (g.za) {
@@ -51,7 +51,7 @@ __device__ __forceinline__ void load_xn(const DG& g, const T* plane_c, const T* 
     }
     if (PREV) {
         o.h_pr = (c.y > 0);
-        if (o.h_pr) o.pr = vload<T, V>(p - g.nx);
+        if (o.h_pr) o.pr = vload<T, V>(p - g.rp);
         const T head = (c.col0 > 0) ? p[-1] : T(0);
         o.pc = shift_right<T, V>(o.c, head);
         if (g.za) {
@@ -89,7 +89,7 @@ __device__ __forceinline__ void d_slots(const DG& g, const WT<T>& w, const XN<T,
     if (BW) {
         if (n.h_pr) b_r = n.c - n.pr;
 #pragma unroll
-        for (int i = 0; i < V; ++i) b_c.v[i] = (n.col0 + i > 0) ? n.c.v[i] - n.pc.v[i] : T(0);
+        for (int i = 0; i < V; ++i) b_c.v[i] = ((unsigned)(n.col0 + i - 1) < (unsigned)(g.nx - 1)) ? n.c.v[i] - n.pc.v[i] : T(0);   // 1 <= col <= nx - 1 (pad columns of a pitched row: 0)
         if (n.h_pz) b_z = w.wz * (n.c - n.pz);
         if (n.h_pt) b_t = (w.wt * (n.c - n.pt)) * mf;
     }
@@ -149,7 +149,7 @@ template <int S, typename T, int V> struct StoreD {
     T* d;
     double* partials;
     __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8]) const {
-        T* base = d + (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+        T* base = d + (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
         for_each_channel<S>(g, [&](auto slot, int ch) { vstore<T, V>(base + (long long)ch * g.s_z, o[decltype(slot)::value]); });
         return 0.0;
     }
@@ -177,7 +177,7 @@ template <int S, typename T, int V> struct NormEpi {
             acc += (double)r;
             n.v[i] = (s.v[i] >= tiny_sumsq<T>()) ? T(1) / r : T(0);
         }
-        vstore<T, V>(norms_ext + (long long)(c.zl + 1) * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, n);
+        vstore<T, V>(norms_ext + (long long)(c.zl + 1) * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0, n);
         return (c.zl >= 0 && c.zl < g.nz) ? acc : 0.0;
     }
 };
@@ -189,7 +189,7 @@ template <int S, typename T, int V> struct CpDual {
     T sigma, inv_lambda;
     double* partials;
     __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8]) const {
-        T* base = q + (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+        T* base = q + (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
         Vec<T, V> v[8];
         Vec<T, V> vs = vsplat<T, V>(T(0));
         for_each_channel<S>(g, [&](auto slot, int ch) {
@@ -223,7 +223,7 @@ template <int S, typename T, int V> struct AdmmZU {
     double* partials;
     int tform = 0;
     __device__ __forceinline__ double operator()(const DG& g, const Coord& c, const Vec<T, V> (&o)[8]) const {
-        const long long off = (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0;
+        const long long off = (long long)c.zl * g.s_dz + (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
         Vec<T, V> v[8];
         Vec<T, V> vs = vsplat<T, V>(T(0));
         for_each_channel<S>(g, [&](auto slot, int ch) {
@@ -276,7 +276,7 @@ template <int S, typename T, int V> struct NormalEpi {
             ov.v[i] = xc.v[i] + rho * (inv_s * r.v[i]);
             acc += (double)xc.v[i] * (double)ov.v[i];
         }
-        vstore<T, V>(out + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.nx + c.col0, ov);
+        vstore<T, V>(out + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0, ov);
         return acc;
     }
 };

@@ -278,7 +278,13 @@ class Geometry:
 
     @property
     def plane(self):
-        return self.shape[1] * self.shape[2] * self.shape[3]
+        """storage elements of one image plane (M frames; pads included when the geometry is pitched)"""
+        return self.shape[1] * self.frame_pitch
+
+    @property
+    def image_elems(self):
+        """storage elements of an image-like array of this geometry (pads included): what the flat vector helpers are given"""
+        return self.shape[0] * self.plane
 
     # ---- pitched storage (tv_geom::row_pitch / frame_pitch) --------------------------------------------------------------
     def image_strides(self):

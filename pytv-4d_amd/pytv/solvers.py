@@ -468,7 +468,8 @@ class ChambollePockOperator(_SlabProblem):
         x <- x - tau A^T p - tau D^T q                                   tv_cpop_fixup, round 3) or tv_cp_dual + tv_DT_axpy2
 
     ``A`` and ``AT`` are callables taking and returning DEVICE tensors (``A``: image (Nz, M, Ny, Nx) -> data of any
-    shape, ``AT``: data -> image); they stay the user's code, the TV part runs in the HIP kernels.  ``tau`` must
+    shape, ``AT``: data -> image); they stay the user's code, the TV part runs in the HIP kernels.  ``A`` is applied ONCE by the
+    constructor (the residual A x_init - b is carried from iteration to iteration); ``b`` must live on x_init's GPU.  ``tau`` must
     satisfy tau (sigma_A |A|^2 + sigma_D |D|^2) <= 1; the default assumes |A| <= 1.
 
     With a ``slab`` (one process per GPU) ``x_init`` / ``b`` are this rank's z-slab of the image and its share of the data,
@@ -478,6 +479,11 @@ class ChambollePockOperator(_SlabProblem):
     def __init__(self, A, AT, b, x_init, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
                  mask_static=False, factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, fused=None):
         super().__init__(x_init, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
+        if not isinstance(b, torch.Tensor) or not b.is_cuda or b.device != self.device:
+            # b's raw pointer goes to HIP kernels (tv_cpop_residual, tv_cpop_p): a host tensor or one on another GPU would be a
+            # memory fault there, not the device-mismatch error torch used to raise (round-3 advice)
+            raise ValueError("b must be a device tensor on the same GPU as x_init (%s), got %s"
+                             % (self.device, b.device if isinstance(b, torch.Tensor) else type(b).__name__))
         self.A, self.AT = A, AT
         # fused (round 3): the TV part as ONE sweep over q (tv_cpop_fused + tv_cpop_fixup: the one-sweep Chambolle-Pock kernel with
         # A^T p in the place of the fidelity dual) instead of tv_cp_dual + tv_DT_axpy2 -- 2 Nd + 4 words per voxel instead of 3 Nd + 4
@@ -589,22 +595,22 @@ class SubgradientDescent(_SlabProblem):
         return h[:, 3:6].sum(axis=1) + regularization * h[:, 0:3].sum(axis=1)
 
     def __init__(self, x0, regularization, step_size, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True):
-        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
+                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True, pitch=None):
+        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.step_size = float(regularization), float(step_size)
-        self.x = self.x0.clone()
+        self.x = self.image_copy(self.x0)
         nz, m, ny, nx = self.x0.shape
-        self.G = torch.empty_like(self.x0)
+        self.G = self.new_image()
         if one_pass is None:      # TV + G + step in one pass over x wherever the geometry allows (tv_subgrad_step_fused)
             one_pass = bool(self.lib.tv_subgrad_fused_supported(self.geo.ref))
             # the round-3 kernel folds the step into its store (it divides by step * reg); a vanishing product is the round-1
             # kernel's case, and that one needs 16-byte lanes and fp32
-            if self.step_size * self.reg < 1e-6 and (nx % 4 != 0 or self.dtype != torch.float32):
-                one_pass = False
+            if self.step_size * self.reg < 1e-6 and (nx % 4 != 0 or self.dtype != torch.float32 or self.geo.weight_vol is not None):
+                one_pass = False      # (the round-1 kernel takes no weight volume either: round-3 advice)
         self.one_pass = bool(one_pass)
         # one pass: TV, G and the descent step in a single kernel, x ping-ponged (G is never stored); else the
         # two-pass tv_subgrad + tv_subgrad_step
-        self.norms_ext = None if self.one_pass else torch.empty((nz + 2, m, ny, nx), dtype=self.dtype, device=self.device)
+        self.norms_ext = None if self.one_pass else self.geo.new_image(nz + 2)
         if self.one_pass:
             self.x_alt = self.G
             self.G = None
@@ -717,8 +723,9 @@ class ADMM(_SlabProblem):
     oracle.admm restates both."""
 
     def __init__(self, x0, regularization, rho, n_cg=10, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=False, x_solver="cg"):
-        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab)
+                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=True, x_solver="cg",
+                 pitch=None):
+        super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.rho, self.n_cg = float(regularization), float(rho), int(n_cg)
         self.single = bool(single_reduction)
         # x_solver="chebyshev" (round 3): n_cg steps of the Chebyshev iteration on (I + rho D^T D) e = b - A x instead of CG.  Its
@@ -735,21 +742,22 @@ class ADMM(_SlabProblem):
         self._cheb_coef = chebyshev_coefficients(1.0 + self.rho * L, self.n_cg) if self.cheb else None
         # one-sweep dual side (round 3): z / u update + the residual of the next x-solve in one pass over u
         # (tv_admm_fused + tv_admm_fixup: 2 Nd + 3 words per voxel instead of the 4 Nd + 6 of tv_admm_tu + tv_DT_axpy +
-        # tv_normal_op2).  keep_z=False stores only the samples of t' = (z - u) - D x the fix-up reads (2 Nd -> Nd + 0.3
-        # written words); the split variable z is then not recoverable and ``.z`` raises.
+        # tv_normal_op2).  keep_z=True (default since round 4: ``.z`` keeps working as it did before the one-sweep path existed) stores
+        # every sample of t' = (z - u) - D x; keep_z=False only the samples the fix-up reads (2 Nd -> Nd + 0.3 written words: the
+        # benchmarks' setting) -- the split variable z is then not recoverable and ``.z`` raises, naming this flag.
         can_fuse = self.single and self.n_cg > 0 and bool(self.lib.tv_cp_fused_supported(self.geo.ref))
         if fused and not can_fuse:
             raise ValueError("fused=True needs single_reduction, n_cg > 0 and a geometry tv_cp_fused_supported() accepts")
         self.fused = can_fuse if fused is None else bool(fused)
         self.keep_z = bool(keep_z)
         self._have_r = False
-        self.x = self.x0.clone()
-        self._zt = torch.zeros(self.geo.grad_shape, dtype=self.dtype, device=self.device)   # z, or t = z - u (single_reduction)
-        self.u = torch.zeros_like(self._zt)
-        self.b = torch.empty_like(self.x0)
-        self.r = torch.empty_like(self.x0)
-        self.d = torch.empty_like(self.x0)
-        self.Ad = torch.empty_like(self.x0)          # A d (textbook) / s = A d (single reduction)
+        self.x = self.image_copy(self.x0)
+        self._zt = self.new_grad()                   # z, or t = z - u (single_reduction)
+        self.u = self.new_grad()
+        self.b = self.new_image()
+        self.r = self.new_image()
+        self.d = self.new_image()
+        self.Ad = self.new_image()                   # A d (textbook) / s = A d (single reduction)
         self.ws = self.geo.workspace()
         self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
         pl, s_ = self.plan, self.slab
@@ -775,8 +783,9 @@ class ADMM(_SlabProblem):
         D x -- on a sharded slab that is a halo exchange, so every rank has to ask for z, not just one)."""
         if self.fused and self._have_r:
             if not self.keep_z:
-                raise RuntimeError("ADMM(keep_z=False) stores only the samples of z - u - D x its fix-up reads: z is not available")
-            d = torch.empty_like(self.u)
+                raise RuntimeError("ADMM(..., keep_z=False) stores only the samples of z - u - D x its fix-up reads: z is not available; "
+                                   "construct the solver with keep_z=True (the default)")
+            d = self.new_grad()
             hp, hn = self._halo2(self.x)
             _nv.check(self.lib.tv_D(self.geo.ref, _nv.ptr(self.x), _nv.ptr(hp[1:2] if hp is not None else None),
                                     _nv.ptr(hn[0:1] if hn is not None else None), _nv.ptr(d), self.stream))
@@ -921,7 +930,7 @@ class ADMM(_SlabProblem):
             rs.copy_(rs_new)
         self._zu(out[0:1])
         # fidelity 1/2 |x - x0|^2 = 1/2 <x-x0, x-x0>: r is free now
-        _nv.check(lib.tv_sub(code, self.x.numel(), _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(self.r), self.stream))
+        _nv.check(lib.tv_sub(code, g.image_elems, _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(self.r), self.stream))
         _nv.check(lib.tv_dot(g.ref, _nv.ptr(self.r), _nv.ptr(self.r), out[1:2].data_ptr(), _nv.ptr(self.ws), self.stream))
 
     def _zu_fused(self, out_tv, out_fid=None):
@@ -1016,6 +1025,10 @@ class ADMM(_SlabProblem):
         nrep = (n_outer - first) // K
         if nrep < 1:
             return 0
+        # the Chebyshev x-solve REBINDS x / d / Ad / b at Python level inside every step (the new image is written next to the old
+        # one and the roles are swapped): a capture that fails part-way must not leave them pointing at buffers whose kernels
+        # never ran (round-3 advice; ChambollePock._run_graphed_from does the same for x / x_alt)
+        saved = (self.x, self.d, self.Ad, self.b, self.r, self._have_r)
         try:
             buf = torch.zeros((K, 2), dtype=torch.float64, device=self.device)
             graph = torch.cuda.CUDAGraph()
@@ -1023,7 +1036,13 @@ class ADMM(_SlabProblem):
                 for k in range(K):
                     self.step(buf[k])
         except Exception:
-            return 0                             # nothing ran: stay eager
+            self.x, self.d, self.Ad, self.b, self.r, self._have_r = saved
+            return 0                             # nothing ran: undo the bookkeeping, stay eager
+        if (self.x is not saved[0]) or (self.d is not saved[1]) or (self.Ad is not saved[2]) or (self.b is not saved[3]):
+            # the block does not return the buffers to their roles (odd number of role swaps): replaying it would not be the
+            # same iteration twice -- cannot happen with GRAPH_BLOCK even, checked all the same
+            self.x, self.d, self.Ad, self.b, self.r, self._have_r = saved
+            return 0
         done = 0
         for r in range(nrep):
             graph.replay()

@@ -289,3 +289,43 @@ def test_admm_sweep_and_cheb_step_stay_inside_their_arrays(nvlib, scheme, dtype)
     torch.cuda.synchronize()
     assert all(bands_intact(b) for b in (xb, rb, yb, ab, x0b, ob))
     assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(dots).all())
+
+
+@pytest.mark.parametrize("fail_at", [1, 2, 3])
+def test_admm_chebyshev_failed_graph_capture_leaves_the_state_intact(monkeypatch, fail_at):
+    """round-3 advice: the Chebyshev x-solve rebinds x / d / Ad / b inside every step; a hipGraph capture that dies after an odd
+    number of steps must not leave them pointing at buffers whose kernels never ran.  The capture is made to fail after
+    `fail_at` steps; the run must then continue eagerly and give exactly the eager result."""
+    import torch
+    import pytv
+    rng = np.random.default_rng(7)
+    x0 = torch.as_tensor((rng.random((1, 1, 96, 128)) * 100).astype(np.float32)).cuda()
+    a = pytv.solvers.ADMM(x0, 4.0, 0.1, n_cg=3, scheme="hybrid", x_solver="chebyshev")
+    b = pytv.solvers.ADMM(x0, 4.0, 0.1, n_cg=3, scheme="hybrid", x_solver="chebyshev")
+    real_step = pytv.solvers.ADMM.step
+    state = {"capturing": False, "n": 0}
+    real_graph = torch.cuda.graph
+
+    class _FailingCapture(real_graph):
+        def __enter__(self):
+            state["capturing"], state["n"] = True, 0
+            return super().__enter__()
+
+        def __exit__(self, *exc):
+            state["capturing"] = False
+            return super().__exit__(*exc)
+
+    def step(self, out):
+        if state["capturing"] and self is a:
+            if state["n"] == fail_at:
+                raise RuntimeError("injected capture failure")
+            state["n"] += 1
+        return real_step(self, out)
+
+    monkeypatch.setattr(torch.cuda, "graph", _FailingCapture)
+    monkeypatch.setattr(pytv.solvers.ADMM, "step", step)
+    la = a.run(13, graph=True)
+    monkeypatch.setattr(torch.cuda, "graph", real_graph)
+    lb = b.run(13, graph=False)
+    assert np.array_equal(la, lb)
+    assert torch.equal(a.result(), b.result())

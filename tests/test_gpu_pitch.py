@@ -66,6 +66,63 @@ def test_one_sweep_cp_pitched_equals_dense_and_oracle(pytv, scheme, dtype, shape
     np.testing.assert_allclose(lp, wloss, rtol=1e-5 if dtype == np.float32 else 1e-11)
 
 
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,pitch", PITCHES[:3] + [((3, 2, 9, 14), (16, 9 * 16 + 8)), ((4, 3, 7, 13), (16, 7 * 16))])
+def test_kernel_pair_cp_pitched(pytv, scheme, dtype, shape, pitch):
+    """tv_cp_dual + tv_cp_primal (one-site kernels when the state is pitched) on padded state == oracle; ragged Nx (13, 14 columns)
+    runs through the scalar lanes of the same kernels"""
+    import torch
+    x0 = _x(shape, dtype, 1)
+    kw = dict(reg_z_over_reg=0.7, reg_time=1.3)
+    n = 5
+    pit = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 20.0, scheme=scheme, fused=False, pitch=pitch, **kw)
+    lp = pit.run(n)
+    wx, wloss = orc.chambolle_pock(x0.astype(np.float64), n, 20.0, scheme=scheme, **kw)
+    tol = dict(rtol=1e-5, atol=1e-3) if dtype == np.float32 else dict(rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(lp, wloss, rtol=tol["rtol"])
+    np.testing.assert_allclose(pit.result().cpu().numpy(), wx, **tol)
+    for t in (pit.x, pit.p, pit.q):
+        assert _pads_zero(t)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("variant", ["fused-cg", "fused-cheb", "trio", "textbook"])
+def test_admm_pitched(pytv, scheme, dtype, variant):
+    import torch
+    shape, pitch = (6, 3, 16, 64), (72, 16 * 72 + 20)
+    x0 = _x(shape, dtype, 2)
+    kw = dict(reg_z_over_reg=0.7, reg_time=1.3)
+    okw = dict(single_reduction=(variant != "textbook"), x_solver="chebyshev" if variant == "fused-cheb" else "cg")
+    skw = dict(okw, fused=variant.startswith("fused"))
+    ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 4.0, 0.1, n_cg=4, scheme=scheme, pitch=pitch, **skw, **kw)
+    assert ad.fused == variant.startswith("fused") and ad.geo.pitched
+    loss = ad.run(4)
+    wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 4, 4.0, 0.1, 4, scheme=scheme, return_state=True, **okw, **kw)
+    tol = dict(rtol=2e-5, atol=2e-3) if dtype == np.float32 else dict(rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(loss, wloss, rtol=1e-5 if dtype == np.float32 else 1e-10)
+    np.testing.assert_allclose(ad.result().cpu().numpy(), wx, **tol)
+    np.testing.assert_allclose(ad.z.cpu().numpy(), wz, **tol)
+    for t in (ad.x, ad.u, ad._zt, ad.r):
+        assert _pads_zero(t)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_subgradient_descent_pitched(pytv, scheme, dtype):
+    import torch
+    shape, pitch = (5, 3, 12, 30), (32, 12 * 32 + 8)
+    x0 = _x(shape, dtype, 3)
+    kw = dict(reg_z_over_reg=0.7, reg_time=1.3)
+    sg = pytv.solvers.SubgradientDescent(torch.as_tensor(x0).cuda(), 2.0, 0.05, scheme=scheme, pitch=pitch, **kw)
+    loss = sg.run(5)
+    wx, wloss = orc.subgradient_descent(x0.astype(np.float64), 5, 2.0, 0.05, scheme=scheme, **kw)
+    np.testing.assert_allclose(loss, wloss, rtol=2e-5 if dtype == np.float32 else 1e-10)
+    np.testing.assert_allclose(sg.result().cpu().numpy(), wx, rtol=1e-4 if dtype == np.float32 else 1e-9, atol=1e-3 if dtype == np.float32 else 1e-9)
+    assert _pads_zero(sg.x)
+
+
 def test_bad_pitches_are_argument_errors(pytv):
     import torch
     from pytv import _native as nv
