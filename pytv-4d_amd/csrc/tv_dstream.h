@@ -100,7 +100,7 @@ __global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || M >= 8) ? 2 : 3) void 
     constexpr bool NEXT = (S != DOWNWIND), PREV = (S != UPWIND);
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
-    const int nxv = g.nx / V;
+    const int nxv = (g.nx + V - 1) / V;         // (a last lane with pad columns: ragged PITCHED rows only, tv_geom::row_pitch)
     const int tiles_x = (nxv + ST_BCV - 1) / ST_BCV, tiles_y = (g.ny + ST_BR - 1) / ST_BR;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + DS_TWN - 1) / DS_TWN : 1;
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || M >= 8) ? 2 : 3) void 
     const int bx = tile % tiles_x, by = tile / tiles_x;
     const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * V, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
     const bool ok = (col0 < g.nx) && (y < g.ny);
-    const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * (long long)sizeof(T)) : 0u;      // byte offset inside a frame
-    const unsigned row_bytes = (unsigned)g.nx * (unsigned)sizeof(T);
+    const unsigned voff = ok ? (unsigned)(((long long)y * g.rp + col0) * (long long)sizeof(T)) : 0u;      // byte offset inside a frame
+    const unsigned row_bytes = (unsigned)g.rp * (unsigned)sizeof(T);
     const int zs = chunk * zchunk;
     const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
     const VT zero = vsplat<T, V>(T(0));

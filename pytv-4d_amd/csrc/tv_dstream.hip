@@ -6,15 +6,16 @@
 namespace tvm {
 
 bool D_stream_ok(const tv_geom* g, const DG& d, bool vec) {
-    if (d.pitched) return false;                // pitched arrays: not yet in this kernel
-    if (!vec || d.nx < 64) return false;        // fp32 and (round 3) fp64; a weight volume is one more read stream (round 3)
-    if ((long long)d.ny * d.nx * (g->dtype == TV_F32 ? 4 : 8) > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
+    // fp32 and (round 3) fp64; a weight volume is one more read stream (round 3); pitched arrays incl. ragged rows (round 4: the
+    // last lane of a row then holds pad columns, zeros in and -- through d_slots -- zeros out)
+    if (!vec || d.nx < 64) return false;
+    if (d.s_t * (g->dtype == TV_F32 ? 4 : 8) > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
     return true;
 }
 
 int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, void* dout) {
     const int V = (g->dtype == TV_F32) ? 4 : 2;
-    const long long tx = (d.nx / V + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
+    const long long tx = ((d.nx + V - 1) / V + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
     // planes per z-chunk: a chunk re-reads one plane (its trailing step), so chunks are long; >= ~4096 blocks in flight
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {

@@ -151,8 +151,8 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG
         const int bx = tile % tiles_x, by = tile / tiles_x;
         const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * V, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
         const bool ok = (col0 < g.nx) && (y < g.ny);
-        const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * (long long)sizeof(T)) : 0u;
-        const unsigned row_bytes = (unsigned)g.nx * (unsigned)sizeof(T);
+        const unsigned voff = ok ? (unsigned)(((long long)y * g.rp + col0) * (long long)sizeof(T)) : 0u;
+        const unsigned row_bytes = (unsigned)g.rp * (unsigned)sizeof(T);
         const int zs = chunk * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
         const VT zero = vsplat<T, V>(T(0));
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_ce
         const int bx = tile % tiles_x, by = tile / tiles_x;
         const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * 4, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
         const bool ok = (col0 < g.nx) && (y < g.ny);
-        const unsigned voff = ok ? (unsigned)(((long long)y * g.nx + col0) * 4) : 0u;
-        const unsigned row_bytes = (unsigned)g.nx * 4u;
+        const unsigned voff = ok ? (unsigned)(((long long)y * g.rp + col0) * 4) : 0u;
+        const unsigned row_bytes = (unsigned)g.rp * 4u;
         const int zs = chunk * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
         const F4 zero = vsplat<float, 4>(0.f);

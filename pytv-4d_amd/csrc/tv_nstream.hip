@@ -9,12 +9,13 @@
 namespace tvm {
 
 bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
-    if (d.pitched) return false;                // pitched arrays: not yet in this kernel
-    if (!vec || d.nx < 64 || d.wv != nullptr) return false;
+    // pitched arrays: rows of whole 16-byte lanes only (the column stencil inside a lane assumes every element has both neighbours;
+    // ragged rows take the one-site kernels)
+    if (!vec || d.nx < 64 || d.wv != nullptr || d.nx % ((g->dtype == TV_F32) ? 4 : 2) != 0) return false;
     if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL) return false;                          // fp64 (round 3): the radius-1 kernel only
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return false;   // two-point axes: forward stencil
     const long long eb = (g->dtype == TV_F32) ? 4 : 8;
-    if ((long long)d.ny * d.nx * eb > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
+    if (d.s_t * eb > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
     if (env_int("TV_NO_MARCH", 0) || env_int("TV_NO_MARCH_NORMAL", 0)) return false;
     // small planes: the z / t neighbours of the one-site kernel stay in L2 (same threshold as the other streaming kernels)
     return (long long)d.s_z * eb >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;

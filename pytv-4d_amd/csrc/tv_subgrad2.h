@@ -199,7 +199,7 @@ struct SgCol {
             const int y = yb + i;
             const bool in = in_x && (ROWS_IN || (y >= 0 && y < g.ny));
             const bool own = in && lane_ok && (TV_SG2_WIDE || (!(wv == 0 && i == 0) && !(wv == NW - 1 && i == R - 1)));
-            const unsigned off = (unsigned)(((long long)y * g.nx + cx) * (long long)sizeof(T));
+            const unsigned off = (unsigned)(((long long)y * g.rp + cx) * (long long)sizeof(T));
             roff[i] = in ? off : SG2_OOB;
             soff[i] = own ? off : SG2_OOB;
             cm.v[i] = own ? T(1) : T(0);
@@ -226,15 +226,15 @@ struct SgCol {
         // last wave; every other wave requests an out-of-range offset and gets 0
         unsigned hoff = SG2_OOB;
         if (HALO && in_x && !XLD) {
-            if (wv == 0 && yb > 0) hoff = (unsigned)(((long long)(yb - 1) * g.nx + cx) * (long long)sizeof(T));
-            if (wv == NW - 1 && yb + R < g.ny) hoff = (unsigned)(((long long)(yb + R) * g.nx + cx) * (long long)sizeof(T));
+            if (wv == 0 && yb > 0) hoff = (unsigned)(((long long)(yb - 1) * g.rp + cx) * (long long)sizeof(T));
+            if (wv == NW - 1 && yb + R < g.ny) hoff = (unsigned)(((long long)(yb + R) * g.rp + cx) * (long long)sizeof(T));
         }
         // XLD: EVERY wave reads the row above / below its strip (where the scheme needs it and the row exists: the block's first /
         // last wave only for the schemes whose ring norm looks outwards, exactly like the halo load above)
         unsigned uoff = SG2_OOB, doff = SG2_OOB;
         if (XLD && in_x) {
-            if ((DN || CEN) && yb > 0 && (wv > 0 || HALO)) uoff = (unsigned)(((long long)(yb - 1) * g.nx + cx) * (long long)sizeof(T));
-            if ((UP || CEN) && yb + R < g.ny && (wv < NW - 1 || HALO)) doff = (unsigned)(((long long)(yb + R) * g.nx + cx) * (long long)sizeof(T));
+            if ((DN || CEN) && yb > 0 && (wv > 0 || HALO)) uoff = (unsigned)(((long long)(yb - 1) * g.rp + cx) * (long long)sizeof(T));
+            if ((UP || CEN) && yb + R < g.ny && (wv < NW - 1 || HALO)) doff = (unsigned)(((long long)(yb + R) * g.rp + cx) * (long long)sizeof(T));
         }
         // LDS hand-off rows: own pair, the neighbour's row above / below (the zero row at the block's ends)
         const int r_own = 2 * wv, r_up = (wv > 0) ? 2 * (wv - 1) + 1 : ZR, r_dn = (wv < NW - 1) ? 2 * (wv + 1) : ZR;

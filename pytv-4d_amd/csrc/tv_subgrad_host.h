@@ -11,15 +11,15 @@ inline bool sg_m_ok(int m) { return m >= 1; }
 
 inline int sg_supported(const tv_geom* g) {
     DG d;
-    if (make_dg(g, d)) return 0;
+    if (make_dg(g, d, true)) return 0;
     if (!sg_m_ok(d.m)) return 0;
     // the round-3 kernel holds ONE column per lane (4- / 8-byte buffer loads): any Nx, any element-aligned pointer (late round 3;
     // before, ragged Nx took the two-pass path at 0.11 - 0.17 of the roofline).  The round-1 kernel (TV_SG_KERNEL=1, frames of
     // 2^31 bytes and more) is fp32 with 16-byte lanes.
     const bool k2 = env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * (g->dtype == TV_F32 ? 4 : 8) < (1ll << 31);
-    if (!k2 && (g->dtype != TV_F32 || d.nx % 4 != 0)) return 0;
+    if (!k2 && (g->dtype != TV_F32 || d.nx % 4 != 0 || d.pitched)) return 0;     // (the round-1 kernel knows no pitch)
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return 0;   // two-point axes: forward stencil
-    if ((long long)d.ny * d.nx > (1ll << 30)) return 0;          // 32-bit per-lane byte offsets inside a frame
+    if (d.s_t > (1ll << 30)) return 0;                           // 32-bit per-lane byte offsets inside a frame
     if (d.m > SG_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
     if (env_int("TV_NO_FUSED_SUBGRAD", 0)) return 0;
     return 1;
@@ -138,7 +138,7 @@ template <int MODE>
 inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout, double* fidout,
                      void* ws, void* stream, const SgHostArgs& ha, const char* who) {
     DG d;
-    if (int rc = make_dg(g, d)) return rc;
+    if (int rc = make_dg(g, d, true)) return rc;      // pitched arrays: the round-3 kernel (one column per lane: pads are never touched)
     if (x == nullptr || tvout == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!sg_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-pass sub-gradient");
     const bool vec16 = (d.nx % 4 == 0) && aligned16({x, x_prev, x_next, G, ha.x0, ha.x_out, ha.norms});      // what the round-1 kernel needs
@@ -154,6 +154,7 @@ inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const 
     }
     if (env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * 4 < (1ll << 31) && step_ok)
         return sg2_launch<float, MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
+    if (d.pitched) return fail(TV_E_ARG, "pitched arrays need the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad + tv_subgrad_step");
     if (d.wv != nullptr) return fail(TV_E_ARG, "a weight volume needs the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad");
     if (!vec16) return fail(TV_E_ARG, "ragged Nx / unaligned arrays need the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad + tv_subgrad_step");
     SgStepArgs sa{(const float*)ha.x0, (float*)ha.x_out, (float)ha.step, (float)ha.lambda, nullptr, (float*)ha.norms};

@@ -605,7 +605,8 @@ class SubgradientDescent(_SlabProblem):
             one_pass = bool(self.lib.tv_subgrad_fused_supported(self.geo.ref))
             # the round-3 kernel folds the step into its store (it divides by step * reg); a vanishing product is the round-1
             # kernel's case, and that one needs 16-byte lanes and fp32
-            if self.step_size * self.reg < 1e-6 and (nx % 4 != 0 or self.dtype != torch.float32 or self.geo.weight_vol is not None):
+            if self.step_size * self.reg < 1e-6 and (nx % 4 != 0 or self.dtype != torch.float32 or self.geo.weight_vol is not None
+                                                     or self.geo.pitched):
                 one_pass = False      # (the round-1 kernel takes no weight volume either: round-3 advice)
         self.one_pass = bool(one_pass)
         # one pass: TV, G and the descent step in a single kernel, x ping-ponged (G is never stored); else the

@@ -3,10 +3,10 @@
 ``tv_<scheme>(img, ...)`` returns the total variation of ``img`` and the reference's sub-gradient
 (pytv/tv_GPU.py:47,142,217,290).  The reference materialises D(img) (Nd x the image), then runs
 3..14 sliced ``G[...] += +-D/norm`` updates; here TV, G and -- when asked for -- the per-voxel norms come
-from a SINGLE pass over ``img`` (C-ABI ``tv_subgrad_fused`` / ``tv_subgrad_fused_norms``, include/pytv4d.h: fp32,
-Nx % 4 == 0); fp64 input, ragged rows, a per-voxel weight volume and central with a two-point axis take the
-two-pass form (``tv_subgrad``: 1/|D img| per voxel + TV partial sums, then a gather of G from ``img`` and those
-norms).  The gradient array is never stored either way.
+from a SINGLE pass over ``img`` (C-ABI ``tv_subgrad_fused`` / ``tv_subgrad_fused_norms``, include/pytv4d.h: fp32 and
+fp64, any Nx, any number of frames, with or without a per-voxel weight volume -- since round 3); only ``central`` with a
+two-point z or time axis takes the two-pass form (``tv_subgrad``: 1/|D img| per voxel + TV partial sums, then a gather of
+G from ``img`` and those norms).  The gradient array is never stored either way.
 
 Conventions kept: ``mask`` zeroes the caller's array in place; the TV
 value is always a 0-d numpy array; G (and grad_norms) are numpy unless ``return_pytorch_tensor``;
