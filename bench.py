@@ -15,6 +15,7 @@ Workloads (--workload):
   config1    (256, 1, 512, 512)   3-D hybrid        (BASELINE.json configs[1])
   config2    (128, 8, 512, 512)   4-D hybrid        (BASELINE.json configs[2])
   small      (16, 4, 256, 256)    quick functional run
+  rehearsal  (64, 8, 1024, 1024)  the north-star frame, 64 planes: 8 test ranks sharing one GPU (tests/test_gpu_rccl.py)
 """
 import argparse
 import json
@@ -34,6 +35,9 @@ WORKLOADS = {
     "config1": dict(shape=(256, 1, 512, 512), reg_z=1.0, reg_time=0.0),
     "config2": dict(shape=(128, 8, 512, 512), reg_z=1.0, reg_time=1.0),
     "small": dict(shape=(16, 4, 256, 256), reg_z=1.0, reg_time=1.0),
+    # the north-star frame (8 x 1024 x 1024) with 64 planes: what 8 ranks sharing ONE GPU can hold -- the N = 8 rehearsal of
+    # tests/test_gpu_rccl.py (no 8-GPU box is available to the build; the driver runs the real curve)
+    "rehearsal": dict(shape=(64, 8, 1024, 1024), reg_z=1.0, reg_time=1.0),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 

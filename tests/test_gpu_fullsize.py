@@ -237,7 +237,7 @@ def test_fp64_one_sweep_cp_with_q_beyond_4_gib(pytv, production, scheme):
 
 def test_weight_volume_sweep_with_q_beyond_4_gib(pytv, production):
     import torch
-    shape = (24, 8, 512, 1024)
+    shape = (36, 8, 512, 1024)                                     # q: 36 x 8 x 8 x 2 MiB = 4.5 GiB
     kw = dict(reg_z_over_reg=1.0, reg_time=1.0)
     gen = torch.Generator(device="cuda").manual_seed(45)
     x0 = _rand_planes(shape, 100.0, gen)

@@ -131,6 +131,33 @@ def test_bench_sharded_over_ranks_gives_the_single_rank_loss(ranks):
     assert "phases" not in one
 
 
+def test_n8_rehearsal_eight_ranks_on_one_gpu():
+    """Round-3 verdict item 8: no 8-GPU box is available to the build, so the N = 8 job is rehearsed with everything but RCCL --
+    `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` exactly as the driver launches it (the launcher starts
+    BEFORE anything touches the GPU), eight ranks sharing cuda:0 over the TEST transport (gloo, host-staged halos), on the
+    north-star frame (64 x 8 x 1024 x 1024: 8 planes per rank, 32 MiB halo planes).  The 8-rank loss must equal the 1-rank loss,
+    all seven phase fields of the interior-first schedule must be present, the line must say n_gpus = 8 / strong scaling.
+    This is NOT a scaling measurement (none exists)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TV_BENCH_BACKEND", "TV_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    common = ["--workload", "rehearsal", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--pmc", "off"]
+    env1 = dict(env, TV_ZCHUNK="2")
+    one = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env1)
+    env8 = dict(env, TV_BENCH_BACKEND="gloo", TV_BENCH_SHARE_GPU="1", TV_ZCHUNK="2")      # 2-plane chunks: 4 chunks per 8-plane slab
+    many = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29658", os.path.join(ROOT, "bench.py"), "--gpus", "8"] + common, env8)
+    assert many["n_gpus"] == 8 and many["steps"] == 4 and many["scaling"] == "strong" and many["rccl_ranks"] == 0
+    assert many["config"]["shape"] == [64, 8, 1024, 1024] and "z-slab x8" in many["config"]["parallelism"]
+    a, b = one["loss_first_last"], many["loss_first_last"]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1])
+    ph = many["phases"]
+    want = {"sweep_interior_a", "x_halo_wait_exposed", "sweep_edges", "sweep_interior_b", "fixup_interior", "q_halo_wait_exposed", "fixup_edges"}
+    assert set(ph["max_over_ranks"]) == want == set(ph["mean_over_ranks"]) == set(ph["rank0"])
+    assert many["halo"]["bytes_per_plane"] == 32 * 1024 * 1024 and many["halo"]["exchanges_per_iteration"] == 2
+    assert "series_ms" in many and "gpu_state" in many
+
+
 def test_bench_reports_a_failed_communicator_setup_and_exits_nonzero():
     """round-2 verdict item 3c: if the communicator cannot be set up, rank 0 prints a JSON line carrying the error and the
     process exits non-zero (fresh process; nothing is re-exec'ed).  Provoked with a backend name that does not exist."""
@@ -141,6 +168,23 @@ def test_bench_reports_a_failed_communicator_setup_and_exits_nonzero():
     assert p.returncode != 0
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["value"] is None and "communicator setup failed" in out["error"] and out["n_gpus"] == 1
+
+
+def test_bench_error_path_under_the_launcher_exits_nonzero():
+    """the same failure with several ranks under torch.distributed.run (how the driver starts N > 1): the launcher's exit code is
+    non-zero and rank 0's JSON line names the error"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(TV_BENCH_BACKEND="no_such_backend", TV_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29659", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--pmc", "off"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, p.stdout[-1500:]
+    out = json.loads(lines[-1])
+    assert out["value"] is None and "communicator setup failed" in out["error"] and out["n_gpus"] == 2
 
 
 def test_bench_measures_its_hbm_traffic_live():
