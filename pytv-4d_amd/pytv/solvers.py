@@ -62,35 +62,48 @@ def chebyshev_coefficients(lmax, n):
     return out[:n]
 
 
-def auto_pitch(ny, nx, dtype, frame_pad_bytes=None):
-    """(row_pitch, frame_pitch) in elements for a solver's private state: rows rounded up to 128 bytes (a frame whose rows are
-    not whole cache lines has every row segment straddle lines and 64-byte write sectors: 1000-column frames ran at 0.55 x of
-    1024-column ones in round 3), frames padded so that the frame pitch is NOT a multiple of a large power of two -- the ~20
-    streams a one-sweep block reads are one frame pitch apart."""
+def auto_pitch(ny, nx, dtype, frame_pad_bytes=0):
+    """(row_pitch, frame_pitch) in elements for a solver's private state, or None when dense storage is as good.
+    Rows are rounded up to 128 bytes when that costs at most 8 % (a frame whose rows are not whole cache lines has every row
+    segment straddle lines and 64-byte write sectors: 64 x 8 x 1000 x 1000 runs the one-sweep Chambolle-Pock iteration in 9.2 ms
+    padded against 18.1 ms dense, profiles/r4_pitch_bench.txt); otherwise -- short rows, where 128-byte rounding would add up to
+    a quarter more bytes and measured SLOWER (256 x 4 x 100 x 100: 0.33 against 0.27 ms) -- only ragged rows (Nx not a multiple
+    of the 16-byte lane) are rounded up to the lane, which takes them off the scalar-lane kernels.
+    frame_pad_bytes: extra bytes between frames (round 4 measured that de-aliasing the frame pitch does NOT move the one-sweep
+    kernel: tools/bwtest4, tools/alias_probe.py, profiles/r4_stream_aliasing.txt; kept as an argument for experiments)."""
     es = 4 if dtype == torch.float32 else 8
-    rp = ((int(nx) * es + 127) // 128 * 128) // es
-    pad = AUTO_FRAME_PAD_BYTES if frame_pad_bytes is None else int(frame_pad_bytes)
-    return rp, int(ny) * rp + pad // es
-
-
-AUTO_FRAME_PAD_BYTES = 4352      # 4 KiB + 256 B (placeholder until the round-4 measurement picks it)
+    lane = 16 // es
+    nx, ny = int(nx), int(ny)
+    rp128 = ((nx * es + 127) // 128 * 128) // es
+    if rp128 != nx and (rp128 - nx) <= 0.08 * nx:
+        rp = rp128
+    elif nx % lane != 0:
+        rp = (nx + lane - 1) // lane * lane
+    else:
+        rp = nx
+    pad = int(frame_pad_bytes) // es
+    if rp == nx and pad == 0:
+        return None
+    return rp, ny * rp + pad
 
 
 class _SlabProblem:
     """Common state: local slab geometry (and sub-slab geometries for interior / edge launches)."""
 
     def __init__(self, x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=None):
-        """pitch: None = the solver's state is dense like the caller's x0; (row_pitch, frame_pitch) in elements = every array of
-        the solver's state (x0 is COPIED into such storage) is pitched (include/pytv4d.h, tv_geom::row_pitch / frame_pitch);
-        "auto" = ``auto_pitch``.  Results (``result()``, ``x``) are then (Nz, M, Ny, Nx) VIEWS of padded storage."""
+        """pitch: "auto" (the solvers' default) = ``auto_pitch`` decides: dense for frames whose rows are whole cache lines (every
+        BASELINE configuration), padded rows otherwise; None / "dense" = the state is dense like the caller's x0;
+        (row_pitch, frame_pitch) in elements = every array of the solver's state (x0 is COPIED into such storage) is pitched
+        (include/pytv4d.h, tv_geom::row_pitch / frame_pitch).  With padded state ``result()`` / ``x`` are (Nz, M, Ny, Nx) VIEWS of
+        padded storage (``.contiguous()`` gives a dense copy)."""
         if not isinstance(x0, torch.Tensor) or not x0.is_cuda:
             raise ValueError("x0 must be a device tensor (this rank's z-slab of the volume)")
         if x0.dim() != 4:
             raise ValueError("x0 must be 4-D (Nz_local, M, N, N)")
         if isinstance(pitch, str):
-            if pitch != "auto":
-                raise ValueError("pitch must be None, 'auto' or (row_pitch, frame_pitch)")
-            pitch = auto_pitch(x0.shape[2], x0.shape[3], x0.dtype)
+            if pitch not in ("auto", "dense"):
+                raise ValueError("pitch must be 'auto', 'dense' (or None) or (row_pitch, frame_pitch)")
+            pitch = auto_pitch(x0.shape[2], x0.shape[3], x0.dtype) if pitch == "auto" else None
         self.pitch = (0, 0) if pitch is None else (int(pitch[0]), int(pitch[1]))
         self.x0 = x0.contiguous() if self.pitch == (0, 0) else x0
         self.device = x0.device
@@ -195,10 +208,10 @@ class ChambollePock(_SlabProblem):
         return h[:, cls.F:cls.SLOTS].sum(axis=1) + regularization * h[:, 0:cls.F].sum(axis=1)
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
-                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch=None):
+                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch="auto"):
         """fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
         iteration) whenever the geometry supports it, False = always the dual + primal kernel pair.
-        pitch: see ``_SlabProblem`` (None: dense state; "auto" / (row_pitch, frame_pitch): padded state)."""
+        pitch: see ``_SlabProblem`` ("auto", the default: padded rows where that pays; None / "dense"; (row_pitch, frame_pitch))."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
@@ -595,7 +608,7 @@ class SubgradientDescent(_SlabProblem):
         return h[:, 3:6].sum(axis=1) + regularization * h[:, 0:3].sum(axis=1)
 
     def __init__(self, x0, regularization, step_size, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True, pitch=None):
+                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True, pitch="auto"):
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.step_size = float(regularization), float(step_size)
         self.x = self.image_copy(self.x0)
@@ -724,8 +737,8 @@ class ADMM(_SlabProblem):
     oracle.admm restates both."""
 
     def __init__(self, x0, regularization, rho, n_cg=10, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=True, x_solver="cg",
-                 pitch=None):
+                 mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=True, x_solver=None,
+                 pitch="auto"):
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.rho, self.n_cg = float(regularization), float(rho), int(n_cg)
         self.single = bool(single_reduction)
@@ -734,8 +747,16 @@ class ADMM(_SlabProblem):
         # its stencil, r0 and e_{k-1} read, e_{k+1} written -- 4 words per voxel where a CG step moves 11) and a sharded solve
         # exchanges halo planes only: no all-reduce.  Same convergence as CG on this operator within the digits the loss is
         # reported to (the spectrum of D^T D fills its interval); oracle.admm(x_solver="chebyshev") restates it.
+        # DEFAULT since round 4 (x_solver=None): Chebyshev wherever it applies (single_reduction, n_cg > 0), CG otherwise.  Measured on
+        # the configs[4] per-GPU slab, 50 outer iterations, four schemes, rho in {0.02, 0.05, 0.2}, fp32 and fp64
+        # (tools/admm_xsolve_study.py, profiles/r4_admm_xsolve_study_*.txt): with the same number of steps the two reach the same
+        # objective to 6 - 7 digits at EVERY outer iteration, and a Chebyshev outer iteration takes 12.8 - 16.3 ms where CG takes
+        # 27 - 33 (fp64: 15 - 21 against 29 - 37): 2.1 - 2.4 x less wall time to any objective level, no all-reduce in the solve.
+        # ``n_cg`` keeps its meaning: steps of the x-solve per outer iteration.  x_solver="cg" is the round-1..3 behaviour.
+        if x_solver is None:
+            x_solver = "chebyshev" if (self.single and self.n_cg > 0) else "cg"
         if x_solver not in ("cg", "chebyshev"):
-            raise ValueError("x_solver must be 'cg' or 'chebyshev'")
+            raise ValueError("x_solver must be None, 'cg' or 'chebyshev'")
         self.cheb = (x_solver == "chebyshev")
         if self.cheb and not (self.single and self.n_cg > 0):
             raise ValueError("x_solver='chebyshev' needs single_reduction=True (the default) and n_cg > 0")

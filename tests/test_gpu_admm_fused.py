@@ -101,7 +101,7 @@ def test_admm_fused_matches_oracle(scheme, shape, lz, mu, reg, rho):
             assert np.abs(wz).max() > 1.0              # the shrinkage branch is exercised
         for keep_z in (True, False):
             ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), reg, rho, n_cg=5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
-                                   keep_z=keep_z)
+                                   keep_z=keep_z, x_solver="cg")
             assert ad.fused
             loss = ad.run(6)
             np.testing.assert_allclose(loss, wloss, rtol=rtol / 2, err_msg="%s %s" % (scheme, shape))
@@ -122,7 +122,7 @@ def test_admm_fused_equals_kernel_trio(scheme):
     import pytv
     rng = np.random.default_rng(8)
     x0 = torch.as_tensor((rng.random((10, 12, 40, 320)) * 100).astype(np.float32)).cuda()
-    kw = dict(n_cg=4, scheme=scheme, reg_time=0.8)
+    kw = dict(n_cg=4, scheme=scheme, reg_time=0.8, x_solver="cg")
     a = pytv.solvers.ADMM(x0, 4.0, 0.1, fused=True, **kw)             # threshold 40 against differences of +-100: z is active
     b = pytv.solvers.ADMM(x0, 4.0, 0.1, fused=False, **kw)
     c = pytv.solvers.ADMM(x0, 4.0, 0.1, fused=True, keep_z=True, **kw)

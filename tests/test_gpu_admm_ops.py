@@ -178,8 +178,8 @@ def test_admm_graph_replay_equals_eager(nvlib, scheme, single):
     import pytv
     rng = np.random.default_rng(6)
     x0 = torch.as_tensor((rng.random((1, 1, 96, 128)) * 100).astype(np.float32)).cuda()
-    a = pytv.solvers.ADMM(x0, 20.0, 0.1, n_cg=3, scheme=scheme, single_reduction=single)
-    b = pytv.solvers.ADMM(x0, 20.0, 0.1, n_cg=3, scheme=scheme, single_reduction=single)
+    a = pytv.solvers.ADMM(x0, 20.0, 0.1, n_cg=3, scheme=scheme, single_reduction=single, x_solver="cg")
+    b = pytv.solvers.ADMM(x0, 20.0, 0.1, n_cg=3, scheme=scheme, single_reduction=single, x_solver="cg")
     la, lb = a.run(19, graph=True), b.run(19, graph=False)
     assert np.array_equal(la, lb)
     assert torch.equal(a.result(), b.result())

@@ -278,7 +278,7 @@ def _admm_worker(rank, world, port, shape, scheme, kw, n_outer, n_cg, ret):
         x0_full = (60.0 * rng.random(shape)).astype(np.float32)
         slab = Slab(shape[0])
         x0 = torch.as_tensor(slab.local(x0_full).copy()).cuda()
-        ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=n_cg, scheme=scheme, slab=slab, keep_z=True, **kw)      # z is compared below
+        ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=n_cg, scheme=scheme, slab=slab, keep_z=True, x_solver="cg", **kw)      # z is compared below
         assert ad.fused                      # the one-sweep dual side (tv_admm_fused + tv_admm_fixup) with real halos
         loss = ad.run(n_outer)
         win = (slice(None), slice(None), slice(8, 40), slice(300, 620))

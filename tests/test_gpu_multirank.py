@@ -60,10 +60,11 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
             sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, slab=slab, **kw)
             out["sg_loss"] = sg.run(5)
             out["sg_x"] = sg.result().cpu().numpy()
-            ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, **kw)
+            ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, x_solver="cg", **kw)
             out["ad_loss"] = ad.run(3)
             out["ad_x"] = ad.result().cpu().numpy()
-            ac = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, slab=slab, x_solver="chebyshev", **kw)      # no all-reduce in the x-solve
+            ac = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, slab=slab, **kw)      # the default x-solve (Chebyshev): no all-reduce
+            assert ac.cheb
             out["ac_loss"] = ac.run(3)
             out["ac_x"] = ac.result().cpu().numpy()
         # data-fidelity operator slot on a slab: a diagonal operator (local to the slab), TV part with halos

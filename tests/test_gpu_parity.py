@@ -202,7 +202,7 @@ def test_marching_kernels_match_oracle_and_generic_path(pytv, scheme, zchunk, tv
             np.testing.assert_allclose(cp.result().cpu().numpy(), wx, rtol=1e-5, atol=1e-3)
         shape = MARCH_SHAPES[2]
         x0 = (50.0 * rng.random(shape)).astype(np.float32)
-        ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 5.0, 0.1, n_cg=4, scheme=scheme, reg_time=0.5)
+        ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 5.0, 0.1, n_cg=4, scheme=scheme, reg_time=0.5, x_solver="cg")
         loss = ad.run(4)
         wx, wloss = orc.admm(x0.astype(np.float64), 4, 5.0, 0.1, 4, scheme=scheme, reg_time=0.5, single_reduction=True)
         np.testing.assert_allclose(loss, wloss, rtol=2e-5)
@@ -483,7 +483,7 @@ def test_admm_matches_oracle(pytv, scheme, shape, lz, mu, reg, rho):
             wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 8, reg, rho, 6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
                                          single_reduction=single, return_state=True)
             ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), reg, rho, n_cg=6, scheme=scheme, reg_z_over_reg=lz, reg_time=mu,
-                                   single_reduction=single, keep_z=True)
+                                   single_reduction=single, keep_z=True, x_solver="cg")
             loss = ad.run(8)
             np.testing.assert_allclose(loss, wloss, rtol=rtol / 2, err_msg="%s %s single=%s" % (scheme, shape, single))
             np.testing.assert_allclose(ad.result().cpu().numpy(), wx, rtol=rtol, atol=atol)

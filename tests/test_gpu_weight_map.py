@@ -75,7 +75,7 @@ def test_general_weight_map_matches_oracle(pytv, scheme, dtype, shape):
         np.testing.assert_allclose(loss, ref_loss, rtol=1e-5 if dtype == np.float32 else 1e-10)
         np.testing.assert_allclose(cp.result().cpu().numpy(), ref_x, rtol=1e-4, atol=1e-3 if dtype == np.float32 else 1e-8)
     # ADMM (normal operator, z/u update, D^T axpy all see the map)
-    ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, **kw)
+    ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, x_solver="cg", **kw)
     la = ad.run(3)
     _, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, single_reduction=True, **kw)
     np.testing.assert_allclose(la, lref, rtol=1e-6 if dtype == np.float32 else 1e-9)      # measured 3e-8: profiles/r3_admm_tolerances.txt

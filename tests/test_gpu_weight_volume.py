@@ -101,7 +101,7 @@ def test_general_weight_volume_matches_oracle(pytv, scheme, dtype, shape):
         loss = cp.run(8)
         np.testing.assert_allclose(loss, ref_loss, rtol=1e-5 if dtype == np.float32 else 1e-10)
         np.testing.assert_allclose(cp.result().cpu().numpy(), ref_x, rtol=1e-4, atol=1e-3 if dtype == np.float32 else 1e-8)
-    ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, **kw)
+    ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=4, scheme=scheme, x_solver="cg", **kw)
     la = ad.run(3)
     ax, lref = orc.admm(x64 * 5, 3, 7.0, 0.1, 4, scheme=scheme, single_reduction=True, **kw)
     # fp32 bounds ~10 x the measured deviation (profiles/r3_admm_tolerances.txt)
@@ -252,7 +252,7 @@ def _worker(rank, world, port, shape, scheme, kw, ret):
         out["cp_loss"], out["cp_x"], out["tau"] = cp.run(6), cp.result().cpu().numpy(), cp.tau
         sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, slab=slab, **kwl)
         out["sg_loss"], out["sg_x"] = sg.run(4), sg.result().cpu().numpy()
-        ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, **kwl)
+        ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, x_solver="cg", **kwl)
         out["ad_loss"], out["ad_x"] = ad.run(2), ad.result().cpu().numpy()
         ret[rank] = out
     finally:

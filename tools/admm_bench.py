@@ -13,9 +13,9 @@ V = x0.numel()
 print("ADMM on %s (V = %.0f Mvox), %d CG steps per outer iteration, rho = 0.05, lambda = 25" % (shape, V / 1e6, n_cg))
 for scheme in ("upwind", "downwind", "central", "hybrid"):
     # one-sweep dual side (round 3, sparse / full storage of t'), the kernel trio it replaces, the textbook recurrence
-    for name, kw in (("one-sweep+chebyshev", dict(fused=True, x_solver="chebyshev", keep_z=False)), ("one-sweep", dict(fused=True, keep_z=False)),
-                     ("one-sweep keep_z", dict(fused=True, keep_z=True)),
-                     ("single-reduction", dict(fused=False)), ("textbook CG", dict(single_reduction=False))):
+    for name, kw in (("one-sweep+chebyshev", dict(fused=True, x_solver="chebyshev", keep_z=False)), ("one-sweep", dict(fused=True, keep_z=False, x_solver="cg")),
+                     ("one-sweep keep_z", dict(fused=True, keep_z=True, x_solver="cg")),
+                     ("single-reduction", dict(fused=False, x_solver="cg")), ("textbook CG", dict(single_reduction=False))):
         if os.environ.get("ONLY") and os.environ["ONLY"] != name:          # ONLY=<exact name>: one variant (profiling)
             continue
         ad = pytv.solvers.ADMM(x0, 25.0, 0.05, n_cg=n_cg, scheme=scheme, reg_time=1.0, **kw)

@@ -12,7 +12,7 @@ x0 = (60.0 * rng.random(shape)).astype(np.float32)
 for scheme in ("upwind", "downwind", "central", "hybrid"):
     wx, wloss, wz, wu = occ.admm(x0.astype(np.float64), n_outer, 7.0, 0.1, n_cg, scheme=scheme, return_state=True, single_reduction=True, **kw)
     for fused in (True, False):
-        ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 7.0, 0.1, n_cg=n_cg, scheme=scheme, keep_z=True, fused=fused, **kw)
+        ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 7.0, 0.1, n_cg=n_cg, scheme=scheme, keep_z=True, fused=fused, x_solver="cg", **kw)
         loss = ad.run(n_outer)
         x = ad.result().cpu().numpy().astype(np.float64); z = ad.z.cpu().numpy().astype(np.float64)
         print("config4-like %-8s fused=%d loss rel %.2e  x abs %.2e (max |x| %.1f)  z abs %.2e (max |z| %.1f)" % (
@@ -23,7 +23,7 @@ for shape, lz, mu in (((1, 1, 24, 64), 1.0, 0.0), ((5, 3, 16, 64), 1.5, 0.5), ((
     x0 = (rng.random(shape) * 100).astype(np.float32)
     for scheme in ("upwind", "downwind", "central", "hybrid"):
         wx, wloss, wz, wu = orc.admm(x0.astype(np.float64), 6, 25.0, 0.05, 5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu, single_reduction=True, return_state=True)
-        ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 25.0, 0.05, n_cg=5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu, keep_z=True)
+        ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 25.0, 0.05, n_cg=5, scheme=scheme, reg_z_over_reg=lz, reg_time=mu, keep_z=True, x_solver="cg")
         loss = ad.run(6)
         x = ad.result().cpu().numpy().astype(np.float64); z = ad.z.cpu().numpy().astype(np.float64); u = ad.u.cpu().numpy().astype(np.float64)
         print("small %s %-8s fused=%d loss rel %.2e  x abs %.2e  z abs %.2e  u abs %.2e (max |x| %.0f |z| %.0f)" % (

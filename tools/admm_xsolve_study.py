@@ -22,7 +22,7 @@ marks = [m for m in (5, 10, 20, 30, 50, 100) if m <= n_outer]
 for scheme in ("upwind", "downwind", "central", "hybrid"):
     for rho in (0.02, 0.05, 0.2):
         res = {}
-        for name, kw in (("cg5", dict(n_cg=5)), ("cheb5", dict(n_cg=5, x_solver="chebyshev")), ("cg3", dict(n_cg=3)), ("cheb3", dict(n_cg=3, x_solver="chebyshev")),
+        for name, kw in (("cg5", dict(n_cg=5, x_solver="cg")), ("cheb5", dict(n_cg=5, x_solver="chebyshev")), ("cg3", dict(n_cg=3, x_solver="cg")), ("cheb3", dict(n_cg=3, x_solver="chebyshev")),
                          ("cheb8", dict(n_cg=8, x_solver="chebyshev"))):
             ad = pytv.solvers.ADMM(x0, lam, rho, scheme=scheme, reg_time=1.0, keep_z=False, **kw)
             ad.run(1)                                 # first outer iteration (no warm residual yet) + warm-up

@@ -40,7 +40,7 @@ template <bool NT> __device__ __forceinline__ void st(char* p, f4 v) {
 // blocks per CU as the registers allow)
 template <int MAP, bool NT, int LDSKB>
 __global__ __launch_bounds__(512, 2) void k_sweep(Geo g, const char* __restrict__ x, const char* __restrict__ x0, char* __restrict__ p,
-                                                   char* __restrict__ q, char* __restrict__ xo) {
+                                                   char* q, char* __restrict__ xo, char* qo) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     __shared__ float lds_pad[LDSKB > 0 ? LDSKB * 256 : 1];
     if (g.nz < 0) lds_pad[tid] = 1.f;            // never true: keeps the allocation
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void k_sweep(Geo g, const char* __restrict_
 #pragma unroll
             for (int c = 0; c < ND; ++c) {
                 s += qv[c];
-                st<NT>(const_cast<char*>(qb) + (long long)c * M * g.fp, qv[c] * 1.0001f + xn);
+                st<NT>(qo + (qb - q) + (long long)c * M * g.fp, qv[c] * 1.0001f + xn);      // qo == q: in place; else ping-pong
             }
             st<NT>(p + po, pv + x0v);
             st<NT>(xo + po, s + pv);
@@ -105,7 +105,8 @@ int main(int argc, char** argv) {
     const long long fpmax = (long long)NY * (NXB + maxpad_r) + maxpad_f;
     const long long xbytes = (long long)nz * M * fpmax + maxstag, qbytes = (long long)nz * ND * M * fpmax + maxstag;
     char *pool;
-    const long long total = 4 * xbytes + qbytes + 5 * maxstag;
+    const bool pingpong = (argc > 3);                 // third argument: also run the q ping-pong variant (needs a second q array)
+    const long long total = 4 * xbytes + (pingpong ? 2 : 1) * qbytes + 6 * maxstag;
     CK(hipMalloc(&pool, total));
     CK(hipMemset(pool, 0, total));
     CK(hipEventCreate(&e0));
@@ -131,7 +132,8 @@ int main(int argc, char** argv) {
     };
     // variants: 0 = sweep mapping, nt, one block per CU (the real kernel's shape); 1 = the same with plain loads / stores;
     // 2 = wave-per-row mapping, nt, one block per CU; 3 = sweep mapping, nt, no LDS reservation (2 blocks per CU)
-    for (int var = 0; var < 4; ++var) {
+    // 4 (with a third argument) = variant 0 with q written to a SECOND array (ping-pong) instead of in place
+    for (int var = 0; var < (pingpong ? 5 : 4); ++var) {
             const int map = (var == 2) ? 1 : 0, nt = (var != 1);
             for (const Case& c : cases) {
                 Geo g;
@@ -146,14 +148,15 @@ int main(int argc, char** argv) {
                 char* x0 = base; base += xbytes + c.stag;
                 char* p = base; base += xbytes + c.stag;
                 char* xo = base; base += xbytes + c.stag;
-                char* q = base;
+                char* q = base; base += qbytes + c.stag;
+                char* qo = (var == 4) ? base : q;
                 const dim3 grid(NXB / 1024 * NY / 8, (nz + 31) / 32), blk(512);
                 std::vector<float> all;
                 double ms;
-                if (var == 0) ms = run([&] { hipLaunchKernelGGL((k_sweep<0, true, 128>), grid, blk, 0, 0, g, x, x0, p, q, xo); }, reps, &all);
-                else if (var == 1) ms = run([&] { hipLaunchKernelGGL((k_sweep<0, false, 128>), grid, blk, 0, 0, g, x, x0, p, q, xo); }, reps, &all);
-                else if (var == 2) ms = run([&] { hipLaunchKernelGGL((k_sweep<1, true, 128>), grid, blk, 0, 0, g, x, x0, p, q, xo); }, reps, &all);
-                else ms = run([&] { hipLaunchKernelGGL((k_sweep<0, true, 0>), grid, blk, 0, 0, g, x, x0, p, q, xo); }, reps, &all);
+                if (var == 0 || var == 4) ms = run([&] { hipLaunchKernelGGL((k_sweep<0, true, 128>), grid, blk, 0, 0, g, x, x0, p, q, xo, qo); }, reps, &all);
+                else if (var == 1) ms = run([&] { hipLaunchKernelGGL((k_sweep<0, false, 128>), grid, blk, 0, 0, g, x, x0, p, q, xo, qo); }, reps, &all);
+                else if (var == 2) ms = run([&] { hipLaunchKernelGGL((k_sweep<1, true, 128>), grid, blk, 0, 0, g, x, x0, p, q, xo, qo); }, reps, &all);
+                else ms = run([&] { hipLaunchKernelGGL((k_sweep<0, true, 0>), grid, blk, 0, 0, g, x, x0, p, q, xo, qo); }, reps, &all);
                 printf("var %d map %d %s  %-58s median %7.3f ms %6.0f GB/s  (", var, map, nt ? "nt   " : "plain", c.name, ms, bytes / ms * 1e-6);
                 (void)map;
                 for (float v : all) printf(" %.2f", v);

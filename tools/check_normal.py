@@ -46,9 +46,9 @@ for shape in [(7, 3, 9, 256), (5, 3, 8, 12)]:
     for scheme in ("upwind", "hybrid", "central"):
         x0 = (50.0 * rng.random(shape)).astype(np.float32)
         for single in (True, False):
-            ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 5.0, 0.1, n_cg=4, scheme=scheme, reg_time=0.5, single_reduction=single)
+            ad = pytv.solvers.ADMM(torch.as_tensor(x0).cuda(), 5.0, 0.1, n_cg=4, scheme=scheme, reg_time=0.5, single_reduction=single, x_solver="cg")
             loss = ad.run(4)
-            wx, wloss = orc.admm(x0.astype(np.float64), 4, 5.0, 0.1, 4, scheme=scheme, reg_time=0.5, single_reduction=single)
+            wx, wloss = orc.admm(x0.astype(np.float64), 4, 5.0, 0.1, 4, scheme=scheme, reg_time=0.5, single_reduction=single, x_solver="cg")
             rel = np.abs(loss - wloss).max() / wloss.max()
             ok = rel < 2e-5
             bad += (not ok)

@@ -64,7 +64,7 @@ for case in range(n_cases):
         check("cp loss fused=%s" % cp.fused, cp.run(4), rl, info, rtol=1e-5 * lt, atol=0)
         check("cp x fused=%s" % cp.fused, cp.result().cpu().numpy(), rx, info, rtol=1e-4 * lt, atol=1e-3 * lt)
     for single in (True, False):
-        ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, single_reduction=single, **kw)
+        ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, single_reduction=single, x_solver="cg", **kw)
         _, al = orc.admm(x64 * 5, 2, 7.0, 0.1, 3, scheme=scheme, single_reduction=single, **kw)
         check("admm single=%s" % single, ad.run(2), al, info, rtol=1e-4 * lt, atol=0)
     sg = pytv.solvers.SubgradientDescent(x0, 2.0, 0.02, scheme=scheme, **kw)
