@@ -201,6 +201,19 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
                 int64_t chunk_count, double* tv, double* fid, void* ws, void* stream);
 int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,
                 double tau, int64_t z_begin, int64_t z_count, double* fid, void* ws, void* stream);
+/* tv_cp_fused with flags (round 4).  TV_CP_FID_OF_INPUT: *fid = 1/2 |x_in - x0|^2 over ALL local sites (the sweep has x_in
+ * and x0 in registers) instead of 1/2 |x_out - x0|^2 over the sites that are already complete; tv_cp_fixup then needs no x0
+ * (pass x0 = NULL: it adds the missing terms only, *fid = 0) and moves one word less per site it visits.  A loop takes the
+ * fidelity of iterate k+1 from sweep k+1 (the README's loss line, README.md:157, pairs 1/2 |x_{k+1} - x0|^2 with the TV of x_k)
+ * and needs one plain reduction for the last iterate.
+ * q_in / q_out: the dual variable is read from q_in and written to q_out.  q_in == q_out is the in-place update of tv_cp_fused;
+ * two arrays (ping-pong, the caller swaps them after every iteration) cost a second q but run ~9 % faster: HBM serves "read one
+ * array, write another" better than a read-modify-write of the same lines (tools/bwtest4: 5.98 against 5.50 TB/s for this
+ * kernel's memory shape).  tv_cp_fixup takes q_out. */
+#define TV_CP_FID_OF_INPUT 1
+int tv_cp_sweep(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q_out, const void* x0,
+                void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int32_t flags, int64_t chunk_begin,
+                int64_t chunk_count, double* tv, double* fid, void* ws, void* stream);
 
 /* ---- fused ADMM updates (not in the reference; README.md:26,135 mention only) --------------- */
 /* v = D x + u; z = v * max(0, 1 - thresh/|v|_2); u = v - z; *tv (device fp64) = |D x|_{2,1}. */

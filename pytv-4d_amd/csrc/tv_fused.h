@@ -263,6 +263,10 @@ template <typename T> struct FusedArgsT {
     double* part_tv;
     double* part_fid;
     int full_store;       // ALG_ADMM: bit 0 = every sample of t' is stored (z stays recoverable; else only what the fix-up reads), bit 1 = the second partial is |x - x0|^2
+                          // ALG_CP: bit 1 = the second partial is 1/2 |x_in - x0|^2 over all sites (TV_CP_FID_OF_INPUT)
+    const T* q_in;        // where the dual variable is READ (round 4: q ping-pong, tv_cp_sweep; == q: in place, as before).  Reading one
+                          // array and writing another is ~9 % faster than the in-place read-modify-write for this kernel's memory shape
+                          // (tools/bwtest4 variant 4: 5.98 against 5.50 TB/s) -- the price is a second q array
 };
 using FusedArgs = FusedArgsT<float>;
 
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
 #pragma unroll
         for (int k = 0; k < 4; ++k) qpre[k] = zero;
         if (c.ok) {
-            const T* qb0 = a.q + (long long)c.zs * g.s_dz + (long long)t0 * g.s_t;
+            const T* qb0 = a.q_in + (long long)c.zs * g.s_dz + (long long)t0 * g.s_t;
             for_each_channel<S>(g, [&](auto slot, int ch) {
                 constexpr int k = decltype(slot)::value;
                 qpre[k & 3] = ldu_s_t<T, V>(qb0 + (long long)ch * g.s_z, voff);
@@ -425,7 +429,18 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
         }
         stu_s_t<T, V>(a.p + foff, voff, pn);
         stu_s_t<T, V>(a.x_out + foff, voff, xo);
-        if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += e2;
+        if (a.full_store & 2) {
+            // fidelity of the INPUT iterate over ALL sites (round 4, tv_cp_sweep flag TV_CP_FID_OF_INPUT): x_in is complete and x0 is
+            // in registers, so the fix-up no longer has to read x0 for the sites it completes -- the solver takes 1/2 |x_k - x0|^2
+            // from sweep k (README.md:157 pairs it with the TV of x_{k-1}, which sweep k - 1 delivered)
+            double f2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const double e = (double)xv.v[i] - (double)x0v.v[i];
+                f2 += 0.5 * e * e;
+            }
+            acc_fid += f2;
+        } else if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += e2;
     };
 
     // wait until the neighbouring waves have published `planes` planes (all waves of a block are resident and
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
                 const bool wrap = (t + 1 >= M) || (TWIN && t0 + t + 1 >= Mg);         // the window's last frame: on to the next plane
                 const int tn = wrap ? 0 : t + 1, zn = wrap ? z + 1 : z;
                 if (c.ok && zn < c.ze) {
-                    const T* qbn = a.q + (long long)zn * g.s_dz + (long long)(t0 + tn) * g.s_t;
+                    const T* qbn = a.q_in + (long long)zn * g.s_dz + (long long)(t0 + tn) * g.s_t;
                     for_each_channel<S>(g, [&](auto slot, int ch) {
                         constexpr int k = decltype(slot)::value;
                         qpre[k & 3] = ldu_s_t<T, V>(qbn + (long long)ch * g.s_z, voff);
@@ -556,11 +571,12 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = zero;
             T* qbase = a.q + (long long)z * g.s_dz + toff;                    // uniform
+            const T* qbase_in = a.q_in + (long long)z * g.s_dz + toff;        // uniform (== qbase unless q is ping-ponged)
             VT vs = zero;
             if (c.ok) {
                 for_each_channel<S>(g, [&](auto slot, int ch) {
                     constexpr int k = decltype(slot)::value;
-                    const VT qv = PFQ ? qcur[k & 3] : ldu_s_t<T, V>(qbase + (long long)ch * g.s_z, voff);
+                    const VT qv = PFQ ? qcur[k & 3] : ldu_s_t<T, V>(qbase_in + (long long)ch * g.s_z, voff);
                     v[k] = (ALG == ALG_ADMM) ? o[k] + qv : qv + a.sigma * o[k];
                     vs = vs + v[k] * v[k];
                 });
@@ -780,7 +796,7 @@ __device__ __forceinline__ double fixup_site(const DG& g, const WT<T>& w, const 
     const long long off = (long long)zl * g.s_z + inpl;
     const VT xv = FXLD<T, V>(a.x_out + off);
     VT x0v = zero;
-    if constexpr (ALG == ALG_CP) x0v = FXLD<T, V>(a.x0 + off);
+    if constexpr (ALG == ALG_CP) { if (a.x0 != nullptr) x0v = FXLD<T, V>(a.x0 + off); }      // x0 NULL: the caller takes the fidelity elsewhere
     VT xo;
     double acc = 0.0;
 #pragma unroll

@@ -146,9 +146,28 @@ int tv_cp_zchunk(const tv_geom* g) {
     return fused_zchunk(d);
 }
 
+static int cp_sweep_impl(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q, const void* x0,
+                         void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int32_t flags, int64_t chunk_begin,
+                         int64_t chunk_count, double* tvout, double* fid, void* ws, void* stream);
+
 int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, void* q, const void* x0,
                 void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int64_t chunk_begin,
                 int64_t chunk_count, double* tvout, double* fid, void* ws, void* stream) {
+    return cp_sweep_impl(g, x_in, x_prev, x_next, q, q, x0, p, x_out, sigma_D, lambda, tau, sigma_A, 0, chunk_begin, chunk_count, tvout, fid, ws, stream);
+}
+
+int tv_cp_sweep(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q_out, const void* x0,
+                void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int32_t flags, int64_t chunk_begin,
+                int64_t chunk_count, double* tvout, double* fid, void* ws, void* stream) {
+    if (flags & ~TV_CP_FID_OF_INPUT) return fail(TV_E_ARG, "tv_cp_sweep: unknown flag");
+    if (q_in == nullptr) return fail(TV_E_ARG, "NULL array");
+    if (!aligned16({q_in})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    return cp_sweep_impl(g, x_in, x_prev, x_next, q_in, q_out, x0, p, x_out, sigma_D, lambda, tau, sigma_A, flags, chunk_begin, chunk_count, tvout, fid, ws, stream);
+}
+
+static int cp_sweep_impl(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q, const void* x0,
+                         void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int32_t flags, int64_t chunk_begin,
+                         int64_t chunk_count, double* tvout, double* fid, void* ws, void* stream) {
     DG d;
     if (int rc = make_dg(g, d, true)) return rc;
     if (!x_in || !q || !x0 || !p || !x_out || !tvout || !fid || !ws) return fail(TV_E_ARG, "NULL array");
@@ -169,7 +188,8 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
     double* w1 = w0 + sp.nmax + kStage + 16;
     auto sweep = [&]<typename T>() -> int {
         FusedArgsT<T> a{(const T*)x_in, (const T*)x_prev, (const T*)x_next, (T*)q, (const T*)x0, (T*)p,
-                        (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)), w0, w1, 0};
+                        (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)), w0, w1,
+                        (flags & TV_CP_FID_OF_INPUT) ? 2 : 0, (const T*)(q_in ? q_in : q)};
         return tvm::fused_sweep<T, ALG_CP>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
     };
     const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();
@@ -182,7 +202,7 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
                 double tau, int64_t z_begin, int64_t z_count, double* fid, void* ws, void* stream) {
     DG d;
     if (int rc = make_dg(g, d, true)) return rc;
-    if (!q || !x_out || !x0 || !fid || !ws) return fail(TV_E_ARG, "NULL array");
+    if (!q || !x_out || !fid || !ws) return fail(TV_E_ARG, "NULL array");      // x0 may be NULL: no fidelity (*fid = 0)
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
     if (!aligned16({q, q_prev, q_next, x_out, x0})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -200,6 +220,10 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
         return tvm::fused_fixup<T, ALG_CP>(g, d, st, a, fp, w0);
     };
     if (int rc = (g->dtype == TV_F32) ? fix.template operator()<float>() : fix.template operator()<double>()) return rc;
+    if (x0 == nullptr) {                 // no fidelity asked for (tv_cp_sweep with TV_CP_FID_OF_INPUT delivers it): the partials are meaningless
+        HIP_TRY(hipMemsetAsync(fid, 0, sizeof(double), st));
+        return 0;
+    }
     return reduce_partials(w0, fp.n0 + fp.n1 + fp.n2 + fp.n3, nmax, fid, st);
 }
 
@@ -229,7 +253,7 @@ int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const voi
     double* w1 = w0 + sp.nmax + kStage + 16;
     auto sweep = [&]<typename T>() -> int {
         FusedArgsT<T> a{(const T*)x, (const T*)x_prev, (const T*)x_next, (T*)u, (const T*)x0, (T*)t,
-                        (T*)r, (T)thresh, (T)0, (T)rho, (T)0, (T)0, w0, w1, (int)(full_store & 3)};
+                        (T*)r, (T)thresh, (T)0, (T)rho, (T)0, (T)0, w0, w1, (int)(full_store & 3), (const T*)u};
         return tvm::fused_sweep<T, ALG_ADMM>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
     };
     const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();
@@ -286,7 +310,7 @@ int tv_cpop_fused(const tv_geom* g, const void* x_in, const void* x_prev, const 
     double* w1 = w0 + sp.nmax + kStage + 16;
     auto sweep = [&]<typename T>() -> int {
         FusedArgsT<T> a{(const T*)x_in, (const T*)x_prev, (const T*)x_next, (T*)q, nullptr, (T*)const_cast<void*>(atp),
-                        (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)0, (T)1, w0, w1, 0};
+                        (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)0, (T)1, w0, w1, 0, (const T*)q};
         return tvm::fused_sweep<T, ALG_CPOP>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
     };
     const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();

@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void k_subgrad_vec(DG g, WT<T> w, const T* x, 
     } else {
         r = subgrad_site<S, T, V>(g, w, xs, ns, mf2);
     }
+    zero_pad_cols<T, V>(g, c.col0, r);
     vstore<T, V>(G + (long long)c.zl * g.s_z + (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0, r);
 }
 
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(256) void k_normal_vec(DG g, WT<T> w, const T* x, c
             o.v[i] = xs.c.v[i] + rho * r.v[i];
             acc += (double)xs.c.v[i] * (double)o.v[i];
         }
+        zero_pad_cols<T, V>(g, c.col0, o);
         vstore<T, V>(out + off, o);
     }
     acc = block_sum(acc, sm);
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(256) void k_normal_central_vec(DG g, WT<T> w, const
             o.v[i] = xc.v[i] + rho * (T(0.25) * r.v[i]);
             acc += (double)xc.v[i] * (double)o.v[i];
         }
+        zero_pad_cols<T, V>(g, c.col0, o);
         vstore<T, V>(out + (long long)c.zl * g.s_z + inpl, o);
     }
     acc = block_sum(acc, sm);
@@ -533,7 +536,9 @@ __global__ __launch_bounds__(256) void k_subgrad_central_vec(DG g, WT<T> w, cons
             cen(c.t, g.m, (c.t >= 2) ? vload<T, V>(pc - 2 * g.s_t) : zero, (c.t + 2 < g.m) ? vload<T, V>(pc + 2 * g.s_t) : zero,
                 (c.t >= 1) ? vload<T, V>(nc - g.s_t) : zero, (c.t + 1 < g.m) ? vload<T, V>(nc + g.s_t) : zero, w.wt, true, true);
     }
-    vstore<T, V>(G + (long long)c.zl * g.s_z + inpl, h * r);
+    Vec<T, V> hr = h * r;
+    zero_pad_cols<T, V>(g, c.col0, hr);
+    vstore<T, V>(G + (long long)c.zl * g.s_z + inpl, hr);
 }
 
 // =============================================================================================

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "tv_cp_zchunk": (ctypes.c_int, [_G]),
     "tv_cp_fused": (ctypes.c_int, [_G] + [_c_void_p] * 7 + [ctypes.c_double] * 4 + [ctypes.c_int64] * 2 + [_c_double_p] * 2
                     + [_c_void_p, _c_void_p]),
+    "tv_cp_sweep": (ctypes.c_int, [_G] + [_c_void_p] * 8 + [ctypes.c_double] * 4 + [ctypes.c_int32] + [ctypes.c_int64] * 2 + [_c_double_p] * 2
+                    + [_c_void_p, _c_void_p]),
     "tv_cp_fixup": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double] + [ctypes.c_int64] * 2 + [_c_double_p, _c_void_p, _c_void_p]),
     "tv_admm_zu": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double, _c_double_p, _c_void_p, _c_void_p]),
     "tv_cpop_fused": (ctypes.c_int, [_G] + [_c_void_p] * 6 + [ctypes.c_double] * 3 + [ctypes.c_int64] * 2 + [_c_double_p, _c_void_p, _c_void_p]),

@@ -208,10 +208,14 @@ class ChambollePock(_SlabProblem):
         return h[:, cls.F:cls.SLOTS].sum(axis=1) + regularization * h[:, 0:cls.F].sum(axis=1)
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
-                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch="auto"):
+                 factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch="auto",
+                 q_pingpong=None):
         """fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
         iteration) whenever the geometry supports it, False = always the dual + primal kernel pair.
-        pitch: see ``_SlabProblem`` ("auto", the default: padded rows where that pays; None / "dense"; (row_pitch, frame_pitch))."""
+        pitch: see ``_SlabProblem`` ("auto", the default: padded rows where that pays; None / "dense"; (row_pitch, frame_pitch)).
+        q_pingpong (one-sweep path): read the dual variable from one array and write it to a second one, swapping them every
+        iteration, instead of updating it in place -- HBM serves that ~9 % faster for this kernel's memory shape (tools/bwtest4),
+        at the price of a second q (Nd images).  None = yes when the GPU has the memory to spare."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
@@ -243,12 +247,22 @@ class ChambollePock(_SlabProblem):
             raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry (tv_cp_fused_supported: "
                              "fp32, Nx % 4 == 0, Nx >= 64, Ny * Nx <= 2^30; any number of frames)")
         self.x_alt = self.new_image() if self.fused else None      # ping-pong partner of x
+        self.q_alt = None
+        if self.fused:
+            if q_pingpong is None:      # a second q when it fits with room to spare (the caller's other allocations are unknown)
+                free, _total = torch.cuda.mem_get_info(self.device)
+                q_pingpong = free >= 1.5 * self.q.numel() * self.q.element_size() + (8 << 30)
+            if q_pingpong:
+                self.q_alt = self.new_grad()
         self.overlap = bool(overlap) and sh and self.slab.nz >= 3 and not self.fused
         self.hist = None
         self.it = 0
         self.timing = None      # set to a list to collect (start, after kernel 1, after kernel 2) HIP events per step
         self.phase_timing = None  # set to a list to collect one (name, event) list per step: every phase boundary of the schedule
         self._scratch = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
+        self._lag = None                 # None: every step returns its own fidelity; else: lagged-fidelity block (see run_steps)
+        self._lag_void = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._cur_out = self._scratch
         if self.fused:
             self.zchunk = int(self.lib.tv_cp_zchunk(self.geo.ref))
             self.nchunks = (self.slab.nz + self.zchunk - 1) // self.zchunk
@@ -268,15 +282,28 @@ class ChambollePock(_SlabProblem):
                                         out.data_ptr(), _nv.ptr(self.ws), self.stream))
 
     def _sweep(self, c0, cn, xp, xn, tv_slot, fid_slot):
+        """One sweep launch.  In a lagged-fidelity block (``_lag``, see ``_run_eager``) the sweep returns 1/2 |x_in - x0|^2 over all
+        sites -- the fidelity of the iterate the PREVIOUS step produced -- into the previous step's slot, and the fix-up reads no x0."""
         g = self.geo
-        _nv.check(self.lib.tv_cp_fused(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.q), _nv.ptr(self.x0),
-                                       _nv.ptr(self.p), _nv.ptr(self.x_alt), self.sigma_D, self.reg, self.tau, self.sigma_A,
+        flags = 0
+        if self._lag is not None:
+            flags = 1                                    # TV_CP_FID_OF_INPUT
+            if self._lag is False:
+                fid_slot = self._lag_void                # first sweep of a block: nobody waits for its input's fidelity
+            else:                                        # the same slot index, one row back
+                i = fid_slot.storage_offset() - self._cur_out.storage_offset()
+                fid_slot = self._lag[i:i + 1]
+        _nv.check(self.lib.tv_cp_sweep(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.q),
+                                       _nv.ptr(self.q_alt if self.q_alt is not None else self.q), _nv.ptr(self.x0),
+                                       _nv.ptr(self.p), _nv.ptr(self.x_alt), self.sigma_D, self.reg, self.tau, self.sigma_A, flags,
                                        c0, cn, tv_slot.data_ptr(), fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
 
     def _fixup(self, z0, zn, qp, qn, fid_slot):
         g = self.geo
-        _nv.check(self.lib.tv_cp_fixup(g.ref, _nv.ptr(self.q), _nv.ptr(qp), _nv.ptr(qn), _nv.ptr(self.x_alt), _nv.ptr(self.x0),
-                                       self.tau, z0, zn, fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
+        lag = self._lag is not None
+        _nv.check(self.lib.tv_cp_fixup(g.ref, _nv.ptr(self.q_alt if self.q_alt is not None else self.q), _nv.ptr(qp), _nv.ptr(qn), _nv.ptr(self.x_alt),
+                                       None if lag else _nv.ptr(self.x0), self.tau, z0, zn,
+                                       (self._lag_void if lag else fid_slot).data_ptr(), _nv.ptr(self.ws), self.stream))
 
     def _step_fused(self, out):
         """One-sweep iteration: x halos -> sweep (x -> x_alt) -> q' halos -> fix-up -> swap.  With a sharded
@@ -286,6 +313,7 @@ class ChambollePock(_SlabProblem):
         ``phase_timing`` (a list): one event per phase boundary on the launch stream, so that a scaling run can say where an
         iteration's time went -- in particular how long the stream sat in ``s.wait(h)`` with nothing left to overlap."""
         s, nz, F = self.slab, self.slab.nz, self.F
+        self._cur_out = out
         ev = self._events()
         mark = self._phase_marker()
         qhp = self.qh_prev[0] if self.qh_prev is not None else None
@@ -305,7 +333,7 @@ class ChambollePock(_SlabProblem):
             self._sweep(0, 1, self.xh_prev, None, out[1:2], out[F + 1:F + 2])
             self._sweep(nch - 1, 1, None, self.xh_next, out[2:3], out[F + 2:F + 3])
             mark("sweep_edges")
-            h = self.plan.exchange_grad(self.q, qhp, qhn)
+            h = self.plan.exchange_grad(self.q_alt if self.q_alt is not None else self.q, qhp, qhn)
             if nb > 0:
                 self._sweep(1 + na, nb, None, None, out[3:4], out[F + 3:F + 4])
             mark("sweep_interior_b")
@@ -318,7 +346,7 @@ class ChambollePock(_SlabProblem):
             mark("sweep")
             if ev:
                 ev[1].record()
-            h = self.plan.exchange_grad(self.q, qhp, qhn)
+            h = self.plan.exchange_grad(self.q_alt if self.q_alt is not None else self.q, qhp, qhn)
         if self.overlap_fused:
             self._fixup(1, nz - 2, None, None, out[F + 4:F + 5])
             mark("fixup_interior")
@@ -335,7 +363,11 @@ class ChambollePock(_SlabProblem):
         if ev:
             ev[2].record()
         self.x, self.x_alt = self.x_alt, self.x
+        if self.q_alt is not None:
+            self.q, self.q_alt = self.q_alt, self.q          # self.q is always the current dual variable
         self.it += 1
+        if self._lag is not None:
+            self._lag = out                      # the next sweep delivers THIS step's fidelity into these slots
 
     def _phase_marker(self):
         """mark(name): record an event on the launch stream that closes phase `name` (no-op unless ``phase_timing`` is a list)"""
@@ -435,12 +467,34 @@ class ChambollePock(_SlabProblem):
             self.step(hist[1])
             done = self._run_graphed_from(hist, 2, n_iter)
             start = 2 + max(done, 0)
-        for it in range(start, n_iter):
-            self.step(hist[it])
+        self.run_steps(hist[start:n_iter])
         if not record_loss:
             return None
         self.slab.allreduce_sum_(hist)
         return self.loss_from_slots(hist.cpu().numpy(), self.reg)
+
+    def run_steps(self, rows):
+        """Enqueue ``len(rows)`` iterations, row k of the (n, SLOTS) fp64 device tensor ``rows`` receiving the scalars of iteration k.
+        One-sweep path (round 4): the fidelity 1/2 |x_{k+1} - x0|^2 of row k is delivered by the sweep of iteration k+1 (it has
+        x_{k+1} and x0 in registers: tv_cp_sweep, TV_CP_FID_OF_INPUT), so the fix-up reads no x0; the last row's fidelity comes from
+        one plain reduction at the end of the block.  The rows must be zero on entry (slots are written once each)."""
+        n = rows.shape[0]
+        if n == 0:
+            return
+        if not self.fused:
+            for k in range(n):
+                self.step(rows[k])
+            return
+        self._lag = False                # first sweep of the block: its input's fidelity belongs to nobody
+        try:
+            for k in range(n):
+                self.step(rows[k])
+        finally:
+            self._lag = None
+        # fidelity of the last iterate: |x - x0|^2 by the flat helper (x_alt is free between two steps: scratch output)
+        _nv.check(self.lib.tv_axpby(self.geo.ref, 1.0, _nv.ptr(self.x), 0.0, None, _nv.ptr(self.x0), _nv.ptr(self.x_alt),
+                                    self._lag_void.data_ptr(), _nv.ptr(self.ws), self.stream))
+        rows[n - 1, self.F] = 0.5 * self._lag_void[0]
 
     def _run_graphed_from(self, hist, first, n_iter):
         """Capture GRAPH_BLOCK iterations (not executed during capture) and replay them over hist[first:]."""
@@ -448,7 +502,7 @@ class ChambollePock(_SlabProblem):
         nrep = (n_iter - first) // K
         if nrep < 1:
             return 0
-        it0, x_ref, xalt_ref = self.it, self.x, self.x_alt
+        it0, x_ref, xalt_ref, q_ref, qalt_ref = self.it, self.x, self.x_alt, self.q, self.q_alt
         try:
             buf = torch.zeros((K, self.SLOTS), dtype=torch.float64, device=self.device)
             graph = torch.cuda.CUDAGraph()
@@ -456,7 +510,7 @@ class ChambollePock(_SlabProblem):
                 for k in range(K):
                     self.step(buf[k])
         except Exception:
-            self.it, self.x, self.x_alt = it0, x_ref, xalt_ref      # nothing ran: undo the bookkeeping, stay eager
+            self.it, self.x, self.x_alt, self.q, self.q_alt = it0, x_ref, xalt_ref, q_ref, qalt_ref      # nothing ran: undo the bookkeeping, stay eager
             return 0
         self.it = it0
         done = 0

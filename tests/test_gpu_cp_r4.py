@@ -1,0 +1,72 @@
+"""Round-4 forms of the one-sweep Chambolle-Pock iteration (README.md:141-157 of the reference), against the forms they replace:
+
+  * q ping-pong (tv_cp_sweep with q_in != q_out): the same arithmetic on the same values -- bit-identical x, q, loss;
+  * lagged fidelity (TV_CP_FID_OF_INPUT; the fix-up reads no x0): the same iterates bit for bit, the loss history equal to the
+    last digits (the fidelity is one fp64 sum over all sites instead of two partial sums), and equal to the oracle's.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCHEMES
+from oracle import tv_oracle as orc
+
+pytestmark = pytest.mark.gpu
+os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
+os.environ["TV_FUSED_MIN_KVOXELS"] = "0"
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(6, 3, 32, 64), (9, 8, 24, 256), (4, 11, 16, 64), (5, 2, 17, 128), (1, 1, 40, 320)])
+def test_pingpong_and_lagged_fidelity_equal_the_classic_loop(scheme, dtype, shape):
+    import torch
+    import pytv
+    rng = np.random.default_rng(3)
+    x0 = (orc.phantom(shape, dtype=np.float64) + 100 * rng.random(shape)).astype(dtype)
+    kw = dict(reg_z_over_reg=0.7, reg_time=1.3)
+    n = 7
+    dev = torch.as_tensor(x0).cuda()
+    # classic: in-place q, every step returns its own fidelity (step() outside run_steps)
+    a = pytv.solvers.ChambollePock(dev, 20.0, scheme=scheme, fused=True, q_pingpong=False, **kw)
+    hist = torch.zeros((n, a.SLOTS), dtype=torch.float64, device="cuda")
+    for k in range(n):
+        a.step(hist[k])
+    la = a.loss_from_slots(hist.cpu().numpy(), 20.0)
+    # round 4: ping-pong + lagged fidelity (run -> run_steps)
+    b = pytv.solvers.ChambollePock(dev, 20.0, scheme=scheme, fused=True, q_pingpong=True, **kw)
+    assert b.q_alt is not None
+    lb = b.run(n)
+    assert torch.equal(a.result(), b.result()) and torch.equal(a.q, b.q) and torch.equal(a.p, b.p)
+    np.testing.assert_allclose(lb, la, rtol=1e-12)
+    # in-place q with the lagged fidelity, and a run split in two blocks
+    c = pytv.solvers.ChambollePock(dev, 20.0, scheme=scheme, fused=True, q_pingpong=False, **kw)
+    lc = np.concatenate([c.run(3), c.run(n - 3)])
+    assert torch.equal(a.result(), c.result()) and torch.equal(a.q, c.q)
+    np.testing.assert_allclose(lc, la, rtol=1e-12)
+    _, wloss = orc.chambolle_pock(x0.astype(np.float64), n, 20.0, scheme=scheme, **kw)
+    np.testing.assert_allclose(lb, wloss, rtol=1e-5 if dtype == np.float32 else 1e-11)
+
+
+def test_fixup_without_x0_returns_zero_fidelity():
+    import torch
+    from pytv import _native as nv
+    lib = nv.lib()
+    shape = (4, 2, 16, 64)
+    g = nv.Geometry(shape, "hybrid", torch.float32, "cuda", reg_time=1.0)
+    rng = np.random.default_rng(0)
+    x = torch.as_tensor(rng.random(shape).astype(np.float32)).cuda()
+    x0 = torch.as_tensor(rng.random(shape).astype(np.float32)).cuda()
+    q, q2, p, xo = torch.zeros(g.grad_shape, device="cuda"), torch.zeros(g.grad_shape, device="cuda"), torch.zeros_like(x), torch.empty_like(x)
+    sc = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ws, st = g.workspace(), nv.current_stream(x.device)
+    nv.check(lib.tv_cp_sweep(g.ref, nv.ptr(x), None, None, nv.ptr(q), nv.ptr(q2), nv.ptr(x0), nv.ptr(p), nv.ptr(xo), 0.5, 5.0, 0.05, 1.0, 1, 0, -1,
+                             sc[0:1].data_ptr(), sc[1:2].data_ptr(), nv.ptr(ws), st))
+    want = 0.5 * torch.sum((x.double() - x0.double()) ** 2).item()
+    assert abs(sc[1].item() - want) <= 1e-12 * want                       # fidelity of the INPUT over all sites
+    sc[2] = 7.0
+    nv.check(lib.tv_cp_fixup(g.ref, nv.ptr(q2), None, None, nv.ptr(xo), None, 0.05, 0, -1, sc[2:3].data_ptr(), nv.ptr(ws), st))
+    assert sc[2].item() == 0.0
+    assert lib.tv_cp_sweep(g.ref, nv.ptr(x), None, None, nv.ptr(q), nv.ptr(q2), nv.ptr(x0), nv.ptr(p), nv.ptr(xo), 0.5, 5.0, 0.05, 1.0, 8, 0, -1,
+                           sc[0:1].data_ptr(), sc[1:2].data_ptr(), nv.ptr(ws), st) == -1
