@@ -57,7 +57,9 @@ def test_one_sweep_cp_pitched_equals_dense_and_oracle(pytv, scheme, dtype, shape
     pit = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 20.0, scheme=scheme, fused=True, pitch=pitch, **kw)
     assert pit.geo.pitched and pit.x.stride()[-2] == pitch[0] and pit.x.stride()[-3] == pitch[1]
     lp = pit.run(n)
-    np.testing.assert_array_equal(lp, ld)                                   # same blocks, same arithmetic: bit for bit
+    # same blocks, same arithmetic: the iterates are bit-identical; the loss agrees to fp64 rounding (the last fidelity of a block of
+    # iterations is a flat reduction over the storage, whose partial sums group the padded array differently)
+    np.testing.assert_allclose(lp, ld, rtol=1e-14)
     assert torch.equal(pit.result(), dense.result())
     assert torch.equal(pit.q, dense.q)
     for t in (pit.x, pit.x_alt, pit.p, pit.q):
