@@ -128,7 +128,7 @@ def live_traffic(args):
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None, "already running under a profiler"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pmc", "off",
-             "--workload", args.workload, "--scheme", args.scheme, "--pitch", args.pitch] + (["--two-kernel"] if args.two_kernel else [])
+             "--workload", args.workload, "--scheme", args.scheme, "--pitch", args.pitch, "--tune-placement", "off"] + (["--two-kernel"] if args.two_kernel else [])
     sums = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--pitch", default=os.environ.get("TV_BENCH_PITCH", "default"),
                     help="layout of the solver's private state: default (what solvers.ChambollePock picks), none (dense), auto, or "
                          "<frame pad in bytes> (rows rounded up to 128 B, frames padded by that many bytes)")
+    ap.add_argument("--tune-placement", default="default", choices=["default", "on", "off"],
+                    help="solvers.ChambollePock(tune_placement=...): default = the solver's own rule")
     ap.add_argument("--phases", action="store_true", help="per-phase HIP-event times of the schedule in the JSON line (always on at N > 1)")
     args = ap.parse_args()
     # must be in the environment BEFORE the HIP runtime starts (the pool's driver only supports dmabuf IPC; RCCL's
@@ -346,6 +348,8 @@ def main():
         pkw["pitch"] = "auto"
     elif args.pitch != "default":
         pkw["pitch"] = pytv.solvers.auto_pitch(shape[2], shape[3], torch.float32, frame_pad_bytes=int(args.pitch))
+    if args.tune_placement != "default":
+        pkw["tune_placement"] = (args.tune_placement == "on")
     cp = pytv.solvers.ChambollePock(x0, 25.0, scheme=args.scheme, reg_z_over_reg=wl["reg_z"], reg_time=wl["reg_time"],
                                     slab=slab, overlap=not args.no_overlap, fused=False if args.two_kernel else None, **pkw)
     state_layout = {"row_pitch_elems": cp.geo.row_pitch, "frame_pitch_elems": cp.geo.frame_pitch,
@@ -432,6 +436,9 @@ def main():
                                "one_sweep_(5+2Nd)_words": 4.0 * (5 + 2 * nd) * V * it_s / 1e9 / world, "per": "GPU"},
         "loss_first_last": [float(loss[W]), float(loss[-1])],
         "state_layout": state_layout,
+        # solvers.ChambollePock picks the two buffers of the x ping-pong by measurement at construction (outside the timed region, like
+        # the allocation itself): the candidates' sweep times and the pair it kept
+        "placement_tuning": getattr(cp, "placement", None),
         "rccl_ranks": rccl_ranks, "comm": comm_name,        # rccl_ranks: size of the RCCL communicator the run used (0: no process group / test backend)
         "halo": {"backend": (dist.get_backend() if dist.is_initialized() else None), "planes_per_exchange": 1,
                  "bytes_per_plane": 4 * shape[1] * shape[2] * shape[3], "exchanges_per_iteration": 2 if world > 1 else 0},

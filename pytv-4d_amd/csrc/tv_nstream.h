@@ -273,30 +273,34 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG
 // the vector itself and two DPP moves per side (edge lanes: an 8-byte load), frames t+-2 are registers.
 // Two-point z / t axes (forward stencil) stay on the one-site kernel (the host does not launch this one then).
 // =============================================================================================
-__device__ __forceinline__ F4 shfl_up32(const F4& v) {
-    F4 r;
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> shfl_up32_t(const Vec<T, V>& v) {
+    Vec<T, V> r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_up(v.v[i], 32, 64);
+    for (int i = 0; i < V; ++i) r.v[i] = __shfl_up(v.v[i], 32, 64);
     return r;
 }
-__device__ __forceinline__ F4 shfl_down32(const F4& v) {
-    F4 r;
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> shfl_down32_t(const Vec<T, V>& v) {
+    Vec<T, V> r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = __shfl_down(v.v[i], 32, 64);
+    for (int i = 0; i < V; ++i) r.v[i] = __shfl_down(v.v[i], 32, 64);
     return r;
 }
-struct F2 { float a, b; };
-__device__ __forceinline__ F2 ldu2(const float* ubase, unsigned voff) {
-    const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(ubase) + voff);
-    return F2{v.x, v.y};
+// the two elements just outside a lane's vector (x(col0-2), x(col0-1) or x(col0+V), x(col0+V+1)): one 2-element load
+template <typename T> struct E2 { T a, b; };
+template <typename T> __device__ __forceinline__ E2<T> ldu_e2(const T* ubase, unsigned voff) {
+    const Vec<T, 2> v = *reinterpret_cast<const Vec<T, 2>*>(reinterpret_cast<const char*>(ubase) + voff);
+    return E2<T>{v.v[0], v.v[1]};
 }
 
-template <int M, bool TWIN, bool CHEB = false>
-__global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g, WT<float> w, NormalArgs a, int zchunk, int nchunks) {
+// T: float (4 columns per 16-byte lane) or -- round 4 -- double (2 columns: the +-2 column neighbours are then whole neighbour lanes)
+template <int M, bool TWIN, bool CHEB = false, typename T = float>
+__global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
+    constexpr int V = 16 / (int)sizeof(T);
+    using VT = Vec<T, V>;
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
-    const int nxv = g.nx / 4;
+    const int nxv = (g.nx + V - 1) / V;
     const int tiles_x = (nxv + ST_BCV - 1) / ST_BCV, tiles_y = (g.ny + ST_BR - 1) / ST_BR;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + NS_TWN - 1) / NS_TWN : 1;
@@ -308,111 +312,114 @@ __global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_ce
         const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
         const int t0 = TWIN ? win * NS_TWN : 0;
         const int bx = tile % tiles_x, by = tile / tiles_x;
-        const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * 4, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
+        const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * V, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
         const bool ok = (col0 < g.nx) && (y < g.ny);
-        const unsigned voff = ok ? (unsigned)(((long long)y * g.rp + col0) * 4) : 0u;
-        const unsigned row_bytes = (unsigned)g.rp * 4u;
+        const unsigned voff = ok ? (unsigned)(((long long)y * g.rp + col0) * (long long)sizeof(T)) : 0u;
+        const unsigned row_bytes = (unsigned)g.rp * (unsigned)sizeof(T);
         const int zs = chunk * zchunk;
         const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
-        const F4 zero = vsplat<float, 4>(0.f);
-        F4 mf2 = vsplat<float, 4>(1.f);
+        const VT zero = vsplat<T, V>(T(0));
+        VT mf2 = vsplat<T, V>(T(1));
         if (g.ta) {
-            const F4 mf = mask_factor<float, 4>(g, w.sf, ok ? y : 0, ok ? col0 : 0);
+            const VT mf = mask_factor<T, V>(g, w.sf, ok ? y : 0, ok ? col0 : 0);
             mf2 = (w.wt * w.wt) * (mf * mf);
         }
-        const float wz2 = g.za ? w.wz * w.wz : 0.f;
+        const T wz2 = g.za ? w.wz * w.wz : T(0);
         // a term exists iff the channel it comes from does: backward term <=> p_a >= 2, forward term <=> p_a <= n_a - 3
-        const float m_pr = (ok && y >= 2) ? 1.f : 0.f, m_nr = (ok && y + 2 < g.ny) ? 1.f : 0.f;
-        float m_cb[4], m_cf[4];
+        const T m_pr = (ok && y >= 2) ? T(1) : T(0), m_nr = (ok && y + 2 < g.ny) ? T(1) : T(0);
+        T m_cb[V], m_cf[V];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            m_cb[i] = (ok && col0 + i >= 2) ? 1.f : 0.f;
-            m_cf[i] = (ok && col0 + i + 2 < g.nx) ? 1.f : 0.f;
+        for (int i = 0; i < V; ++i) {
+            m_cb[i] = (ok && col0 + i >= 2) ? T(1) : T(0);
+            m_cf[i] = (ok && col0 + i + 2 < g.nx) ? T(1) : T(0);
         }
         const bool want_up = (row <= 1) && ok && (y >= 2), want_dn = (row >= 2) && ok && (y + 2 < g.ny);
         const unsigned hoff = want_up ? voff - 2u * row_bytes : voff + 2u * row_bytes;
-        const bool want_le = (lx == 0) && ok && (col0 >= 2), want_re = (lx == 15) && ok && (col0 + 4 < g.nx);
-        const unsigned eoff = want_le ? voff - 8u : voff + 16u;
+        const bool want_le = (lx == 0) && ok && (col0 >= 2), want_re = (lx == 15) && ok && (col0 + V < g.nx);
+        const unsigned eoff = want_le ? voff - 2u * (unsigned)sizeof(T) : voff + 16u;
         auto fvalid = [&](int t) { return !TWIN || (t0 + t < Mg); };
         auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };
-        auto plane = [&](int zl) { return g.za ? zplane<float>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
-        auto load_c = [&](const float* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu(pl + foff(t), voff) : zero; };
+        auto plane = [&](int zl) { return g.za ? zplane<T>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
+        auto load_c = [&](const T* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu_t<T, V>(pl + foff(t), voff) : zero; };
         // same delayed-store structure as k_normal_stream, on each of the two stride-2 plane lattices: step z finishes plane z-2
-        F4 C[M], P[M], R[M], H[M];
-        F2 E[M];
+        VT C[M], P[M], R[M], H[M];
+        E2<T> E[M];
         for (int par = 0; par < 2; ++par) {
             const int zfirst = zs + par;
             if (zfirst >= ze) break;
             {
-                const float* pp = g.za ? plane(zfirst - 2) : nullptr;
-                const float* pc = plane(zfirst);
+                const T* pp = g.za ? plane(zfirst - 2) : nullptr;
+                const T* pc = plane(zfirst);
 #pragma unroll
                 for (int t = 0; t < M; ++t) {
                     P[t] = load_c(pp, t);
                     C[t] = load_c(pc, t);
                     R[t] = zero;
-                    H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu(pc + foff(t), hoff) : zero;
-                    E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu2(pc + foff(t), eoff) : F2{0.f, 0.f};
+                    H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pc + foff(t), hoff) : zero;
+                    E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu_e2<T>(pc + foff(t), eoff) : E2<T>{T(0), T(0)};
                 }
             }
             for (int z = zfirst; z < ze + 2; z += 2) {          // the step behind the chunk only finishes the lattice's last plane
                 st_sync_plane();
                 const bool in_chunk = (z < ze), next_in = (z + 2 < ze);
                 const int gz = g.z0 + z;
-                const float mz = (g.za && gz >= 2 && gz < g.nzg) ? wz2 : 0.f;
-                const float* pc = in_chunk ? plane(z) : nullptr;
-                const float* pn = (next_in || (g.za && in_chunk)) ? plane(z + 2) : nullptr;
-                F4 cold1 = zero, cold2 = zero;         // x(z, t-1), x(z, t-2)
+                const T mz = (g.za && gz >= 2 && gz < g.nzg) ? wz2 : T(0);
+                const T* pc = in_chunk ? plane(z) : nullptr;
+                const T* pn = (next_in || (g.za && in_chunk)) ? plane(z + 2) : nullptr;
+                VT cold1 = zero, cold2 = zero;         // x(z, t-1), x(z, t-2)
                 if (TWIN && g.ta && ok && in_chunk) {
-                    if (t0 >= 1) cold1 = ldu(pc + foff(-1), voff);
-                    if (t0 >= 2) cold2 = ldu(pc + foff(-2), voff);
+                    if (t0 >= 1) cold1 = ldu_t<T, V>(pc + foff(-1), voff);
+                    if (t0 >= 2) cold2 = ldu_t<T, V>(pc + foff(-2), voff);
                 }
 #pragma unroll
                 for (int t = 0; t < M; ++t) {
                     if (TWIN && !fvalid(t)) break;
                     st_sync_frame();
                     const int tg = t0 + t;
-                    const F4 c = C[t], h = H[t], xm = P[t];
-                    const F4 dz = ns_mul(mz, c, xm);
-                    const F4 rfin = ns_sub(R[t], dz);
+                    const VT c = C[t], h = H[t], xm = P[t];
+                    const VT dz = ns_mul<T, V>(mz, c, xm);
+                    const VT rfin = ns_sub<T, V>(R[t], dz);
                     if (in_chunk) {
                         // rows y-2 / y+2: rows 2, 3 take y-2 from rows 0, 1 of the tile (32 lanes up), rows 0, 1 from the halo load
-                        const F4 sup = shfl_up32(c), sdn = shfl_down32(c);
-                        const F4 pr = (row <= 1) ? h : sup, nr = (row >= 2) ? h : sdn;
-                        F4 r = m_pr * (c - pr) - m_nr * (nr - c);
+                        const VT sup = shfl_up32_t<T, V>(c), sdn = shfl_down32_t<T, V>(c);
+                        const VT pr = (row <= 1) ? h : sup, nr = (row >= 2) ? h : sdn;
+                        VT r = m_pr * (c - pr) - m_nr * (nr - c);
                         {
-                            const float l2 = dpp_from_left(c.v[2]), l3 = dpp_from_left(c.v[3]);       // executed by every lane
-                            const float r0 = dpp_from_right(c.v[0]), r1 = dpp_from_right(c.v[1]);
-                            const float lm2 = (lx == 0) ? E[t].a : l2, lm1 = (lx == 0) ? E[t].b : l3;   // x(col0-2), x(col0-1)
-                            const float rp4 = (lx == 15) ? E[t].a : r0, rp5 = (lx == 15) ? E[t].b : r1; // x(col0+4), x(col0+5)
-                            r.v[0] += m_cb[0] * (c.v[0] - lm2) - m_cf[0] * (c.v[2] - c.v[0]);
-                            r.v[1] += m_cb[1] * (c.v[1] - lm1) - m_cf[1] * (c.v[3] - c.v[1]);
-                            r.v[2] += m_cb[2] * (c.v[2] - c.v[0]) - m_cf[2] * (rp4 - c.v[2]);
-                            r.v[3] += m_cb[3] * (c.v[3] - c.v[1]) - m_cf[3] * (rp5 - c.v[3]);
+                            // the last two elements of the lane on the left, the first two of the lane on the right (V == 2: its whole vector)
+                            const T l2 = dpp_from_left(c.v[V - 2]), l3 = dpp_from_left(c.v[V - 1]);       // executed by every lane
+                            const T r0 = dpp_from_right(c.v[0]), r1 = dpp_from_right(c.v[1]);
+                            const T lm[2] = {(lx == 0) ? E[t].a : l2, (lx == 0) ? E[t].b : l3};           // x(col0-2), x(col0-1)
+                            const T rp[2] = {(lx == 15) ? E[t].a : r0, (lx == 15) ? E[t].b : r1};         // x(col0+V), x(col0+V+1)
+#pragma unroll
+                            for (int i = 0; i < V; ++i) {
+                                const T xb = (i >= 2) ? c.v[(i >= 2) ? i - 2 : 0] : lm[(i < 2) ? i : 0];
+                                const T xf = (i + 2 < V) ? c.v[(i + 2 < V) ? i + 2 : 0] : rp[(i + 2 >= V) ? i + 2 - V : 0];
+                                r.v[i] += m_cb[i] * (c.v[i] - xb) - m_cf[i] * (xf - c.v[i]);
+                            }
                         }
                         if (g.ta) {
-                            F4 tt = zero;
+                            VT tt = zero;
                             if (tg >= 2) tt = tt + (c - cold2);
                             if (tg + 2 < Mg) {
                                 if (t + 2 < M) tt = tt - (C[(t + 2 < M) ? t + 2 : t] - c);
-                                else if (TWIN) tt = tt - ((ok ? ldu(pc + foff(t + 2), voff) : zero) - c);
+                                else if (TWIN) tt = tt - ((ok ? ldu_t<T, V>(pc + foff(t + 2), voff) : zero) - c);
                             }
                             r = r + mf2 * tt;
                         }
-                        R[t] = ns_add(r, dz);
+                        R[t] = ns_add<T, V>(r, dz);
                     }
                     cold2 = cold1;
                     cold1 = c;
                     P[t] = c;
                     C[t] = load_c(pn, t);
-                    H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu(pn + foff(t), hoff) : zero;
-                    E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu2(pn + foff(t), eoff) : F2{0.f, 0.f};
+                    H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pn + foff(t), hoff) : zero;
+                    E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu_e2<T>(pn + foff(t), eoff) : E2<T>{T(0), T(0)};
                     if (!ok || z == zfirst) continue;
                     const long long fo = (long long)(z - 2) * g.s_z + foff(t);
-                    F4 ax;
+                    VT ax;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ax.v[i] = xm.v[i] + a.rho * (0.25f * rfin.v[i]);
-                    ns_epilogue<float, 4, CHEB>(a, fo, voff, xm, ax, acc0, acc1);
+                    for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * (T(0.25) * rfin.v[i]);
+                    ns_epilogue<T, V, CHEB>(a, fo, voff, xm, ax, acc0, acc1);
                 }
             }
         }

@@ -12,7 +12,6 @@ bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
     // pitched arrays: rows of whole 16-byte lanes only (the column stencil inside a lane assumes every element has both neighbours;
     // ragged rows take the one-site kernels)
     if (!vec || d.nx < 64 || d.wv != nullptr || d.nx % ((g->dtype == TV_F32) ? 4 : 2) != 0) return false;
-    if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL) return false;                          // fp64 (round 3): the radius-1 kernel only
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return false;   // two-point axes: forward stencil
     const long long eb = (g->dtype == TV_F32) ? 4 : 8;
     if (d.s_t * eb > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
@@ -48,8 +47,10 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
                            (const double*)c.y, (const double*)c.add, (const double*)c.ref, c.alpha, c.beta, cheb ? 1 : 0, c.yscale};
 #define TV_NS_LAUNCH1(MM, TW, CH)                                                                                       \
     do {                                                                                                               \
-        if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
-        else if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH>), grid, block, 0, st, d, w, a, zc, (int)nch); \
+        if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL)                                                             \
+            hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, double>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
+        else if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
+        else if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, float>), grid, block, 0, st, d, w, a, zc, (int)nch); \
         else hipLaunchKernelGGL((k_normal_stream<MM, TW, float, CH>), grid, block, 0, st, d, w, a, zc, (int)nch);       \
     } while (0)
     // the Chebyshev epilogue is its own instantiation (tv_nstream.h, ns_epilogue)

@@ -209,13 +209,16 @@ class ChambollePock(_SlabProblem):
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
                  factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch="auto",
-                 q_pingpong=None):
+                 q_pingpong=False, tune_placement=None):
         """fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
         iteration) whenever the geometry supports it, False = always the dual + primal kernel pair.
         pitch: see ``_SlabProblem`` ("auto", the default: padded rows where that pays; None / "dense"; (row_pitch, frame_pitch)).
-        q_pingpong (one-sweep path): read the dual variable from one array and write it to a second one, swapping them every
-        iteration, instead of updating it in place -- HBM serves that ~9 % faster for this kernel's memory shape (tools/bwtest4),
-        at the price of a second q (Nd images).  None = yes when the GPU has the memory to spare."""
+        q_pingpong (one-sweep path; default off): read the dual variable from one array and write it to a second one, swapping them
+        every iteration, instead of updating it in place.  An arithmetic-free kernel with the sweep's memory shape gains 9 % from
+        it (tools/bwtest4, profiles/r4_bwtest4_q_pingpong.txt); the real sweep does not (tools/pp_probe.py: 33.3 against 33.4 ms in
+        one pool, and one of the two directions can be 3 ms slower than the other when the arrays are separate allocations) --
+        kept as an option of tv_cp_sweep, not used by default.
+        tune_placement: None = on for unsharded volumes of >= 4 GiB per image with memory to spare (see ``_tune_x_placement``)."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
@@ -249,9 +252,6 @@ class ChambollePock(_SlabProblem):
         self.x_alt = self.new_image() if self.fused else None      # ping-pong partner of x
         self.q_alt = None
         if self.fused:
-            if q_pingpong is None:      # a second q when it fits with room to spare (the caller's other allocations are unknown)
-                free, _total = torch.cuda.mem_get_info(self.device)
-                q_pingpong = free >= 1.5 * self.q.numel() * self.q.element_size() + (8 << 30)
             if q_pingpong:
                 self.q_alt = self.new_grad()
         self.overlap = bool(overlap) and sh and self.slab.nz >= 3 and not self.fused
@@ -268,6 +268,14 @@ class ChambollePock(_SlabProblem):
             self.nchunks = (self.slab.nz + self.zchunk - 1) // self.zchunk
             # interior-first scheduling of the one-sweep path needs an interior: >= 3 chunks and >= 3 planes
             self.overlap_fused = bool(overlap) and sh and self.nchunks >= 3 and self.slab.nz >= 3
+        self.placement = None
+        if self.fused:
+            img_bytes = self.x.numel() * self.x.element_size()
+            if tune_placement is None:
+                free, _total = torch.cuda.mem_get_info(self.device)
+                tune_placement = (not self.slab.sharded) and img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
+            if tune_placement:
+                self._tune_x_placement()
 
     # ---- one phase on local planes [a, b) -----------------------------------------------------
     def _dual(self, a, b, xp, xn, out):
@@ -280,6 +288,60 @@ class ChambollePock(_SlabProblem):
         _nv.check(self.lib.tv_cp_primal(g.ref, _nv.ptr(self.q[a:b]), _nv.ptr(qp), _nv.ptr(qn), _nv.ptr(self.x[a:b]),
                                         _nv.ptr(self.x0[a:b]), _nv.ptr(self.p[a:b]), self.tau, self.sigma_A,
                                         out.data_ptr(), _nv.ptr(self.ws), self.stream))
+
+    def _tune_x_placement(self, n_extra=2, reps=2):
+        """Pick the two image buffers the iterate ping-pongs between by MEASUREMENT.
+
+        Why: on MI355X the time of the one-sweep kernel depends on WHERE its arrays landed in
+        physical memory -- the same binary on the same data runs the north-star sweep in 31.5 or in 34 ms, the level is fixed for
+        the life of an allocation, and it differs between the two directions of the x ping-pong (sweeps alternate 34.5 / 32.5 ms):
+        the memory side answers the reads of one buffer ~4 % later than those of the other (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ,
+        evenly over all 128 L2 channels: profiles/r4_channel_counters.txt; the rate of a plain copy depends on the distance
+        between source and destination in the same way: profiles/r4_deltatest.txt).  Nothing a process can ask the allocator for
+        controls it (page size, alignment, one pool or many: profiles/r4_vmtest.txt, r3_placement_experiments.txt), but it can
+        be MEASURED: allocate ``n_extra`` more image buffers, time one sweep for every ordered (input, output) pair, keep the pair
+        with the smallest round-trip time, free the rest.  Costs n (n - 1) reps sweeps once per solver (~0.9 s for the north star);
+        the state is re-initialised afterwards, results do not depend on it."""
+        import time as _time
+        t_begin = _time.perf_counter()
+        cands = [self.x, self.x_alt] + [self.new_image() for _ in range(n_extra)]
+        n = len(cands)
+        out = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
+        ev = [[None] * n for _ in range(n)]
+        x_keep, xalt_keep = self.x, self.x_alt
+        hp = cands[0][0:1] if self.plan.x_need_prev else None           # timing only: any plane of the right layout serves as a halo
+        hn = cands[0][0:1] if self.plan.x_need_next else None
+        for _ in range(2):                                                   # warm-up (code load, clocks)
+            self._sweep(0, -1, hp, hn, out[0:1], out[self.F:self.F + 1])
+        for r in range(reps):
+            for i in range(n):
+                for j in range(n):
+                    if i == j:
+                        continue
+                    self.x, self.x_alt = cands[i], cands[j]
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    self._sweep(0, -1, hp, hn, out[0:1], out[self.F:self.F + 1])
+                    b.record()
+                    ev[i][j] = (ev[i][j] or []) + [(a, b)]
+        torch.cuda.synchronize(self.device)
+        t = [[(min(a.elapsed_time(b) for a, b in ev[i][j]) if i != j else float("inf")) for j in range(n)] for i in range(n)]
+        best = min(((t[i][j] + t[j][i], i, j) for i in range(n) for j in range(i + 1, n)))
+        _, bi, bj = best
+        self.x, self.x_alt = cands[bi], cands[bj]
+        self.placement = {"candidates": n, "sweep_ms": [[None if i == j else round(t[i][j], 3) for j in range(n)] for i in range(n)],
+                          "chosen": [bi, bj], "chosen_ms": [round(t[bi][bj], 3), round(t[bj][bi], 3)],
+                          "first_pair_ms": [round(t[0][1], 3), round(t[1][0], 3)]}
+        del cands, x_keep, xalt_keep
+        # back to the initial state: x = x0, p = q = 0 (the timed sweeps wrote into them)
+        self.x.copy_(self.x0)
+        self.p.zero_()
+        self.q.zero_()
+        if self.q_alt is not None:
+            self.q_alt.zero_()
+        torch.cuda.synchronize(self.device)
+        torch.cuda.empty_cache()
+        self.placement["seconds"] = round(_time.perf_counter() - t_begin, 3)
 
     def _sweep(self, c0, cn, xp, xn, tv_slot, fid_slot):
         """One sweep launch.  In a lagged-fidelity block (``_lag``, see ``_run_eager``) the sweep returns 1/2 |x_in - x0|^2 over all
