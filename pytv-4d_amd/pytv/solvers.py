@@ -290,49 +290,89 @@ class ChambollePock(_SlabProblem):
                                         out.data_ptr(), _nv.ptr(self.ws), self.stream))
 
     def _tune_x_placement(self, n_extra=2, reps=2):
-        """Pick the two image buffers the iterate ping-pongs between by MEASUREMENT.
+        """Pick WHERE the arrays of the iteration live by MEASUREMENT: the dual variable q (one alternative allocation, when the
+        memory is there), the two image buffers the iterate ping-pongs between (``n_extra`` more candidates, every ordered pair
+        timed), and the fidelity dual p (the candidates that are left).
 
-        Why: on MI355X the time of the one-sweep kernel depends on WHERE its arrays landed in
-        physical memory -- the same binary on the same data runs the north-star sweep in 31.5 or in 34 ms, the level is fixed for
+        Why: on MI355X the time of the one-sweep kernel depends on where its arrays landed in
+        physical memory -- the same binary on the same data runs the north-star sweep in 31.2 or in 34 ms, the level is fixed for
         the life of an allocation, and it differs between the two directions of the x ping-pong (sweeps alternate 34.5 / 32.5 ms):
-        the memory side answers the reads of one buffer ~4 % later than those of the other (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ,
+        the memory side answers the reads of one placement ~4 % later than those of another (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ,
         evenly over all 128 L2 channels: profiles/r4_channel_counters.txt; the rate of a plain copy depends on the distance
         between source and destination in the same way: profiles/r4_deltatest.txt).  Nothing a process can ask the allocator for
-        controls it (page size, alignment, one pool or many: profiles/r4_vmtest.txt, r3_placement_experiments.txt), but it can
-        be MEASURED: allocate ``n_extra`` more image buffers, time one sweep for every ordered (input, output) pair, keep the pair
-        with the smallest round-trip time, free the rest.  Costs n (n - 1) reps sweeps once per solver (~0.9 s for the north star);
+        controls it (page size, alignment, one pool or many, a pitch: profiles/r4_vmtest.txt, r4_bwtest4_frame_pitch.txt,
+        r3_placement_experiments.txt), but it can be MEASURED.  Costs ~40 sweeps once per solver (~1.3 s for the north star:
+        same-box A/B 33.8 / 34.3 / 34.8 ms per iteration with it, 35.2 / 35.4 / 35.2 without, profiles/r4_placement_tuner_ab.txt);
         the state is re-initialised afterwards, results do not depend on it."""
         import time as _time
         t_begin = _time.perf_counter()
-        cands = [self.x, self.x_alt] + [self.new_image() for _ in range(n_extra)]
-        n = len(cands)
         out = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
-        ev = [[None] * n for _ in range(n)]
-        x_keep, xalt_keep = self.x, self.x_alt
-        hp = cands[0][0:1] if self.plan.x_need_prev else None           # timing only: any plane of the right layout serves as a halo
-        hn = cands[0][0:1] if self.plan.x_need_next else None
-        for _ in range(2):                                                   # warm-up (code load, clocks)
+        hp = self.x[0:1] if self.plan.x_need_prev else None           # timing only: any plane of the right layout serves as a halo
+        hn = self.x[0:1] if self.plan.x_need_next else None
+        info = {}
+
+        def one(i_buf, o_buf):
+            self.x, self.x_alt = i_buf, o_buf
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
             self._sweep(0, -1, hp, hn, out[0:1], out[self.F:self.F + 1])
+            b.record()
+            return a, b
+
+        def round_trip(u, v):
+            """ms of u -> v plus v -> u (best of ``reps``)"""
+            evs = [(one(u, v), one(v, u)) for _ in range(reps)]
+            torch.cuda.synchronize(self.device)
+            return min(e[0][0].elapsed_time(e[0][1]) for e in evs) + min(e[1][0].elapsed_time(e[1][1]) for e in evs)
+
+        x_a, x_b = self.x, self.x_alt
+        for _ in range(2):                                                   # warm-up (code load, clocks)
+            one(x_a, x_b)
+        # ---- the dual variable: one alternative allocation, if it fits with room to spare ---------------------------------------
+        q_bytes = self.q.numel() * self.q.element_size()
+        img_bytes = x_a.numel() * x_a.element_size()
+        free, _total = torch.cuda.mem_get_info(self.device)
+        if self.q_alt is None and free >= q_bytes + (n_extra + 1) * img_bytes + (8 << 30):
+            q1 = self.q
+            t1 = round_trip(x_a, x_b)
+            q2 = self.new_grad()
+            self.q = q2
+            t2 = round_trip(x_a, x_b)
+            info["q_round_trip_ms"] = [round(t1, 3), round(t2, 3)]
+            if t1 <= t2:
+                self.q = q1
+            del q1, q2
+            torch.cuda.empty_cache()
+        # ---- the image pair: every ordered pair of the candidates ------------------------------------------------------------------
+        cands = [x_a, x_b] + [self.new_image() for _ in range(n_extra)]
+        n = len(cands)
+        ev = [[[] for _ in range(n)] for _ in range(n)]
         for r in range(reps):
             for i in range(n):
                 for j in range(n):
-                    if i == j:
-                        continue
-                    self.x, self.x_alt = cands[i], cands[j]
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    self._sweep(0, -1, hp, hn, out[0:1], out[self.F:self.F + 1])
-                    b.record()
-                    ev[i][j] = (ev[i][j] or []) + [(a, b)]
+                    if i != j:
+                        ev[i][j].append(one(cands[i], cands[j]))
         torch.cuda.synchronize(self.device)
         t = [[(min(a.elapsed_time(b) for a, b in ev[i][j]) if i != j else float("inf")) for j in range(n)] for i in range(n)]
-        best = min(((t[i][j] + t[j][i], i, j) for i in range(n) for j in range(i + 1, n)))
-        _, bi, bj = best
-        self.x, self.x_alt = cands[bi], cands[bj]
-        self.placement = {"candidates": n, "sweep_ms": [[None if i == j else round(t[i][j], 3) for j in range(n)] for i in range(n)],
-                          "chosen": [bi, bj], "chosen_ms": [round(t[bi][bj], 3), round(t[bj][bi], 3)],
-                          "first_pair_ms": [round(t[0][1], 3), round(t[1][0], 3)]}
-        del cands, x_keep, xalt_keep
+        _, bi, bj = min(((t[i][j] + t[j][i], i, j) for i in range(n) for j in range(i + 1, n)))
+        info.update({"candidates": n, "sweep_ms": [[None if i == j else round(t[i][j], 3) for j in range(n)] for i in range(n)],
+                     "chosen": [bi, bj], "chosen_ms": [round(t[bi][bj], 3), round(t[bj][bi], 3)],
+                     "first_pair_ms": [round(t[0][1], 3), round(t[1][0], 3)]})
+        x_a, x_b = cands[bi], cands[bj]
+        # ---- the fidelity dual p: the candidates that are left, against the allocation it has ------------------------------------------
+        rest = [c for k, c in enumerate(cands) if k not in (bi, bj)]
+        del cands
+        p_cands = [self.p] + rest
+        tp = []
+        for c in p_cands:
+            self.p = c
+            tp.append(round_trip(x_a, x_b))
+        kp = min(range(len(tp)), key=lambda k: tp[k])
+        self.p = p_cands[kp]
+        info["p_round_trip_ms"] = [round(v, 3) for v in tp]
+        info["p_chosen"] = kp
+        del p_cands, rest
+        self.x, self.x_alt = x_a, x_b
         # back to the initial state: x = x0, p = q = 0 (the timed sweeps wrote into them)
         self.x.copy_(self.x0)
         self.p.zero_()
@@ -341,7 +381,8 @@ class ChambollePock(_SlabProblem):
             self.q_alt.zero_()
         torch.cuda.synchronize(self.device)
         torch.cuda.empty_cache()
-        self.placement["seconds"] = round(_time.perf_counter() - t_begin, 3)
+        info["seconds"] = round(_time.perf_counter() - t_begin, 3)
+        self.placement = info
 
     def _sweep(self, c0, cn, xp, xn, tv_slot, fid_slot):
         """One sweep launch.  In a lagged-fidelity block (``_lag``, see ``_run_eager``) the sweep returns 1/2 |x_in - x0|^2 over all
