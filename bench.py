@@ -128,7 +128,7 @@ def live_traffic(args):
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None, "already running under a profiler"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pmc", "off",
-             "--workload", args.workload, "--scheme", args.scheme, "--pitch", args.pitch, "--tune-placement", "off", "--lazy", args.lazy] + (["--two-kernel"] if args.two_kernel else [])
+             "--workload", args.workload, "--scheme", args.scheme, "--pitch", args.pitch, "--tune-placement", "off"] + (["--two-kernel"] if args.two_kernel else [])
     sums = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -263,9 +263,6 @@ def main():
     ap.add_argument("--pitch", default=os.environ.get("TV_BENCH_PITCH", "default"),
                     help="layout of the solver's private state: default (what solvers.ChambollePock picks), none (dense), auto, or "
                          "<frame pad in bytes> (rows rounded up to 128 B, frames padded by that many bytes)")
-    ap.add_argument("--lazy", default={"1": "on", "0": "off"}.get(os.environ.get("TV_BENCH_LAZY", ""), "default"), choices=["default", "on", "off"],
-                    help="solvers.ChambollePock(lazy=...): the one-kernel iteration (pending adjoint terms applied by the next sweep); "
-                         "default = the solver's own rule")
     ap.add_argument("--tune-placement", default="default", choices=["default", "on", "off"],
                     help="solvers.ChambollePock(tune_placement=...): default = the solver's own rule")
     ap.add_argument("--phases", action="store_true", help="per-phase HIP-event times of the schedule in the JSON line (always on at N > 1)")
@@ -353,8 +350,6 @@ def main():
         pkw["pitch"] = pytv.solvers.auto_pitch(shape[2], shape[3], torch.float32, frame_pad_bytes=int(args.pitch))
     if args.tune_placement != "default":
         pkw["tune_placement"] = (args.tune_placement == "on")
-    if args.lazy != "default":
-        pkw["lazy"] = (args.lazy == "on")
     cp = pytv.solvers.ChambollePock(x0, 25.0, scheme=args.scheme, reg_z_over_reg=wl["reg_z"], reg_time=wl["reg_time"],
                                     slab=slab, overlap=not args.no_overlap, fused=False if args.two_kernel else None, **pkw)
     state_layout = {"row_pitch_elems": cp.geo.row_pitch, "frame_pitch_elems": cp.geo.frame_pitch,
@@ -467,7 +462,6 @@ def main():
                         "note": "kernel1 = sweep (or dual), kernel2 = fix-up (or primal), step = start of iteration k to start of k+1"}
     out["gpu_state"] = {"before": state_before, "after": state_after, "source": "sysfs (pp_dpm_*, hwmon) read by rank 0 outside the timed region"}
     cp_fused = bool(cp.fused)
-    cp_lazy = bool(getattr(cp, "lazy", False))
     if want_live:
         # AFTER the timed region, with this process's device memory handed back: the child passes need the HBM for the same
         # volume, and a process that starts right after another one released ~100 GB can run 5 - 7 % slower for its whole life
@@ -484,8 +478,7 @@ def main():
     sharded = " (per GPU; kernel 2 interval includes the halo wait)" if world > 1 else ""
     if cp_fused:
         b_k1 = 4.0 * (5 + 2 * nd) * V_local      # read x, x0, p, q ; write q, x, p
-        out["config"]["kernels"] = ("one-sweep, lazy: tv_cp_sweep alone (pending adjoint terms applied by the next sweep; one tv_cp_fixup per block of iterations)"
-                                    if cp_lazy else "one-sweep: tv_cp_sweep + tv_cp_fixup")
+        out["config"]["kernels"] = "one-sweep: tv_cp_fused + tv_cp_fixup"
         out["roofline"] = {"bound": "hbm", "kernel": "tv_cp_fused: k_cp_fused<S,M> (dual update + lagged primal update, one pass over q)",
                            "achieved": b_k1 / t_k1 / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_k1 / t_k1 / 1e9 / HBM_PEAK_GBPS,
                            "traffic": traffic.get("fused"),

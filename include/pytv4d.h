@@ -211,14 +211,6 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
  * array, write another" better than a read-modify-write of the same lines (tools/bwtest4: 5.98 against 5.50 TB/s for this
  * kernel's memory shape).  tv_cp_fixup takes q_out. */
 #define TV_CP_FID_OF_INPUT 1
-/* TV_CP_LAZY (unsharded volumes, m <= 8, q_in != q_out): NO fix-up between iterations.  x_in is what the previous tv_cp_sweep
- * wrote, i.e. it lacks the adjoint terms that cross a wave tile / block tile / z-chunk; this sweep adds them to every value of
- * x it loads, taking them from q_in -- the dual variable the previous sweep wrote, which is why it cannot be updated in place.
- * Same terms, same order, same arithmetic as tv_cp_fixup: the iterates are bit-identical to the sweep + fix-up form.  To READ x
- * (result, halo, loss) run tv_cp_fixup(g, q_out, NULL, NULL, x_out, NULL, tau, ...) once: it completes x_out, and the next
- * sweep is then told so with TV_CP_X_COMPLETE (as is the first sweep of a run). */
-#define TV_CP_LAZY 2
-#define TV_CP_X_COMPLETE 4
 int tv_cp_sweep(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q_out, const void* x0,
                 void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int32_t flags, int64_t chunk_begin,
                 int64_t chunk_count, double* tv, double* fid, void* ws, void* stream);

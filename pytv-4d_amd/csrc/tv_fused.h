@@ -148,62 +148,6 @@ __device__ __forceinline__ bool fused_needs_fixup(const DG& g, int zl, int y, in
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// LAZY form of the one-sweep iteration (round 4, tv_cp_sweep with TV_CP_LAZY): sweep k leaves the adjoint terms that cross a wave
-// tile / block tile / z-chunk out of x_out(k) exactly as before, but no fix-up kernel adds them afterwards -- sweep k+1 applies
-// them to every value of x it loads:  x = x~ - tau (s m),  m = the pending sum of that site, taken from the dual variable sweep k
-// WROTE (q_in of sweep k+1, which therefore must not be the array sweep k+1 writes: q ping-pong).  Same terms, same order, same
-// arithmetic as fixup_site below, so the iterates are bit-identical to the sweep + fix-up form.  Unsharded volumes, M <= 8.
-// ---------------------------------------------------------------------------------------------
-template <int S, bool XW, typename T, int V = 16 / (int)sizeof(T)>
-__device__ __forceinline__ Vec<T, V> cp_pending_vec(const DG& g, const WT<T>& w, const T* q, int zchunk, int zl, int t, int y, int col0) {
-    using VT = Vec<T, V>;
-    constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
-    VT m = vsplat<T, V>(T(0));
-    if (!fused_needs_fixup<S, XW, V>(g, zl, y, col0, zchunk)) return m;
-    constexpr int CM = XW ? CPG<V>::BC - 1 : CPG<V>::WC - 1;
-    const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
-    const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
-    const bool z_fwd = CEN && g.z_two;
-    const T* qb = q + (long long)zl * g.s_dz + (long long)t * g.s_t + (long long)y * g.rp + col0;
-    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + vload<T, V>(qb + (long long)c_ru * g.s_z - g.rp);
-    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - vload<T, V>(qb + (long long)c_rd * g.s_z + g.rp);
-    if (UP && (col0 & CM) == 0 && col0 >= (CEN ? 2 : 1)) m.v[0] += qb[(long long)c_cu * g.s_z - 1];
-    if (DN && (col0 & CM) == CM - (V - 1) && col0 + V <= g.nx - (CEN ? 2 : 1)) m.v[V - 1] -= qb[(long long)c_cd * g.s_z + V];
-    if (g.za) {
-        const int gz = g.z0 + zl;
-        const int zs = (zl / zchunk) * zchunk;
-        const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
-        if (UP && zl == zs && gz >= ((CEN && !z_fwd) ? 2 : 1) && zl >= 1) m = m + w.wz * vload<T, V>(qb + (long long)c_zu * g.s_z - g.s_dz);
-        if (DN && !z_fwd && zl == ze - 1 && gz <= g.nzg - (CEN ? 3 : 2) && zl + 1 < g.nz) m = m - w.wz * vload<T, V>(qb + (long long)c_zd * g.s_z + g.s_dz);
-    }
-    return m;
-}
-// the same for ONE element (the 4-byte column neighbours across a wave-tile border)
-template <int S, bool XW, typename T, int V = 16 / (int)sizeof(T)>
-__device__ __forceinline__ T cp_pending_elem(const DG& g, const WT<T>& w, const T* q, int zchunk, int zl, int t, int y, int col) {
-    constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
-    constexpr int BC = XW ? CPG<V>::BC : CPG<V>::WC;
-    const int c_ru = 0, c_cu = 1, c_rd = (S == HYBRID) ? 2 : 0, c_cd = (S == HYBRID) ? 3 : 1;
-    const int c_zu = g.ch_z, c_zd = (S == HYBRID) ? g.ch_z + 1 : g.ch_z;
-    const bool z_fwd = CEN && g.z_two;
-    const T* qb = q + (long long)zl * g.s_dz + (long long)t * g.s_t + (long long)y * g.rp + col;
-    T m = T(0);
-    if (UP && (y & (CP_TR - 1)) == 0 && y >= (CEN ? 2 : 1)) m = m + qb[(long long)c_ru * g.s_z - g.rp];
-    if (DN && (y & (CP_TR - 1)) == CP_TR - 1 && y <= g.ny - (CEN ? 3 : 2)) m = m - qb[(long long)c_rd * g.s_z + g.rp];
-    // the element is the FIRST column of a block tile (its vector starts there) / the LAST one (its vector ends there)
-    if (UP && (col % BC) == 0 && col >= (CEN ? 2 : 1)) m += qb[(long long)c_cu * g.s_z - 1];
-    if (DN && (col % BC) == BC - 1 && col + 1 <= g.nx - (CEN ? 2 : 1)) m -= qb[(long long)c_cd * g.s_z + 1];
-    if (g.za) {
-        const int gz = g.z0 + zl;
-        const int zs = (zl / zchunk) * zchunk;
-        const int ze = (zs + zchunk < g.nz) ? zs + zchunk : g.nz;
-        if (UP && zl == zs && gz >= ((CEN && !z_fwd) ? 2 : 1) && zl >= 1) m = m + w.wz * qb[(long long)c_zu * g.s_z - g.s_dz];
-        if (DN && !z_fwd && zl == ze - 1 && gz <= g.nzg - (CEN ? 3 : 2) && zl + 1 < g.nz) m = m - w.wz * qb[(long long)c_zd * g.s_z + g.s_dz];
-    }
-    return m;
-}
-
 // uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: lets the compiler use the scalar-base form of
 // global_load / global_store (one VGPR of address for every stream of the site instead of a 64-bit VGPR pair each)
 __device__ __forceinline__ F4 ldu(const float* ubase, unsigned voff) {
@@ -345,11 +289,10 @@ constexpr int ALG_CP = 0, ALG_ADMM = 1, ALG_CPOP = 2;
 // [t0, t0 + M) of the volume (M = CP_TWN), reads x of the frame on either side of its window for the time differences
 // and leaves the adjoint terms that cross a window seam to the fix-up (exactly like the z-chunk edges)
 // T: float (4 columns per 16-byte lane) or double (2 columns, round 3): the same tile in lanes, half as wide in columns.
-template <int S, int M, bool XW, bool TWIN = false, typename T = float, int ALG = ALG_CP, bool LAZY = false>
+template <int S, int M, bool XW, bool TWIN = false, typename T = float, int ALG = ALG_CP>
 __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, FusedArgsT<T> a, int zchunk, int chunk0) {
     constexpr int V = 16 / (int)sizeof(T);
     using VT = Vec<T, V>;
-    static_assert(!LAZY || (ALG == ALG_CP && XW), "the lazy form exists for the Chambolle-Pock sweep with the in-block column hand-off");
     __shared__ double sm[16];
     const FusedCoord c = cp_coord<V>(g, zchunk, chunk0);
     const int t0 = TWIN ? (int)blockIdx.z * CP_TWN : 0;       // first frame of this block's window
@@ -366,24 +309,6 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
     const VT mf = g.ta ? mask_factor<T, V>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<T, V>(T(1));
     const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : (CEN ? T(0.5) : T(1));
     double acc_tv = 0.0, acc_fid = 0.0;
-    // LAZY: every value of x this block loads gets the terms the previous sweep left out of it (cp_pending_vec / _elem); bit 2 of
-    // full_store: x_in is complete (first iteration, or a fix-up ran): nothing is pending
-    const bool pend = LAZY && !(a.full_store & 4);
-    auto fixv = [&](VT& xv, int zl, int tg, int yy, bool valid) {
-        if constexpr (LAZY) {
-            if (pend && valid) {
-                const VT m = cp_pending_vec<S, XW, T, V>(g, w, a.q_in, zchunk, zl, tg, yy, c.col0);
-#pragma unroll
-                for (int i = 0; i < V; ++i) xv.v[i] = xv.v[i] - a.tau * (s * m.v[i]);
-            }
-        }
-    };
-    auto fixe = [&](T& e, int zl, int tg, int col, bool valid) {
-        if constexpr (LAZY) {
-            if (pend && valid) e = e - a.tau * (s * cp_pending_elem<S, XW, T, V>(g, w, a.q_in, zchunk, zl, tg, c.y, col));
-        }
-    };
-    const int ecol = (PREV && (c.lx == 0)) ? c.col0 - 1 : c.col0 + V;       // column of this lane's border element (e_le / e_re below)
     // x planes z (C) and z-1 (P) live in registers; the adjoint accumulators R (plane z-1 waiting
     // for its z+1 term) and the carried z-up terms U live in LDS, private per thread ([frame][thread]:
     // conflict-free 16-byte lanes, no barrier needed) -- 4 M vectors of state do not fit the VGPR file
@@ -447,9 +372,6 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
             C[t] = fok ? ldu_t<T, V>(pc + (long long)(t0 + t) * g.s_t, voff) : zero;
             P[t] = (fok && pp != nullptr) ? ldu_t<T, V>(pp + (long long)(t0 + t) * g.s_t, voff) : zero;
             if (EA) E[t] = (fok && (e_le || e_re)) ? ldu1_t<T>(pc + (long long)(t0 + t) * g.s_t, eoff) : T(0);
-            fixv(C[t], c.zs, t0 + t, c.y, fok);
-            fixv(P[t], c.zs - 1, t0 + t, c.y, fok && pp != nullptr);
-            if (EA) fixe(E[t], c.zs, t0 + t, ecol, fok && (e_le || e_re));
             lds_R[t][tid] = zero;
             lds_U[t][tid] = zero;
             if (XE) {
@@ -544,18 +466,13 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
         VT Nn[PFN ? M : 1];
         if (PFN) {
 #pragma unroll
-            for (int t = 0; t < M; ++t) {
-                Nn[t] = (load_next && t0 + t < Mg) ? ldu_t<T, V>(pn + (long long)(t0 + t) * g.s_t, voff) : zero;
-                fixv(Nn[t], z + 1, t0 + t, c.y, load_next && t0 + t < Mg);
-            }
+            for (int t = 0; t < M; ++t) Nn[t] = (load_next && t0 + t < Mg) ? ldu_t<T, V>(pn + (long long)(t0 + t) * g.s_t, voff) : zero;
         }
         T En[(PFN && EA) ? M : 1];      // the border elements of plane z+1 travel with its wide loads
         if (PFN && EA) {
 #pragma unroll
-            for (int t = 0; t < M; ++t) {
+            for (int t = 0; t < M; ++t)
                 En[t] = (load_next && (e_le || e_re) && t0 + t < Mg) ? ldu1_t<T>(pn + (long long)(t0 + t) * g.s_t, eoff) : T(0);
-                fixe(En[t], z + 1, t0 + t, ecol, load_next && (e_le || e_re) && t0 + t < Mg);
-            }
         }
         VT cold = zero;        // x(z, t-1)
         VT ut_prev = zero;     // wt * q'_tup(z, t-1) * mf, already valid-masked
@@ -567,18 +484,12 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
             const long long toff = (long long)tg * g.s_t;                         // uniform
             VT N;
             if constexpr (PFN) N = Nn[t];
-            else {
-                N = load_next ? ldu_t<T, V>(pn + toff, voff) : zero;
-                fixv(N, z + 1, tg, c.y, load_next);
-            }
+            else N = load_next ? ldu_t<T, V>(pn + toff, voff) : zero;
             T e_cur = T(0);
             if (EA) {
                 e_cur = E[t];
                 if constexpr (PFN) E[t] = En[t];
-                else {
-                    E[t] = (load_next && (e_le || e_re)) ? ldu1_t<T>(pn + toff, eoff) : T(0);
-                    fixe(E[t], z + 1, tg, ecol, load_next && (e_le || e_re));
-                }
+                else E[t] = (load_next && (e_le || e_re)) ? ldu1_t<T>(pn + toff, eoff) : T(0);
             }
             VT qcur[PFQ ? 4 : 1];
             if (PFQ) {
@@ -610,7 +521,6 @@ __global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, Fused
                 const bool want_dn = NEXT && (c.row == CP_TR - 1) && c.ok && (c.y + 1 < g.ny);
                 VT halo = zero;
                 if (want_up || want_dn) halo = ldu_t<T, V>(pc + toff, want_up ? voff - row_bytes : voff + row_bytes);
-                fixv(halo, z, tg, want_up ? c.y - 1 : c.y + 1, want_up || want_dn);
                 if (NEXT) {
                     n.h_nr = c.ok && (c.y + 1 < g.ny);
                     const VT sdn = cp_shfl_down<T, V>(C[t]);

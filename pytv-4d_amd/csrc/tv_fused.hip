@@ -159,13 +159,7 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
 int tv_cp_sweep(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q_out, const void* x0,
                 void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int32_t flags, int64_t chunk_begin,
                 int64_t chunk_count, double* tvout, double* fid, void* ws, void* stream) {
-    if (flags & ~(TV_CP_FID_OF_INPUT | TV_CP_LAZY | TV_CP_X_COMPLETE)) return fail(TV_E_ARG, "tv_cp_sweep: unknown flag");
-    if (flags & TV_CP_LAZY) {
-        if (q_in == q_out) return fail(TV_E_ARG, "TV_CP_LAZY reads the previous dual variable while it writes the new one: q_in and q_out must be different arrays");
-        if (g != nullptr && (g->nz != g->nz_global || g->m > 8 || g->time_weight_vol != nullptr))
-            return fail(TV_E_ARG, "TV_CP_LAZY: unsharded volumes of at most 8 frames without a weight volume");
-        if (env_int("TV_FUSED_XW", 1) == 0) return fail(TV_E_ARG, "TV_CP_LAZY needs the in-block column hand-off (TV_FUSED_XW=1)");
-    }
+    if (flags & ~TV_CP_FID_OF_INPUT) return fail(TV_E_ARG, "tv_cp_sweep: unknown flag");
     if (q_in == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!aligned16({q_in})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     return cp_sweep_impl(g, x_in, x_prev, x_next, q_in, q_out, x0, p, x_out, sigma_D, lambda, tau, sigma_A, flags, chunk_begin, chunk_count, tvout, fid, ws, stream);
@@ -195,8 +189,7 @@ static int cp_sweep_impl(const tv_geom* g, const void* x_in, const void* x_prev,
     auto sweep = [&]<typename T>() -> int {
         FusedArgsT<T> a{(const T*)x_in, (const T*)x_prev, (const T*)x_next, (T*)q, (const T*)x0, (T*)p,
                         (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)), w0, w1,
-                        ((flags & TV_CP_FID_OF_INPUT) ? 2 : 0) | ((flags & TV_CP_X_COMPLETE) ? 4 : 0), (const T*)(q_in ? q_in : q)};
-        if (flags & TV_CP_LAZY) return tvm::fused_sweep_lazy<T>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.force_win);
+                        (flags & TV_CP_FID_OF_INPUT) ? 2 : 0, (const T*)(q_in ? q_in : q)};
         return tvm::fused_sweep<T, ALG_CP>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
     };
     const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();

@@ -53,18 +53,6 @@ static int fused_sweep_launch(const tv_geom* g, const DG& d, const LC& lc, hipSt
     });
 }
 
-// the LAZY form of the Chambolle-Pock sweep (tv_fused.h, cp_pending_vec): its own instantiations, its own translation units
-template <typename T>
-static int fused_sweep_lazy_launch(const tv_geom* g, const DG& d, const LC& lc, hipStream_t st, const FusedArgsT<T>& a, int zc, int chunk0, bool force_win) {
-    if (d.m > CP_TWN) return fail(TV_E_ARG, "the lazy one-sweep form handles up to 8 frames");
-    return dispatch_fused(g->scheme, force_win ? 0 : d.m, [&]<int S, int M>() -> int {
-        if constexpr (M == 0) hipLaunchKernelGGL((k_cp_fused<S, CP_TWN, true, true, T, ALG_CP, true>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
-        else hipLaunchKernelGGL((k_cp_fused<S, M, true, false, T, ALG_CP, true>), lc.grid, lc.block, 0, st, d, make_w<T>(g), a, zc, chunk0);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    });
-}
-
 template <typename T, int ALG>
 static int fused_fixup_launch(const tv_geom* g, const DG& d, hipStream_t st, const FixupArgsT<T>& a, const FixPlan& p, double* w0) {
     if (ALG != ALG_CP && !p.xw) return fail(TV_E_ARG, "the ADMM / operator sweeps are built with TV_FUSED_XW=1 only");
@@ -94,17 +82,7 @@ namespace tvm {
 template <typename T, int ALG>
 int fused_sweep(const tv_geom* g, const DG& d, const LC& lc, hipStream_t st, const FusedArgsT<T>& a, int zc, int chunk0, bool xw, bool force_win);
 template <typename T, int ALG> int fused_fixup(const tv_geom* g, const DG& d, hipStream_t st, const FixupArgsT<T>& a, const FixPlan& p, double* w0);
-template <typename T> int fused_sweep_lazy(const tv_geom* g, const DG& d, const LC& lc, hipStream_t st, const FusedArgsT<T>& a, int zc, int chunk0, bool force_win);
 }  // namespace tvm
-
-#define TV_FUSED_INSTANTIATE_LAZY(T)                                                                                                       \
-    namespace tvm {                                                                                                                        \
-    template <>                                                                                                                            \
-    int fused_sweep_lazy<T>(const tv_geom* g, const DG& d, const LC& lc, hipStream_t st, const FusedArgsT<T>& a, int zc, int chunk0,      \
-                            bool force_win) {                                                                                              \
-        return fused_sweep_lazy_launch<T>(g, d, lc, st, a, zc, chunk0, force_win);                                                         \
-    }                                                                                                                                      \
-    }
 
 #define TV_FUSED_INSTANTIATE(T, ALG)                                                                                                       \
     namespace tvm {                                                                                                                        \

@@ -209,7 +209,7 @@ class ChambollePock(_SlabProblem):
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
                  factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch="auto",
-                 q_pingpong=False, tune_placement=None, lazy=None):
+                 q_pingpong=False, tune_placement=None):
         """fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
         iteration) whenever the geometry supports it, False = always the dual + primal kernel pair.
         pitch: see ``_SlabProblem`` ("auto", the default: padded rows where that pays; None / "dense"; (row_pitch, frame_pitch)).
@@ -218,11 +218,7 @@ class ChambollePock(_SlabProblem):
         it (tools/bwtest4, profiles/r4_bwtest4_q_pingpong.txt); the real sweep does not (tools/pp_probe.py: 33.3 against 33.4 ms in
         one pool, and one of the two directions can be 3 ms slower than the other when the arrays are separate allocations) --
         kept as an option of tv_cp_sweep, not used by default.
-        tune_placement: None = on for unsharded volumes of >= 4 GiB per image with memory to spare (see ``_tune_x_placement``).
-        lazy (one-sweep path, inside ``run`` / ``run_steps``): NO fix-up kernel between iterations -- the terms a sweep leaves out
-        of x are applied by the next sweep when it loads x (tv_cp_sweep, TV_CP_LAZY; bit-identical iterates), x is completed once at
-        the end of a block of iterations.  Needs the q ping-pong (a second q).  None = on for unsharded volumes of at most 8
-        frames without a weight volume, schemes hybrid / upwind / downwind, when the memory is there."""
+        tune_placement: None = on for unsharded volumes of >= 4 GiB per image with memory to spare (see ``_tune_x_placement``)."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
@@ -255,20 +251,8 @@ class ChambollePock(_SlabProblem):
                              "fp32, Nx % 4 == 0, Nx >= 64, Ny * Nx <= 2^30; any number of frames)")
         self.x_alt = self.new_image() if self.fused else None      # ping-pong partner of x
         self.q_alt = None
-        self.lazy = False
-        self._lazy_on = False            # inside a run_steps block of the lazy form
-        self._x_complete = True          # no adjoint terms are pending in x (they are between two lazy sweeps)
         if self.fused:
-            lazy_ok = (not self.slab.sharded) and self.x0.shape[1] <= 8 and self.geo.weight_vol is None \
-                and _nv.get_option("TV_FUSED_XW", 1) != 0
-            if lazy is None:
-                free, _total = torch.cuda.mem_get_info(self.device)
-                lazy = lazy_ok and scheme != "central" and free >= self.q.numel() * self.q.element_size() + (16 << 30) \
-                    and self.x0.numel() >= 1024 * _nv.get_option("TV_FUSED_MIN_KVOXELS", 16384)
-            if lazy and not lazy_ok:
-                raise ValueError("lazy=True: unsharded volumes of at most 8 frames without a weight volume")
-            self.lazy = bool(lazy)
-            if q_pingpong or self.lazy:
+            if q_pingpong:
                 self.q_alt = self.new_grad()
         self.overlap = bool(overlap) and sh and self.slab.nz >= 3 and not self.fused
         self.hist = None
@@ -327,24 +311,17 @@ class ChambollePock(_SlabProblem):
         hn = self.x[0:1] if self.plan.x_need_next else None
         info = {}
 
-        q_fwd = (self.q, self.q_alt)          # lazy form: the q ping-pong runs in step with the x ping-pong -- time it that way
-
-        def one(i_buf, o_buf, back=False):
+        def one(i_buf, o_buf):
             self.x, self.x_alt = i_buf, o_buf
-            if self.lazy:
-                self.q, self.q_alt = (q_fwd[1], q_fwd[0]) if back else q_fwd
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             self._sweep(0, -1, hp, hn, out[0:1], out[self.F:self.F + 1])
             b.record()
             return a, b
 
-        self._lazy_on, self._lag = self.lazy, (False if self.lazy else None)      # the kernel the iterations will run ...
-        self._x_complete = not self.lazy                                            # ... in its steady state (pending terms loaded)
-
         def round_trip(u, v):
             """ms of u -> v plus v -> u (best of ``reps``)"""
-            evs = [(one(u, v), one(v, u, True)) for _ in range(reps)]
+            evs = [(one(u, v), one(v, u)) for _ in range(reps)]
             torch.cuda.synchronize(self.device)
             return min(e[0][0].elapsed_time(e[0][1]) for e in evs) + min(e[1][0].elapsed_time(e[1][1]) for e in evs)
 
@@ -355,7 +332,7 @@ class ChambollePock(_SlabProblem):
         q_bytes = self.q.numel() * self.q.element_size()
         img_bytes = x_a.numel() * x_a.element_size()
         free, _total = torch.cuda.mem_get_info(self.device)
-        if self.q_alt is None and not self.lazy and free >= q_bytes + (n_extra + 1) * img_bytes + (8 << 30):
+        if self.q_alt is None and free >= q_bytes + (n_extra + 1) * img_bytes + (8 << 30):
             q1 = self.q
             t1 = round_trip(x_a, x_b)
             q2 = self.new_grad()
@@ -374,7 +351,7 @@ class ChambollePock(_SlabProblem):
             for i in range(n):
                 for j in range(n):
                     if i != j:
-                        ev[i][j].append(one(cands[i], cands[j], back=(i > j)))      # i < j: the first direction of the pair
+                        ev[i][j].append(one(cands[i], cands[j]))
         torch.cuda.synchronize(self.device)
         t = [[(min(a.elapsed_time(b) for a, b in ev[i][j]) if i != j else float("inf")) for j in range(n)] for i in range(n)]
         _, bi, bj = min(((t[i][j] + t[j][i], i, j) for i in range(n) for j in range(i + 1, n)))
@@ -396,9 +373,6 @@ class ChambollePock(_SlabProblem):
         info["p_chosen"] = kp
         del p_cands, rest
         self.x, self.x_alt = x_a, x_b
-        self._lazy_on, self._lag, self._x_complete = False, None, True
-        if self.lazy:
-            self.q, self.q_alt = q_fwd
         # back to the initial state: x = x0, p = q = 0 (the timed sweeps wrote into them)
         self.x.copy_(self.x0)
         self.p.zero_()
@@ -415,10 +389,8 @@ class ChambollePock(_SlabProblem):
         sites -- the fidelity of the iterate the PREVIOUS step produced -- into the previous step's slot, and the fix-up reads no x0."""
         g = self.geo
         flags = 0
-        if self._lazy_on:
-            flags |= 2 | (4 if self._x_complete else 0)  # TV_CP_LAZY [| TV_CP_X_COMPLETE]
         if self._lag is not None:
-            flags |= 1                                   # TV_CP_FID_OF_INPUT
+            flags = 1                                    # TV_CP_FID_OF_INPUT
             if self._lag is False:
                 fid_slot = self._lag_void                # first sweep of a block: nobody waits for its input's fidelity
             else:                                        # the same slot index, one row back
@@ -447,23 +419,6 @@ class ChambollePock(_SlabProblem):
         self._cur_out = out
         ev = self._events()
         mark = self._phase_marker()
-        if self._lazy_on:
-            # the lazy form: ONE kernel per iteration (unsharded: no halos); x stays incomplete until _flush()
-            mark("start")
-            if ev:
-                ev[0].record()
-            self._sweep(0, -1, None, None, out[0:1], out[F:F + 1])
-            mark("sweep")
-            if ev:
-                ev[1].record()
-                ev[2].record()
-            self.x, self.x_alt = self.x_alt, self.x
-            self.q, self.q_alt = self.q_alt, self.q
-            self._x_complete = False
-            self.it += 1
-            if self._lag is not None:
-                self._lag = out
-            return
         qhp = self.qh_prev[0] if self.qh_prev is not None else None
         qhn = self.qh_next[0] if self.qh_next is not None else None
         mark("start")
@@ -621,14 +576,6 @@ class ChambollePock(_SlabProblem):
         self.slab.allreduce_sum_(hist)
         return self.loss_from_slots(hist.cpu().numpy(), self.reg)
 
-    def _flush(self):
-        """Complete x after a block of lazy iterations: the terms the last sweep left out, added by the fix-up kernel (no x0)."""
-        if self._x_complete:
-            return
-        _nv.check(self.lib.tv_cp_fixup(self.geo.ref, _nv.ptr(self.q), None, None, _nv.ptr(self.x), None, self.tau, 0, -1,
-                                       self._lag_void.data_ptr(), _nv.ptr(self.ws), self.stream))
-        self._x_complete = True
-
     def run_steps(self, rows):
         """Enqueue ``len(rows)`` iterations, row k of the (n, SLOTS) fp64 device tensor ``rows`` receiving the scalars of iteration k.
         One-sweep path (round 4): the fidelity 1/2 |x_{k+1} - x0|^2 of row k is delivered by the sweep of iteration k+1 (it has
@@ -642,14 +589,11 @@ class ChambollePock(_SlabProblem):
                 self.step(rows[k])
             return
         self._lag = False                # first sweep of the block: its input's fidelity belongs to nobody
-        self._lazy_on = self.lazy
         try:
             for k in range(n):
                 self.step(rows[k])
         finally:
             self._lag = None
-            self._lazy_on = False
-        self._flush()
         # fidelity of the last iterate: |x - x0|^2 by the flat helper (x_alt is free between two steps: scratch output)
         _nv.check(self.lib.tv_axpby(self.geo.ref, 1.0, _nv.ptr(self.x), 0.0, None, _nv.ptr(self.x0), _nv.ptr(self.x_alt),
                                     self._lag_void.data_ptr(), _nv.ptr(self.ws), self.stream))

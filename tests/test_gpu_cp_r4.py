@@ -90,45 +90,3 @@ def test_placement_tuner_changes_nothing_but_the_buffers(scheme):
     la, lb = a.run(7), b.run(7)
     assert np.array_equal(la, lb)
     assert torch.equal(a.result(), b.result()) and torch.equal(a.q, b.q) and torch.equal(a.p, b.p)
-
-
-@pytest.mark.parametrize("scheme", SCHEMES)
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("shape", [(6, 3, 32, 64), (9, 8, 24, 256), (5, 2, 17, 128), (1, 1, 40, 320), (3, 1, 19, 576), (40, 4, 16, 64)])
-def test_lazy_sweep_equals_sweep_plus_fixup(scheme, dtype, shape, tvopt):
-    """tv_cp_sweep with TV_CP_LAZY: no fix-up kernel between iterations, the pending terms are applied by the next sweep on load.
-    Same terms, same order, same arithmetic: x, q, p bit-identical to the sweep + fix-up form after every block of iterations;
-    several z-chunks (TV_ZCHUNK = 3 / the default), several block tiles in x (576 columns), one plane, one frame."""
-    import torch
-    import pytv
-    rng = np.random.default_rng(9)
-    x0 = (orc.phantom(shape, dtype=np.float64) + 100 * rng.random(shape)).astype(dtype)
-    kw = dict(reg_z_over_reg=0.7, reg_time=1.3)
-    dev = torch.as_tensor(x0).cuda()
-    for zc in (0, 3):
-        tvopt("TV_ZCHUNK", zc)
-        a = pytv.solvers.ChambollePock(dev, 20.0, scheme=scheme, fused=True, lazy=False, **kw)
-        b = pytv.solvers.ChambollePock(dev, 20.0, scheme=scheme, fused=True, lazy=True, **kw)
-        assert b.lazy and b.q_alt is not None and not a.lazy
-        la = np.concatenate([a.run(1), a.run(4), a.run(3)])
-        lb = np.concatenate([b.run(1), b.run(4), b.run(3)])
-        assert torch.equal(a.result(), b.result()), (scheme, shape, zc)
-        assert torch.equal(a.q, b.q) and torch.equal(a.p, b.p)
-        np.testing.assert_allclose(lb, la, rtol=1e-12)
-    _, wloss = orc.chambolle_pock(x0.astype(np.float64), 8, 20.0, scheme=scheme, **kw)
-    np.testing.assert_allclose(lb, wloss, rtol=1e-5 if dtype == np.float32 else 1e-11)
-
-
-def test_lazy_sweep_on_pitched_ragged_state():
-    import torch
-    import pytv
-    rng = np.random.default_rng(10)
-    shape = (5, 3, 21, 131)
-    x0 = torch.as_tensor((orc.phantom(shape, dtype=np.float64) + 100 * rng.random(shape)).astype(np.float32)).cuda()
-    kw = dict(reg_z_over_reg=0.7, reg_time=1.3)
-    a = pytv.solvers.ChambollePock(x0, 20.0, scheme="hybrid", fused=True, lazy=False, **kw)
-    b = pytv.solvers.ChambollePock(x0, 20.0, scheme="hybrid", fused=True, lazy=True, **kw)
-    assert a.geo.pitched and b.geo.pitched and b.lazy
-    la, lb = a.run(6), b.run(6)
-    assert torch.equal(a.result(), b.result()) and torch.equal(a.q, b.q)
-    np.testing.assert_allclose(lb, la, rtol=1e-12)
