@@ -64,7 +64,13 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> shfl_down16_t(
     return r;
 }
 
-constexpr int DS_TWN = 8;      // frames per time window (M > 8)
+#ifndef TV_TWN
+#define TV_TWN 8                 // frames per time window of the streaming / one-sweep kernels.  EXPERIMENT -DTV_TWN=4 -DTV_WAVES=4: M = 8 volumes as two windows
+#endif                           // of 4 frames, half the per-thread state, 16 waves per CU (round 4, verdict item 6; profiles/r4_window4_ab.txt)
+#ifndef TV_WAVES
+#define TV_WAVES 0               // 0: the launch bounds below; 4: at least 4 waves per SIMD (<= 128 VGPRs) for every instantiation
+#endif
+constexpr int DS_TWN = TV_TWN;      // frames per time window (M > DS_TWN)
 
 // Block composition of the streaming kernels (k_D_stream, k_normal_stream*): ST_NWX waves side by side times ST_NWY waves
 // stacked, each a 4-row x 16-lane wave tile -> block tile 4 ST_NWY rows x 256 ST_NWX bytes.  Waves of one block request
@@ -91,7 +97,7 @@ constexpr int ST_BR = 4 * ST_NWY;        // rows per block tile
 // (tile, chunk, window) ids.  TWIN: the block works on frames [t0, t0 + M) of a volume with more than 8 frames and reads
 // the x frame on either side of its window for the time differences (M == DS_TWN).
 template <int S, int M, bool TWIN, typename T = float>
-__global__ __launch_bounds__(ST_THREADS, (S == CENTRAL || M >= 8) ? 2 : 3) void k_D_stream(DG g, WT<T> w, const T* __restrict__ x,
+__global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : ((S == CENTRAL || M >= 8) ? 2 : 3)) void k_D_stream(DG g, WT<T> w, const T* __restrict__ x,
                                                                        const T* __restrict__ xp, const T* __restrict__ xn,
                                                                        T* __restrict__ d, int zchunk, int nchunks) {
     constexpr int V = 16 / (int)sizeof(T);          // columns per lane (16-byte lanes): 4 floats / 2 doubles

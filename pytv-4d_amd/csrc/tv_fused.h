@@ -114,7 +114,13 @@ template <int V = 4> __device__ __forceinline__ FusedCoord cp_coord(const DG& g,
 // time windows (M > 8): the sweep works on windows of CP_TWN frames; the adjoint terms that cross a window seam
 // are the fix-up's.  Is frame t a seam frame with a missing time term?  (central: the neighbour's channel must be
 // defined, i.e. the neighbour frame must be an interior one)
-constexpr int CP_TWN = 8;
+#ifndef TV_TWN
+#define TV_TWN 8                 // (tv_dstream.h: the window-of-4 experiment)
+#endif
+#ifndef TV_WAVES
+#define TV_WAVES 0
+#endif
+constexpr int CP_TWN = TV_TWN;
 template <int S> __device__ __forceinline__ bool is_seam_frame(const DG& g, int t) {
     constexpr bool UP = (S != DOWNWIND), DN = (S != UPWIND), CEN = (S == CENTRAL);
     if (g.m <= CP_TWN || !g.ta) return false;
@@ -290,7 +296,7 @@ constexpr int ALG_CP = 0, ALG_ADMM = 1, ALG_CPOP = 2;
 // and leaves the adjoint terms that cross a window seam to the fix-up (exactly like the z-chunk edges)
 // T: float (4 columns per 16-byte lane) or double (2 columns, round 3): the same tile in lanes, half as wide in columns.
 template <int S, int M, bool XW, bool TWIN = false, typename T = float, int ALG = ALG_CP>
-__global__ __launch_bounds__(64 * CP_NW, 2) void k_cp_fused(DG g, WT<T> w, FusedArgsT<T> a, int zchunk, int chunk0) {
+__global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fused(DG g, WT<T> w, FusedArgsT<T> a, int zchunk, int chunk0) {
     constexpr int V = 16 / (int)sizeof(T);
     using VT = Vec<T, V>;
     __shared__ double sm[16];

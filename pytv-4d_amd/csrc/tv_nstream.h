@@ -97,7 +97,7 @@ __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long f
     NSTU<T, V>(a.out + fo, voff, o);
 }
 
-constexpr int NS_TWN = 8;
+constexpr int NS_TWN = TV_TWN;
 
 // The shared z term is added to one plane at one step and subtracted from its neighbour at the next, possibly by a different
 // block (chunk seam) or another rank (slab seam): these three operations must round the same way wherever they are compiled
@@ -131,7 +131,7 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> ns_sub(const V
 }
 
 template <int M, bool TWIN, typename T = float, bool CHEB = false>
-__global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
+__global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3)) void k_normal_stream(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
     constexpr int V = 16 / (int)sizeof(T);          // columns per 16-byte lane: 4 floats / 2 doubles (round 3)
     using VT = Vec<T, V>;
     __shared__ double sm[16];
@@ -294,7 +294,7 @@ template <typename T> __device__ __forceinline__ E2<T> ldu_e2(const T* ubase, un
 
 // T: float (4 columns per 16-byte lane) or -- round 4 -- double (2 columns: the +-2 column neighbours are then whole neighbour lanes)
 template <int M, bool TWIN, bool CHEB = false, typename T = float>
-__global__ __launch_bounds__(ST_THREADS, M >= 6 ? 2 : 3) void k_normal_stream_cen(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
+__global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3)) void k_normal_stream_cen(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
     constexpr int V = 16 / (int)sizeof(T);
     using VT = Vec<T, V>;
     __shared__ double sm[16];
