@@ -137,7 +137,7 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
     __shared__ double sm[16];
     const int lane = (int)threadIdx.x, wave = (int)threadIdx.y;
     const int row = lane >> 4, lx = lane & 15;
-    const int nxv = g.nx / V;
+    const int nxv = (g.nx + V - 1) / V;
     const int tiles_x = (nxv + ST_BCV - 1) / ST_BCV, tiles_y = (g.ny + ST_BR - 1) / ST_BR;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + NS_TWN - 1) / NS_TWN : 1;
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
         // existence of the in-plane neighbours as multipliers (no branches around vectors in the frame loop)
         const T m_pr = (ok && y > 0) ? T(1) : T(0), m_nr = (ok && y + 1 < g.ny) ? T(1) : T(0);
         const T m_c0 = (ok && col0 > 0) ? T(1) : T(0), m_c3 = (ok && col0 + V < g.nx) ? T(1) : T(0);
+        // ragged PITCHED rows (round 4): the last lane of a row holds pad columns; the difference across the frame's last column (and
+        // those between pads) must not count.  me[i] = 1 iff columns col0 + i - 1 and col0 + i both exist (i >= 1)
+        T me[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) me[i] = (ok && col0 + i < g.nx) ? T(1) : T(0);
         const bool want_up = (row == 0) && ok && (y > 0), want_dn = (row == 3) && ok && (y + 1 < g.ny);
         const unsigned hoff = want_up ? voff - row_bytes : voff + row_bytes;
         // a tile row needs BOTH halo rows when the wave tile is a single row high at the frame border: rows 0 and 3 differ,
@@ -224,10 +229,10 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                         const T from_l = dpp_from_left(c.v[V - 1]), from_r = dpp_from_right(c.v[0]);
                         const T left = (lx == 0) ? E[t] : from_l;
                         const T right = (lx == 15) ? E[t] : from_r;
-                        // interior elements of the vector always have both column neighbours inside the frame (nx % V == 0)
+                        // interior elements of the vector have both column neighbours inside the frame unless the row is ragged (me[])
                         T e[V];         // e[i] = c[i] - c[i-1] (e[0]: against the left neighbour), one more for the right neighbour
 #pragma unroll
-                        for (int i = 1; i < V; ++i) e[i] = c.v[i] - c.v[i - 1];
+                        for (int i = 1; i < V; ++i) e[i] = me[i] * (c.v[i] - c.v[i - 1]);
                         r.v[0] += m_c0 * (c.v[0] - left) - e[1];
 #pragma unroll
                         for (int i = 1; i + 1 < V; ++i) r.v[i] += e[i] - e[i + 1];
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
         T m_cb[V], m_cf[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            m_cb[i] = (ok && col0 + i >= 2) ? T(1) : T(0);
+            m_cb[i] = (ok && col0 + i >= 2 && col0 + i < g.nx) ? T(1) : T(0);      // (col < nx: pad columns of a ragged pitched row stay zero)
             m_cf[i] = (ok && col0 + i + 2 < g.nx) ? T(1) : T(0);
         }
         const bool want_up = (row <= 1) && ok && (y >= 2), want_dn = (row >= 2) && ok && (y + 2 < g.ny);

@@ -9,9 +9,9 @@
 namespace tvm {
 
 bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
-    // pitched arrays: rows of whole 16-byte lanes only (the column stencil inside a lane assumes every element has both neighbours;
-    // ragged rows take the one-site kernels)
-    if (!vec || d.nx < 64 || d.wv != nullptr || d.nx % ((g->dtype == TV_F32) ? 4 : 2) != 0) return false;
+    // pitched arrays incl. ragged rows (the radius-1 kernel masks the differences that touch pad columns; the central one has
+    // per-element masks anyway); `vec` says the rows start on 16-byte boundaries
+    if (!vec || d.nx < 64 || d.wv != nullptr) return false;
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return false;   // two-point axes: forward stencil
     const long long eb = (g->dtype == TV_F32) ? 4 : 8;
     if (d.s_t * eb > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
@@ -23,7 +23,7 @@ bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
 int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, const void* b, void* out, void* out2,
              double rho, hipStream_t st, long long* nblocks, double* part0, double* part1, const NCheb* cheb) {
     const int V = (g->dtype == TV_F32) ? 4 : 2;
-    const long long tx = (d.nx / V + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
+    const long long tx = ((d.nx + V - 1) / V + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
         const long long want = (4096 + tx * ty - 1) / (tx * ty);

@@ -91,9 +91,11 @@ def test_kernel_pair_cp_pitched(pytv, scheme, dtype, shape, pitch):
 @pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("variant", ["fused-cg", "fused-cheb", "trio", "textbook"])
-def test_admm_pitched(pytv, scheme, dtype, variant):
+@pytest.mark.parametrize("shape,pitch", [((6, 3, 16, 64), (72, 16 * 72 + 20)), ((5, 3, 12, 71), (72, 12 * 72 + 8))])
+def test_admm_pitched(pytv, scheme, dtype, variant, shape, pitch):
+    """ADMM on padded state; 71 columns on a 72-element pitch: ragged rows on 16-byte lanes in the one-sweep kernels AND in the streaming
+    normal operator / Chebyshev step (round 4: the column differences that touch pad columns are masked)"""
     import torch
-    shape, pitch = (6, 3, 16, 64), (72, 16 * 72 + 20)
     x0 = _x(shape, dtype, 2)
     kw = dict(reg_z_over_reg=0.7, reg_time=1.3)
     okw = dict(single_reduction=(variant != "textbook"), x_solver="chebyshev" if variant == "fused-cheb" else "cg")
