@@ -275,7 +275,18 @@ class ChambollePock(_SlabProblem):
                 free, _total = torch.cuda.mem_get_info(self.device)
                 tune_placement = (not self.slab.sharded) and img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
             if tune_placement:
-                self._tune_x_placement()
+                keep = (self.x, self.x_alt, self.p, self.q)
+                try:
+                    self._tune_x_placement()
+                except RuntimeError as exc:       # out of memory while holding the candidates, ...: the tuner is an optimisation, never a failure
+                    self.x, self.x_alt, self.p, self.q = keep
+                    self._lag = None
+                    self.x.copy_(self.x0)
+                    self.p.zero_()
+                    self.q.zero_()
+                    torch.cuda.empty_cache()
+                    self.placement = {"error": str(exc)[:200]}
+                del keep
 
     # ---- one phase on local planes [a, b) -----------------------------------------------------
     def _dual(self, a, b, xp, xn, out):
