@@ -382,7 +382,20 @@ class ChambollePock(_SlabProblem):
         self.p = p_cands[kp]
         info["p_round_trip_ms"] = [round(v, 3) for v in tp]
         info["p_chosen"] = kp
+        # ---- x0 (read once per sweep): the caller's array against a copy in one of the buffers that are left ------------------------
+        spare = [c for k, c in enumerate(p_cands) if k != kp]
         del p_cands, rest
+        if spare:
+            x0_orig, x0_copy = self.x0, spare[0]
+            x0_copy.copy_(x0_orig)
+            t0_ = round_trip(x_a, x_b)
+            self.x0 = x0_copy
+            t1_ = round_trip(x_a, x_b)
+            info["x0_round_trip_ms"] = [round(t0_, 3), round(t1_, 3)]
+            if t0_ <= t1_:
+                self.x0 = x0_orig
+            del x0_orig, x0_copy
+        del spare
         self.x, self.x_alt = x_a, x_b
         # back to the initial state: x = x0, p = q = 0 (the timed sweeps wrote into them)
         self.x.copy_(self.x0)
