@@ -1,6 +1,9 @@
 #!/bin/bash
-# A/B on one box: (1) config1 / config2 / north star, round-3 tree against the current tree, interleaved; (2) window-of-4 + 16 waves per CU
-# variant (libpytv4d_hip_twn4.so) against the default library with tools/op_bench.py
+# A/B on one box: (1) config1 / config2, round-3 tree against the current tree, interleaved; (2) window-of-4 + 16 waves per CU
+# variant (libpytv4d_hip_twn4.so) against the default library with tools/op_bench.py.
+# Prerequisites (authoring container, before gpurun):
+#   git worktree add r3tree 93a5ad8 && (cd r3tree && python pytv-4d_amd/build.py)
+#   TV_VARIANT=twn4 TV_EXTRA_FLAGS="-DTV_TWN=4 -DTV_WAVES=4" python pytv-4d_amd/build.py
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R" || exit 1
 O=$R/gpurun_out/r4call11
