@@ -112,6 +112,12 @@ constexpr int SG2_TWN = 8, SG2_TWU = SG2_TWN - 2;      // time windows for M > 8
 #ifndef TV_SG2_COPYONLY
 #define TV_SG2_COPYONLY 0      // 1: EXPERIMENT -- store x instead of G and drop the arithmetic: what the memory pattern alone costs
 #endif
+#ifndef TV_SG2_STALIGN
+#define TV_SG2_STALIGN 0       // 1: EXPERIMENT -- stores at line-aligned positions (results wrong): the price of partial-line stores
+#endif
+#ifndef TV_SG2_LDALIGN
+#define TV_SG2_LDALIGN 0       // 1: EXPERIMENT -- loads at line-aligned positions (results wrong)
+#endif
 #ifndef TV_SG2_WIDE
 #define TV_SG2_WIDE 0          // 1: EXPERIMENT (with COPYONLY) -- the waves of a block side by side: 4 rows x 256 columns, no ring
 #endif
@@ -202,6 +208,18 @@ struct SgCol {
             const unsigned off = (unsigned)(((long long)y * g.rp + cx) * (long long)sizeof(T));
             roff[i] = in ? off : SG2_OOB;
             soff[i] = own ? off : SG2_OOB;
+#if TV_SG2_STALIGN        // EXPERIMENT (wrong results): every lane stores, at 64-column-aligned positions -- what whole-line stores would be worth
+            {
+                const int ca = tile_x * 64 + lane;
+                soff[i] = (y >= 0 && y < g.ny && ca < g.rp) ? (unsigned)(((long long)y * g.rp + ca) * (long long)sizeof(T)) : SG2_OOB;
+            }
+#endif
+#if TV_SG2_LDALIGN        // EXPERIMENT (wrong results): the loads at 64-column-aligned positions
+            {
+                const int ca = tile_x * 64 + lane;
+                roff[i] = (y >= 0 && y < g.ny && ca < g.rp) ? (unsigned)(((long long)y * g.rp + ca) * (long long)sizeof(T)) : SG2_OOB;
+            }
+#endif
             cm.v[i] = own ? T(1) : T(0);
             // border multipliers of the generic variant: mi: site exists; mfr / mbr: it has a next / previous row; mfc / mbc:
             // a next / previous column (central: both, for a difference to exist)
