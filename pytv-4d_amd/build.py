@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip", "tv_fused.hip", "tv_fused_f64.hip", "tv_fused_admm.hip", "tv_fused_admm_f64.hip", "tv_fused_cpop.hip", "tv_fused_cpop_f64.hip", "tv_subgrad.hip", "tv_subgrad_norms.hip", "tv_sgstep.hip", "tv_dstream.hip", "tv_comm.hip", "tv_nstream.hip"]
-HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h", "tv_fused.h", "tv_fused_launch.h", "tv_subgrad.h", "tv_subgrad2.h", "tv_subgrad_host.h", "tv_dstream.h", "tv_nstream.h"]
+UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip", "tv_fused.hip", "tv_fused_f64.hip", "tv_fused_admm.hip", "tv_fused_admm_f64.hip", "tv_fused_cpop.hip", "tv_fused_cpop_f64.hip", "tv_subgrad.hip", "tv_subgrad_norms.hip", "tv_sgstep.hip", "tv_subgrad3.hip", "tv_subgrad3_norms.hip", "tv_sgstep3.hip", "tv_dstream.hip", "tv_comm.hip", "tv_nstream.hip"]
+HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h", "tv_fused.h", "tv_fused_launch.h", "tv_subgrad.h", "tv_subgrad2.h", "tv_subgrad3.h", "tv_subgrad_host.h", "tv_subgrad3_host.h", "tv_dstream.h", "tv_nstream.h"]
 DEPS = [os.path.join(CSRC, f) for f in UNITS + HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "pytv4d.h")]
 # TV_VARIANT=<name> (with TV_EXTRA_FLAGS): an experimental build next to the product library, loaded with PYTV4D_LIB=<path>
 _VAR = os.environ.get("TV_VARIANT", "")

@@ -133,6 +133,24 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
     return 0;
 }
 
+// ---- round-4 EXPERIMENT (tv_subgrad3.h): a lane = 2 rows x 2 columns, a wave owns 496-byte row segments --------------------
+// fp32, even Nx / pitches (a lane's two columns are inside the frame or outside together), 8-byte aligned arrays.  One translation
+// unit per MODE (tv_subgrad3.hip, tv_subgrad3_norms.hip, tv_sgstep3.hip).  OPT-IN with TV_SG_KERNEL=3: parity-green (tests/
+// test_gpu_subgrad_pair.py) and measured no faster than the round-3 kernel (profiles/r4_sgpattern.txt), which stays the default.
+int sg3_launch_g(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
+                 double* fidout, void* ws, hipStream_t st, const SgHostArgs& so);
+int sg3_launch_norms(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
+                     double* fidout, void* ws, hipStream_t st, const SgHostArgs& so);
+int sg3_launch_step(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
+                    double* fidout, void* ws, hipStream_t st, const SgHostArgs& so);
+inline bool sg3_ok(const tv_geom* g, const DG& d, std::initializer_list<const void*> ptrs) {
+    if (g->dtype != TV_F32 || env_int("TV_SG_KERNEL", 2) != 3) return false;
+    if (d.nx % 2 != 0 || d.rp % 2 != 0 || d.s_t % 2 != 0 || d.s_z % 2 != 0 || d.s_t * 4 >= (1ll << 31)) return false;
+    for (const void* p : ptrs)
+        if (p != nullptr && ((uintptr_t)p & 7) != 0) return false;
+    return true;
+}
+
 // common argument checks + launch geometry; MODE 1 passes the step arguments, MODE 0 an empty struct
 template <int MODE>
 inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout, double* fidout,
@@ -151,6 +169,11 @@ inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const 
     if (g->dtype == TV_F64) {
         if (!step_ok) return fail(TV_E_ARG, "the fp64 one-pass descent step needs step * lambda >= 1e-6: use tv_subgrad + tv_subgrad_step");
         return sg2_launch<double, MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
+    }
+    if (step_ok && sg3_ok(g, d, {x, x_prev, x_next, G, ha.x0, ha.x_out, ha.norms, d.wv, d.wvp, d.wvn})) {
+        if constexpr (MODE == 0) return sg3_launch_g(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
+        else if constexpr (MODE == 1) return sg3_launch_step(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
+        else return sg3_launch_norms(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
     }
     if (env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * 4 < (1ll << 31) && step_ok)
         return sg2_launch<float, MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
