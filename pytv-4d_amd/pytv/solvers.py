@@ -789,7 +789,8 @@ class SubgradientDescent(_SlabProblem):
         return h[:, 3:6].sum(axis=1) + regularization * h[:, 0:3].sum(axis=1)
 
     def __init__(self, x0, regularization, step_size, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True, pitch="auto"):
+                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True, pitch="auto", tune_placement=None):
+        """tune_placement: None = on for unsharded one-pass problems of >= 4 GiB per image with memory to spare (``_tune_placement``)."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.step_size = float(regularization), float(step_size)
         self.x = self.image_copy(self.x0)
@@ -821,6 +822,88 @@ class SubgradientDescent(_SlabProblem):
         # the exchange is in flight): planes [2, nz - 2) need no halo and hide the two-plane exchange
         self.overlap = bool(overlap) and sh and self.one_pass and nz >= 5
         self._scratch = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
+        self.placement = None
+        if self.one_pass:
+            img_bytes = self.x.numel() * self.x.element_size()
+            if tune_placement is None:
+                free, _total = torch.cuda.mem_get_info(self.device)
+                tune_placement = (not self.slab.sharded) and img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
+            if tune_placement:
+                keep = (self.x, self.x_alt, self.x0)
+                try:
+                    self._tune_placement()
+                except RuntimeError as exc:       # an optimisation, never a failure (out of memory while holding the candidates, ...)
+                    self.x, self.x_alt, self.x0 = keep
+                    self.x.copy_(self.x0)
+                    torch.cuda.empty_cache()
+                    self.placement = {"error": str(exc)[:200]}
+                del keep
+
+    def _tune_placement(self, n_extra=2, reps=2):
+        """Pick where the two image buffers of the x ping-pong (and x0) live by MEASUREMENT, as ``ChambollePock._tune_x_placement``
+        does and for the same reason (the time of a streaming kernel depends on where its arrays landed
+        in physical memory, per allocation and per direction of the ping-pong; the descent loop on the north-star volume runs at
+        128 - 149 it/s from process to process with the same binary).  Every ordered pair of 2 + ``n_extra`` candidates is timed with
+        the real kernel; then the caller's x0 against a copy in a buffer that is left.  ~30 steps once per solver; the iterate is
+        re-initialised afterwards, results do not depend on it."""
+        import time as _time
+        t_begin = _time.perf_counter()
+        nz = self.slab.nz
+        out = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
+        hp = self.xh_prev if self.xh_prev is not None else None
+        hn = self.xh_next if self.xh_next is not None else None
+
+        def one(i_buf, o_buf):
+            self.x, self.x_alt = i_buf, o_buf
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._one_pass_range(0, nz, hp, hn, out[0:1], out[3:4])
+            b.record()
+            return a, b
+
+        def round_trip(u, v):
+            evs = [(one(u, v), one(v, u)) for _ in range(reps)]
+            torch.cuda.synchronize(self.device)
+            return min(e[0][0].elapsed_time(e[0][1]) for e in evs) + min(e[1][0].elapsed_time(e[1][1]) for e in evs)
+
+        x_a, x_b = self.x, self.x_alt
+        for _ in range(2):                                                   # warm-up (code load, clocks)
+            one(x_a, x_b)
+        cands = [x_a, x_b] + [self.new_image() for _ in range(n_extra)]
+        for c in cands[1:]:
+            c.copy_(self.x0)                                                 # every candidate holds data of the problem's kind (no denormals, no NaN)
+        n = len(cands)
+        ev = [[[] for _ in range(n)] for _ in range(n)]
+        for r in range(reps):
+            for i in range(n):
+                for j in range(n):
+                    if i != j:
+                        ev[i][j].append(one(cands[i], cands[j]))
+        torch.cuda.synchronize(self.device)
+        t = [[(min(a.elapsed_time(b) for a, b in ev[i][j]) if i != j else float("inf")) for j in range(n)] for i in range(n)]
+        _, bi, bj = min(((t[i][j] + t[j][i], i, j) for i in range(n) for j in range(i + 1, n)))
+        info = {"candidates": n, "step_ms": [[None if i == j else round(t[i][j], 3) for j in range(n)] for i in range(n)],
+                "chosen": [bi, bj], "chosen_ms": [round(t[bi][bj], 3), round(t[bj][bi], 3)], "first_pair_ms": [round(t[0][1], 3), round(t[1][0], 3)]}
+        x_a, x_b = cands[bi], cands[bj]
+        spare = [c for k, c in enumerate(cands) if k not in (bi, bj)]
+        del cands
+        if spare:                                                            # x0 (read once per step): the caller's array against a copy
+            x0_orig, x0_copy = self.x0, spare[0]
+            x0_copy.copy_(x0_orig)
+            t0_ = round_trip(x_a, x_b)
+            self.x0 = x0_copy
+            t1_ = round_trip(x_a, x_b)
+            info["x0_round_trip_ms"] = [round(t0_, 3), round(t1_, 3)]
+            if t0_ <= t1_:
+                self.x0 = x0_orig
+            del x0_orig, x0_copy
+        del spare
+        self.x, self.x_alt = x_a, x_b
+        self.x.copy_(self.x0)
+        torch.cuda.synchronize(self.device)
+        torch.cuda.empty_cache()
+        info["seconds"] = round(_time.perf_counter() - t_begin, 3)
+        self.placement = info
 
     def _one_pass_range(self, a, b, hp, hn, tv_slot, fid_slot):
         g, x = self.geom(a, b), self.x

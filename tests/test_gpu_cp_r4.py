@@ -90,3 +90,24 @@ def test_placement_tuner_changes_nothing_but_the_buffers(scheme):
     la, lb = a.run(7), b.run(7)
     assert np.array_equal(la, lb)
     assert torch.equal(a.result(), b.result()) and torch.equal(a.q, b.q) and torch.equal(a.p, b.p)
+
+
+@pytest.mark.parametrize("scheme", ["hybrid", "central"])
+@pytest.mark.parametrize("pitch", ["auto", "dense"])
+def test_subgradient_descent_placement_tuner_changes_nothing_but_the_buffers(scheme, pitch):
+    """SubgradientDescent(tune_placement=True) times the ordered pairs of four candidate image buffers (and x0 against a copy) with the
+    real one-pass step kernel and keeps the fastest; the iterate is re-initialised afterwards -- bit-identical to an untuned run."""
+    import torch
+    import pytv
+    rng = np.random.default_rng(8)
+    shape = (5, 3, 33, 250)                          # 1000-byte rows: pitch="auto" pads them
+    x0 = torch.as_tensor((orc.phantom(shape, dtype=np.float64) + 100 * rng.random(shape)).astype(np.float32)).cuda()
+    kw = dict(reg_z_over_reg=0.7, reg_time=1.3, scheme=scheme, pitch=pitch)
+    a = pytv.solvers.SubgradientDescent(x0, 20.0, 5e-3, tune_placement=False, **kw)
+    b = pytv.solvers.SubgradientDescent(x0, 20.0, 5e-3, tune_placement=True, **kw)
+    assert a.one_pass and a.placement is None and b.placement is not None and "error" not in b.placement
+    info = b.placement
+    assert info["candidates"] == 4 and len(info["step_ms"]) == 4 and info["seconds"] > 0 and len(info["x0_round_trip_ms"]) == 2
+    la, lb = a.run(9, graph=False), b.run(9, graph=False)
+    assert np.array_equal(la, lb)
+    assert torch.equal(a.result(), b.result())
