@@ -61,7 +61,13 @@ template <typename T, int MODE>
 inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
                       double* fidout, void* ws, hipStream_t st, const SgHostArgs& so) {
     constexpr bool F64 = sizeof(T) == 8;
-    constexpr int R = F64 ? 2 : 4, NW = 4;
+#ifndef TV_SG2_R32
+#define TV_SG2_R32 4           // fp32: rows per lane.  EXPERIMENT -DTV_SG2_R32=2 -DTV_SG2_NW32=8 -DTV_SG2_XLD32=1: 16 waves of 2-row strips per block (4 waves per SIMD)
+#endif
+#ifndef TV_SG2_NW32
+#define TV_SG2_NW32 4
+#endif
+    constexpr int R = F64 ? 2 : TV_SG2_R32, NW = F64 ? 4 : TV_SG2_NW32;
 #ifndef TV_SG2_NWX
 #define TV_SG2_NWX 2
 #endif
