@@ -218,7 +218,7 @@ class ChambollePock(_SlabProblem):
         it (tools/bwtest4, profiles/r4_bwtest4_q_pingpong.txt); the real sweep does not (tools/pp_probe.py: 33.3 against 33.4 ms in
         one pool, and one of the two directions can be 3 ms slower than the other when the arrays are separate allocations) --
         kept as an option of tv_cp_sweep, not used by default.
-        tune_placement: None = on for unsharded volumes of >= 4 GiB per image with memory to spare (see ``_tune_x_placement``)."""
+        tune_placement: None = on for volumes (slabs) of >= 4 GiB per image with memory to spare (see ``_tune_x_placement``)."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
@@ -273,7 +273,9 @@ class ChambollePock(_SlabProblem):
             img_bytes = self.x.numel() * self.x.element_size()
             if tune_placement is None:
                 free, _total = torch.cuda.mem_get_info(self.device)
-                tune_placement = (not self.slab.sharded) and img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
+                # (sharded slabs too: the tuner launches local kernels only, no rank waits for another; every rank of a weak-scaling run
+                # holds a slab of the single-GPU size and plays the same placement lottery)
+                tune_placement = img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
             if tune_placement:
                 keep = (self.x, self.x_alt, self.p, self.q)
                 try:

@@ -51,7 +51,9 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
         out["cp_x"] = cp.result().cpu().numpy()
         out["cp_overlap"] = cp.overlap
         # ... and the library's default (the one-sweep kernel where the geometry supports it)
-        cp2 = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, slab=slab, **kw)
+        # (the placement tuner forced on: on a slab it launches local sweeps only -- every rank of a weak-scaling run tunes, round 4)
+        cp2 = pytv.solvers.ChambollePock(x0, 7.0, scheme=scheme, slab=slab, tune_placement=True, **kw)
+        out["cp2_tuned"] = cp2.placement is not None and "error" not in cp2.placement
         out["cp2_loss"] = cp2.run(8)
         out["cp2_x"] = cp2.result().cpu().numpy()
         out["cp2_fused"] = cp2.fused
@@ -104,6 +106,7 @@ def test_sharded_solvers_equal_unsharded_oracle(scheme, world, shape, overlap, z
         np.testing.assert_allclose(ret[r]["cp2_x"], wx[z0:z0 + nz], rtol=1e-5, atol=2e-3, err_msg="rank %d (default path)" % r)
     if shape[-1] % 4 == 0 and shape[-1] >= 64:
         assert all(ret[r]["cp2_fused"] for r in range(world))
+        assert all(ret[r]["cp2_tuned"] for r in range(world))
         if overlap and zchunk in ("1", "2"):
             assert all(ret[r]["cp2_overlap"] for r in range(world))     # interior-first one-sweep path exercised
     if overlap:
