@@ -797,7 +797,7 @@ class SubgradientDescent(_SlabProblem):
 
     def __init__(self, x0, regularization, step_size, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
                  mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True, pitch="auto", tune_placement=None):
-        """tune_placement: None = on for unsharded one-pass problems of >= 4 GiB per image with memory to spare (``_tune_placement``)."""
+        """tune_placement: None = on for one-pass problems (slabs) of >= 4 GiB per image with memory to spare (``_tune_placement``)."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.step_size = float(regularization), float(step_size)
         self.x = self.image_copy(self.x0)
@@ -834,7 +834,7 @@ class SubgradientDescent(_SlabProblem):
             img_bytes = self.x.numel() * self.x.element_size()
             if tune_placement is None:
                 free, _total = torch.cuda.mem_get_info(self.device)
-                tune_placement = (not self.slab.sharded) and img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
+                tune_placement = img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)      # slabs too: local launches only
             if tune_placement:
                 keep = (self.x, self.x_alt, self.x0)
                 try:

@@ -59,7 +59,7 @@ def _worker(rank, world, port, shape, scheme, kw, overlap, ret):
         out["cp2_fused"] = cp2.fused
         out["cp2_overlap"] = bool(getattr(cp2, "overlap_fused", False))
         if min(n for _, n in slab.parts) >= 2:
-            sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, slab=slab, **kw)
+            sg = pytv.solvers.SubgradientDescent(x0, 7.0, 2e-3, scheme=scheme, slab=slab, tune_placement=True, **kw)
             out["sg_loss"] = sg.run(5)
             out["sg_x"] = sg.result().cpu().numpy()
             ad = pytv.solvers.ADMM(x0, 7.0, 0.1, n_cg=3, scheme=scheme, slab=slab, x_solver="cg", **kw)
