@@ -1009,7 +1009,8 @@ class ADMM(_SlabProblem):
 
     def __init__(self, x0, regularization, rho, n_cg=10, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
                  mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=True, x_solver=None,
-                 pitch="auto"):
+                 pitch="auto", tune_placement=None):
+        """tune_placement: None = on for unsharded problems whose state is >= 16 GiB with room for a second copy (``_tune_placement``)."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.rho, self.n_cg = float(regularization), float(rho), int(n_cg)
         self.single = bool(single_reduction)
@@ -1069,6 +1070,77 @@ class ADMM(_SlabProblem):
         self.dots3 = torch.zeros((3, 2), dtype=torch.float64, device=self.device)
         self.dots = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.rr = torch.zeros(2, dtype=torch.float64, device=self.device)     # <r, r> of the sweep / of the fix-up
+        self.placement = None
+        set_bytes = sum(getattr(self, k).numel() for k in self._STATE) * self.x.element_size()
+        if tune_placement is None:
+            free, _total = torch.cuda.mem_get_info(self.device) if self.device.type == "cuda" else (0, 0)
+            tune_placement = (not self.slab.sharded) and set_bytes >= (16 << 30) and free >= set_bytes + (8 << 30)
+        if tune_placement:
+            self._tune_placement()
+
+    _STATE = ("x", "_zt", "u", "b", "r", "d", "Ad")      # the arrays an outer iteration streams through
+
+    def _reset_state(self):
+        """Back to the state of a fresh solver (x = x0, everything else zero) in the arrays that are bound now."""
+        self.x.copy_(self.x0)
+        for k in self._STATE[1:]:
+            getattr(self, k).zero_()
+        for t in (self.sc, self.dots3, self.dots, self.rr):
+            t.zero_()
+        self._have_r = False
+
+    def _tune_placement(self, n_sets=4, n_steps=2):
+        """Pick WHERE the state lives by measurement, as ``ChambollePock._tune_x_placement`` does: the same
+        outer iteration on the same data takes 17.5 or 19.5 ms on the configs[4] slab depending on where u, t and the image buffers
+        landed (tools/admm_placement_probe.py).  ``n_sets`` complete sets of state arrays are allocated one after the other (never
+        more than two alive), ``n_steps`` outer iterations are timed on each after one to warm up, the fastest set is kept and put
+        back into the initial state.  Unsharded problems only (an outer iteration of a slab waits for its neighbours)."""
+        import time as _time
+        t_begin = _time.perf_counter()
+        out = torch.zeros((n_steps + 1, 2), dtype=torch.float64, device=self.device)
+
+        def timed():
+            self._reset_state()
+            self.step(out[0])
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for k in range(n_steps):
+                self.step(out[1 + k])
+            b.record()
+            torch.cuda.synchronize(self.device)
+            return a.elapsed_time(b) / n_steps
+
+        def bound():                                 # the buffer roles rotate inside a step: take what is bound NOW
+            return {k: getattr(self, k) for k in self._STATE}
+
+        best_t = timed()
+        best = bound()
+        times = [round(best_t, 3)]
+        info = {}
+        try:
+            for _ in range(n_sets - 1):
+                cand = dict(x=self.new_image(), _zt=self.new_grad(), u=self.new_grad(), b=self.new_image(), r=self.new_image(),
+                            d=self.new_image(), Ad=self.new_image())
+                for k, v in cand.items():
+                    setattr(self, k, v)
+                t = timed()
+                times.append(round(t, 3))
+                cand = bound()
+                if t < best_t:
+                    best_t, best = t, cand
+                del cand
+                for k, v in best.items():            # the loser loses its last reference here
+                    setattr(self, k, v)
+                torch.cuda.empty_cache()
+        except RuntimeError as exc:                  # out of memory while a second set was alive, ...: an optimisation, never a failure
+            for k, v in best.items():
+                setattr(self, k, v)
+            torch.cuda.empty_cache()
+            info["error"] = str(exc)[:200]
+        self._reset_state()
+        torch.cuda.synchronize(self.device)
+        info.update({"outer_ms": times, "chosen": times.index(min(times)), "seconds": round(_time.perf_counter() - t_begin, 3)})
+        self.placement = info
 
     @property
     def z(self):

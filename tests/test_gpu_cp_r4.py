@@ -111,3 +111,23 @@ def test_subgradient_descent_placement_tuner_changes_nothing_but_the_buffers(sch
     la, lb = a.run(9, graph=False), b.run(9, graph=False)
     assert np.array_equal(la, lb)
     assert torch.equal(a.result(), b.result())
+
+
+@pytest.mark.parametrize("scheme", ["hybrid", "upwind"])
+@pytest.mark.parametrize("x_solver", ["chebyshev", "cg"])
+def test_admm_placement_tuner_changes_nothing_but_the_buffers(scheme, x_solver):
+    """ADMM(tune_placement=True) times complete sets of state arrays with real outer iterations and keeps the fastest, back in the initial
+    state -- bit-identical to an untuned run (and ``z`` still available)."""
+    import torch
+    import pytv
+    rng = np.random.default_rng(9)
+    shape = (6, 3, 32, 64)
+    x0 = torch.as_tensor((orc.phantom(shape, dtype=np.float64) + 100 * rng.random(shape)).astype(np.float32)).cuda()
+    kw = dict(reg_z_over_reg=0.7, reg_time=1.3, scheme=scheme, n_cg=4, x_solver=x_solver)
+    a = pytv.solvers.ADMM(x0, 6.0, 0.1, tune_placement=False, **kw)
+    b = pytv.solvers.ADMM(x0, 6.0, 0.1, tune_placement=True, **kw)
+    assert a.placement is None and b.placement is not None and "error" not in b.placement
+    assert len(b.placement["outer_ms"]) == 4 and b.placement["seconds"] > 0
+    la, lb = a.run(5, graph=False), b.run(5, graph=False)
+    assert np.array_equal(la, lb)
+    assert torch.equal(a.result(), b.result()) and torch.equal(a.u, b.u) and torch.equal(a.z, b.z)

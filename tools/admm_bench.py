@@ -13,7 +13,8 @@ V = x0.numel()
 print("ADMM on %s (V = %.0f Mvox), %d CG steps per outer iteration, rho = 0.05, lambda = 25" % (shape, V / 1e6, n_cg))
 for scheme in ("upwind", "downwind", "central", "hybrid"):
     # one-sweep dual side (round 3, sparse / full storage of t'), the kernel trio it replaces, the textbook recurrence
-    for name, kw in (("one-sweep+chebyshev", dict(fused=True, x_solver="chebyshev", keep_z=False)), ("one-sweep", dict(fused=True, keep_z=False, x_solver="cg")),
+    for name, kw in (("default", dict()),          # what ADMM(x0, reg, rho) is since round 4: one-sweep, Chebyshev x-solve, keep_z=True, placement tuner
+                     ("one-sweep+chebyshev", dict(fused=True, x_solver="chebyshev", keep_z=False)), ("one-sweep", dict(fused=True, keep_z=False, x_solver="cg")),
                      ("one-sweep keep_z", dict(fused=True, keep_z=True, x_solver="cg")),
                      ("single-reduction", dict(fused=False, x_solver="cg")), ("textbook CG", dict(single_reduction=False))):
         if os.environ.get("ONLY") and os.environ["ONLY"] != name:          # ONLY=<exact name>: one variant (profiling)
@@ -31,9 +32,11 @@ for scheme in ("upwind", "downwind", "central", "hybrid"):
         # + chebyshev: the x-solve is e_2 from r alone (2), a step with y = a0 r formed on the fly (3), n_cg - 4 steps of 4 (e_k with its
         # stencil, r, e_{k-1} read; e_{k+1} written) and a last step of 5 (+ x read; the new x written instead of e; |x - x0|^2 comes
         # from the sweep that follows): 4 n_cg - 6 words
-        words = {"one-sweep+chebyshev": 2 * nd + 3 + 4 * n_cg - 6, "one-sweep": 2 * nd + 11 * n_cg + 2, "one-sweep keep_z": 3 * nd + 11 * n_cg + 2, "single-reduction": 4 * nd + 11 * n_cg + 5,
+        words = {"default": 3 * nd + 3 + 4 * n_cg - 6, "one-sweep+chebyshev": 2 * nd + 3 + 4 * n_cg - 6, "one-sweep": 2 * nd + 11 * n_cg + 2, "one-sweep keep_z": 3 * nd + 11 * n_cg + 2, "single-reduction": 4 * nd + 11 * n_cg + 5,
                  "textbook CG": 5 * nd + 11 * n_cg + 12}[name]
         print("%-9s Nd=%d %-19s %.2f ms/outer  %.1f it/s  loss %.6e -> %.6e  | algorithmic %.0f words/voxel -> %.0f GB/s" % (
             scheme, nd, name, dt * 1e3, 1 / dt, loss[0], loss[-1], words, words * 4.0 * V / dt / 1e9))
+        if ad.placement:
+            print("          placement tuner: %s" % (ad.placement,))
         del ad
         torch.cuda.empty_cache()
