@@ -73,13 +73,13 @@ def test_fixup_without_x0_returns_zero_fidelity():
 
 
 @pytest.mark.parametrize("scheme", ["hybrid", "upwind"])
-def test_placement_tuner_changes_nothing_but_the_buffers(scheme):
+@pytest.mark.parametrize("shape", [(6, 3, 32, 64), (5, 3, 33, 250)])       # the second: 1000-byte rows, padded state (pitch="auto")
+def test_placement_tuner_changes_nothing_but_the_buffers(scheme, shape):
     """ChambollePock(tune_placement=True) times candidate allocations for q, the x ping-pong pair and p with the real sweep and keeps
     the fastest; the state is re-initialised afterwards -- the run must be bit-identical to an untuned one."""
     import torch
     import pytv
     rng = np.random.default_rng(5)
-    shape = (6, 3, 32, 64)
     x0 = torch.as_tensor((orc.phantom(shape, dtype=np.float64) + 100 * rng.random(shape)).astype(np.float32)).cuda()
     kw = dict(reg_z_over_reg=0.7, reg_time=1.3)
     a = pytv.solvers.ChambollePock(x0, 20.0, scheme=scheme, fused=True, tune_placement=False, **kw)
