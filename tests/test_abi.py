@@ -163,3 +163,20 @@ def test_package_surface_says_what_is_missing(monkeypatch, tmp_path):
     except ImportError:
         with pytest.raises(FileNotFoundError, match="PYTV_CAMERAMAN"):
             pytv.utils.cameraman()
+
+
+def test_auto_pitch_rule():
+    """The solvers' padding rule (host logic, no GPU): whole-cache-line rows stay dense, rows rounded up to 128 bytes when that costs at
+    most 8 %, short ragged rows only up to the 16-byte lane (pytv/solvers.py: auto_pitch; measured in profiles/r4_pitch_bench.txt)."""
+    import torch
+    from pytv.solvers import auto_pitch
+    f32, f64 = torch.float32, torch.float64
+    assert auto_pitch(1024, 1024, f32) is None and auto_pitch(512, 512, f64) is None            # every BASELINE configuration: dense
+    assert auto_pitch(1000, 1000, f32) == (1024, 1000 * 1024)                                   # 1000 -> 1024 columns: + 2.4 %
+    assert auto_pitch(1001, 1001, f32) == (1024, 1001 * 1024)
+    assert auto_pitch(100, 100, f32) is None                                                    # 100 -> 128 would be + 28 %: stays dense (lane-aligned)
+    assert auto_pitch(7, 9, f32) == (12, 7 * 12)                                                # ragged and short: up to the 16-byte lane only
+    assert auto_pitch(9, 13, f64) == (14, 9 * 14)
+    assert auto_pitch(1000, 1000, f64) == (1008, 1000 * 1008)                                   # 8000-byte rows -> 8064 (128-byte multiple)
+    rp, fp = auto_pitch(16, 128, f32, frame_pad_bytes=4352)                                     # experiments: a frame pad on dense rows
+    assert rp == 128 and fp == 16 * 128 + 1088
