@@ -277,7 +277,8 @@ int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const voi
  *   dots[0] = |b - A x|^2,  dots[1] = |out - ref|^2 if ref is given, else |x|^2      (device fp64, local planes)
  * out must not alias an input.  x_prev / x_next: TWO halo planes each, as in tv_normal_op.  The coefficients of step k follow from
  * the spectral interval [1, 1 + rho L] alone (pytv/solvers.py::chebyshev_coefficients restates the recurrence).
- * tv_axpby: out = a x + b y (y NULL: a x); *dist2 (or NULL, then ref and ws may be NULL too) = |out - ref|^2.
+ * tv_axpby: out = a x + b y (y NULL: a x); *dist2 (or NULL, then ref and ws may be NULL too) = |out - ref|^2; out NULL (with ref):
+ * the distance alone, nothing is stored (round 4: the fidelity of the last iterate of a lagged Chambolle-Pock block).
  * Replaces: nothing in the reference (its README names ADMM only, README.md:26,135). */
 int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, double rho, const void* b, const void* y,
                  double yscale, const void* add, const void* ref, double alpha, double beta, void* out, double* dots, void* ws, void* stream);

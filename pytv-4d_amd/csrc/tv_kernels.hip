@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void k_axpby(long long nv, T a, const T* x, T 
                 acc += e * e;
             }
         }
-        CGST<T, V>(out + i * V, o);
+        if (out != nullptr) CGST<T, V>(out + i * V, o);          // out == nullptr: the distance only (a pure reduction: one word less)
     }
     if (ref != nullptr) {
         acc = block_sum(acc, sm);
@@ -1316,12 +1316,12 @@ int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void
     return reduce_partials(w1, kFlatBlocks, nmax, dots + 1, st);
 }
 
-// out = a x + b y (y == NULL: out = a x); *dist2 (or NULL) = |out - ref|^2
+// out = a x + b y (y == NULL: out = a x); *dist2 (or NULL) = |out - ref|^2; out == NULL (with ref): the distance alone, nothing stored
 int tv_axpby(const tv_geom* g, double a, const void* x, double b, const void* y, const void* ref, void* out, double* dist2, void* ws,
              void* stream) {
     DG d;
     if (int rc = make_dg(g, d, true)) return rc;
-    if (x == nullptr || out == nullptr) return fail(TV_E_ARG, "NULL array");
+    if (x == nullptr || (out == nullptr && ref == nullptr)) return fail(TV_E_ARG, "NULL array");
     if ((ref != nullptr) != (dist2 != nullptr) || (ref != nullptr && ws == nullptr)) return fail(TV_E_ARG, "ref, dist2 and ws go together");
     hipStream_t st = (hipStream_t)stream;
     TV_FLAT_LAUNCH(k_axpby, g->dtype, nvox(d), ({x, y, ref, out}), (T)a, (const T*)x, (T)b, (const T*)y, (const T*)ref, (T*)out, (double*)ws);

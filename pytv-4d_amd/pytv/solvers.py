@@ -625,8 +625,8 @@ class ChambollePock(_SlabProblem):
                 self.step(rows[k])
         finally:
             self._lag = None
-        # fidelity of the last iterate: |x - x0|^2 by the flat helper (x_alt is free between two steps: scratch output)
-        _nv.check(self.lib.tv_axpby(self.geo.ref, 1.0, _nv.ptr(self.x), 0.0, None, _nv.ptr(self.x0), _nv.ptr(self.x_alt),
+        # fidelity of the last iterate: |x - x0|^2 by the flat helper, as a pure reduction (out = NULL: two words read, none written)
+        _nv.check(self.lib.tv_axpby(self.geo.ref, 1.0, _nv.ptr(self.x), 0.0, None, _nv.ptr(self.x0), None,
                                     self._lag_void.data_ptr(), _nv.ptr(self.ws), self.stream))
         rows[n - 1, self.F] = 0.5 * self._lag_void[0]
 

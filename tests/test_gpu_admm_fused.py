@@ -187,6 +187,11 @@ def test_cheb_step_matches_numpy(nvlib, scheme, shape):
         np.testing.assert_allclose(sc.item(), np.sum((want - ref) ** 2), rtol=tol * 100)
         nv.check(lib.tv_axpby(g.ref, 0.5, nv.ptr(xd), 0.0, None, None, nv.ptr(od), None, None, st))
         np.testing.assert_allclose(od.cpu().numpy(), 0.5 * x64, rtol=0, atol=tol)
+        # out = NULL with a reference: the distance alone, the same number, nothing stored (round 4)
+        sc2 = torch.zeros(1, dtype=torch.float64, device="cuda")
+        nv.check(lib.tv_axpby(g.ref, 0.7, nv.ptr(xd), -1.3, nv.ptr(yd), nv.ptr(refd), None, sc2.data_ptr(), nv.ptr(ws), st))
+        assert sc2.item() == sc.item()
+        assert lib.tv_axpby(g.ref, 0.7, nv.ptr(xd), -1.3, nv.ptr(yd), None, None, None, None, st) != 0      # neither an output nor a distance: refused
 
 
 def test_chebyshev_coefficients_and_bound():
