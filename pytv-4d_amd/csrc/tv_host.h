@@ -203,12 +203,22 @@ inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
     if ((long long)d.s_z * 4 < (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024) return false;
     return (d.m >= 1 && d.m <= 8) || d.m == 16;
 }
+// the marching ADJOINT (k_DT_march) is instantiated for double as well (round 4): the same rule with the plane measured in bytes -- for the
+// case where it wins: hybrid with a plain store (tv_DT, 32x8x1024x1024 fp64: 3.6 - 3.8 ms = 0.64 - 0.68 against 4.4 - 4.5 one-site; the Nd = 4
+// schemes are 10 - 20 % SLOWER marching, tv_DT_axpy is the same either way: profiles/r4_op_rooflines_f64_dt.txt)
+inline bool march_dt_ok(const tv_geom* g, const DG& d, bool vec, bool plain_store) {
+    if (g->dtype == TV_F32) return march_ok(g, d, vec);
+    if (g->scheme != TV_HYBRID || !plain_store) return false;
+    if (!vec || d.nx < 128 || d.wv != nullptr || d.pitched || env_int("TV_NO_MARCH", 0)) return false;
+    if ((long long)d.s_z * 8 < (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024) return false;
+    return (d.m >= 1 && d.m <= 8) || d.m == 16;
+}
 inline int march_zchunk(const DG& d) {
     // planes per z-chunk: long chunks amortise the chunk prologue (and, for the one-sweep CP kernel, the
     // chunk-edge fix-up planes); short ones keep >= ~4096 blocks in flight.  TV_ZCHUNK overrides.
     int zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
-        long long tiles = (long long)((d.nx / 4 + 63) / 64) * ((d.ny + 3) / 4);
+        long long tiles = (long long)((d.nx / d.vl + 63) / 64) * ((d.ny + 3) / 4);      // d.vl columns per 16-byte lane: 4 (fp32) / 2 (fp64)
         if (tiles < 1) tiles = 1;                        // frames narrower than one 4-column vector (tools/abi_validation.py)
         const long long want_chunks = (4096 + tiles - 1) / tiles;
         zc = (int)(d.nz / (want_chunks > 0 ? want_chunks : 1));
@@ -220,7 +230,7 @@ inline int march_zchunk(const DG& d) {
     return zc;
 }
 inline LC march_cfg(const DG& d, int zchunk) {
-    const long long tx = (d.nx / 4 + 63) / 64, ty = (d.ny + 3) / 4, nch = (d.nz + zchunk - 1) / zchunk;
+    const long long tx = (d.nx / d.vl + 63) / 64, ty = (d.ny + 3) / 4, nch = (d.nz + zchunk - 1) / zchunk;
     LC lc;
     lc.block = dim3(64, 4, 1);
     lc.grid = dim3((unsigned)(tx * ty), (unsigned)nch, 1);
@@ -288,9 +298,10 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
 // streaming forward kernel (tv_dstream.h): d = D x without LDS tile or barrier, every load one plane ahead of its use
 bool D_stream_ok(const tv_geom* g, const DG& d, bool vec);
 int D_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const void* xn, hipStream_t st, void* dout);
-int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb, float* out);
+// (fp32 and fp64: the arrays are of g->dtype)
+int DT_store(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb, void* out);
 int DT_axpy(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
-            float* out, const float* base, float alpha, const float* base2 = nullptr, float beta = 0.f);
+            void* out, const void* base, double alpha, const void* base2 = nullptr, double beta = 0.0);
 int DT_cp_primal(const tv_geom* g, const DG& d, const void* q, const void* qp, const void* qn, hipStream_t st, long long* nb,
                  float* x, const float* x0, float* p, float tau, float sigma_a, float inv_1p_sigma_a, double* partials);
 }  // namespace tvm

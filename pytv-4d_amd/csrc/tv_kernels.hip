@@ -883,10 +883,10 @@ int tv_DT_axpy2(const tv_geom* g, const void* a, const void* b, const void* ab_p
     const bool vec = rows_vectorisable(g, d) && aligned16({a, b, ab_prev, ab_next, base, base2, out, d.wv});
     hipStream_t st = (hipStream_t)stream;
     const bool plain_store = (base == nullptr && base2 == nullptr && alpha == 1.0);
-    if (b == nullptr && march_ok(g, d, vec)) {
+    if (b == nullptr && march_dt_ok(g, d, vec, plain_store)) {          // plane-marching adjoint (tv_march.h): fp32, and since round 4 fp64 hybrid tv_DT
         long long nb;
-        if (plain_store) return tvm::DT_store(g, d, a, ab_prev, ab_next, st, &nb, (float*)out);
-        return tvm::DT_axpy(g, d, a, ab_prev, ab_next, st, &nb, (float*)out, (const float*)base, (float)alpha, (const float*)base2, (float)beta);
+        if (plain_store) return tvm::DT_store(g, d, a, ab_prev, ab_next, st, &nb, out);
+        return tvm::DT_axpy(g, d, a, ab_prev, ab_next, st, &nb, out, base, alpha, base2, beta);
     }
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
         LC lc = launch_cfg(d, V, d.nz);

@@ -191,20 +191,58 @@ __global__ __launch_bounds__(256, LIGHT ? 3 : ((PF || M > 8) ? 2 : 1)) void k_D_
 #ifndef TV_DT_NT
 #define TV_DT_NT 0               // 1: EXPERIMENT the read-once streams of k_DT_march non-temporal: much SLOWER (tv_DT hybrid 3.6 -> 6.3 ms: the border scalars and row taps of neighbouring threads want those lines in the cache)
 #endif
-__device__ __forceinline__ Vec<float, 4> DTLD(const float* p) {
+template <typename T, int V> __device__ __forceinline__ Vec<T, V> DTLD(const T* p) {
 #if TV_DT_NT
-    return vload_s<float, 4>(p);
+    return vload_s<T, V>(p);
 #else
-    return vload<float, 4>(p);
+    return vload<T, V>(p);
 #endif
 }
-template <int S, int M, typename Epi>
-__global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float* __restrict__ q, const float* __restrict__ qp,
-                                                  const float* __restrict__ qn, int zchunk, Epi epi) {
+// the same for one 16-byte lane of T (fp64, round 4: two columns per lane, 128 columns per wave row)
+template <int V> __device__ __forceinline__ MarchCoord march_coord_v(const DG& g, int zchunk) {
+    MarchCoord c;
+    c.lane = (int)threadIdx.x;
+    c.ty = (int)threadIdx.y;
+    const int nxv = g.nx / V;
+    const int tiles_x = (nxv + 63) / 64;
+    const int bx = (int)blockIdx.x % tiles_x, by = (int)blockIdx.x / tiles_x;
+    c.col0 = (bx * 64 + c.lane) * V;
+    c.y = by * 4 + c.ty;
+    c.ok = (c.col0 < g.nx) && (c.y < g.ny);
+    c.zs = (int)blockIdx.y * zchunk;
+    c.ze = (c.zs + zchunk < g.nz) ? c.zs + zchunk : g.nz;
+    c.inpl = (long long)c.y * g.nx + c.col0;
+    return c;
+}
+template <bool LEFT, bool RIGHT, typename T, int V>
+__device__ __forceinline__ void col_neighbours_v(const Vec<T, V>& v, const T* p, bool ok, int lane, int col0, int nx, T& left, T& right) {
+    left = T(0);
+    right = T(0);
+    T edge = T(0);
+    const bool le = LEFT && (lane == 0) && ok && (col0 > 0);
+    const bool re = RIGHT && (lane == 63) && ok && (col0 + V < nx);
+    if (le || re) edge = le ? p[-1] : p[V];
+    if (LEFT) {
+        const T s = __shfl_up(v.v[V - 1], 1, 64);
+        left = (lane == 0) ? edge : s;
+    }
+    if (RIGHT) {
+        const T s = __shfl_down(v.v[0], 1, 64);
+        right = (lane == 63) ? edge : s;
+    }
+}
+// T: float (16-byte lanes of 4 columns) or -- round 4 -- double (2 columns): the same registers, the same 16-byte accesses.  (double is
+// instantiated with the AxpyDT epilogue only: with StoreDT the compiler gives hybrid M = 8 256 VGPRs and one wave per SIMD -- 7.0 ms against
+// 5.0 one-site -- or, capped at 168, 484 bytes of scratch; the plain store runs as AxpyDT with no base and alpha = 1: 135 VGPRs.)
+template <int S, int M, typename Epi, typename T = float>
+__global__ __launch_bounds__(256) void k_DT_march(DG g, WT<T> w, const T* __restrict__ q, const T* __restrict__ qp,
+                                                  const T* __restrict__ qn, int zchunk, Epi epi) {
+    constexpr int V = 16 / (int)sizeof(T);
+    using V4 = Vec<T, V>;                  // (the name of the fp32 original: one 16-byte lane)
     __shared__ double sm[16];
-    const MarchCoord c = march_coord(g, zchunk);
-    const V4 zero = vsplat<float, 4>(0.f);
-    const V4 mf = g.ta ? mask_factor<float, 4>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<float, 4>(1.f);
+    const MarchCoord c = march_coord_v<V>(g, zchunk);
+    const V4 zero = vsplat<T, V>(T(0));
+    const V4 mf = g.ta ? mask_factor<T, V>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<T, V>(T(1));
     double acc = 0.0;
     constexpr bool HY = (S == HYBRID);
     // run-time central fallbacks (two-point axes use the forward stencil, i.e. mode 0)
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float
     constexpr bool ZF = (S == DOWNWIND || S == HYBRID || S == CENTRAL);  // some channel looks forwards in z
 
     auto ldq = [&](int zl, int ch, long long off) -> V4 {   // q[zl, ch] at in-plane offset off
-        return DTLD(q + (long long)zl * g.s_dz + (long long)ch * g.s_z + off);          // z / time channels: each sample is read once
+        return DTLD<T, V>(q + (long long)zl * g.s_dz + (long long)ch * g.s_z + off);          // z / time channels: each sample is read once
     };
 
     V4 A[M], B[M];
@@ -228,7 +266,7 @@ __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float
 #pragma unroll
         for (int t = 0; t < M; ++t) {
             const long long off = (long long)t * g.s_t + c.inpl;
-            if (ZB && gz >= 1) A[t] = (c.zs >= 1) ? ldq(c.zs - 1, ch_zb, off) : vload<float, 4>(qp + off);
+            if (ZB && gz >= 1) A[t] = (c.zs >= 1) ? ldq(c.zs - 1, ch_zb, off) : vload<T, V>(qp + off);
             if (S == DOWNWIND || HY) B[t] = ldq(c.zs, ch_zf, off);          // centre of the forward-looking channel
             if (S == CENTRAL) B[t] = ldq(c.zs, ch_zb, off);                // central: plane z of the same channel
         }
@@ -251,11 +289,11 @@ __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float
                 // ---------------- rows ----------------------------------------------------------
                 auto rows = [&](auto mode, int ch) {
                     constexpr int MD = decltype(mode)::value;
-                    const float* pch = q + off0 + (long long)ch * g.s_z;
-                    const V4 lo = (c.y >= 1 && MD != 1) ? vload<float, 4>(pch - g.nx) : zero;
-                    const V4 ce = (MD != 2) ? vload<float, 4>(pch) : zero;
-                    const V4 hi = (c.y + 1 < g.ny && MD != 0) ? vload<float, 4>(pch + g.nx) : zero;
-                    r = r + adj_axis<MD, float, 4>(c.y, g.ny, lo, ce, hi);
+                    const T* pch = q + off0 + (long long)ch * g.s_z;
+                    const V4 lo = (c.y >= 1 && MD != 1) ? vload<T, V>(pch - g.nx) : zero;
+                    const V4 ce = (MD != 2) ? vload<T, V>(pch) : zero;
+                    const V4 hi = (c.y + 1 < g.ny && MD != 0) ? vload<T, V>(pch + g.nx) : zero;
+                    r = r + adj_axis<MD, T, V>(c.y, g.ny, lo, ce, hi);
                 };
                 if (S == UPWIND) rows(IC<0>{}, 0);
                 if (S == DOWNWIND) rows(IC<1>{}, 0);
@@ -265,19 +303,19 @@ __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float
             // ---------------- columns (shuffles are wave-wide: outside the ok branch) --------------
             auto cols = [&](auto mode, int ch) {
                 constexpr int MD = decltype(mode)::value;
-                const float* pch = q + off0 + (long long)ch * g.s_z;
-                const V4 ce = c.ok ? DTLD(pch) : zero;                 // column channels: the row neighbours of the ROW channels come from
-                float left, right;                                     // the cache (plain loads), everything else is read once
-                col_neighbours<(MD != 1), (MD != 0)>(ce, pch, c.ok, c.lane, c.col0, g.nx, left, right);
-                const V4 lo = shift_right<float, 4>(ce, left);
-                const V4 hi = shift_left<float, 4>(ce, right);
+                const T* pch = q + off0 + (long long)ch * g.s_z;
+                const V4 ce = c.ok ? DTLD<T, V>(pch) : zero;                 // column channels: the row neighbours of the ROW channels come from
+                T left, right;                                     // the cache (plain loads), everything else is read once
+                col_neighbours_v<(MD != 1), (MD != 0), T, V>(ce, pch, c.ok, c.lane, c.col0, g.nx, left, right);
+                const V4 lo = shift_right<T, V>(ce, left);
+                const V4 hi = shift_left<T, V>(ce, right);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < V; ++i) {
                     const int col = c.col0 + i;
-                    float a, b;
-                    if (MD == 0) { a = (col >= 1) ? lo.v[i] : 0.f; b = (col <= g.nx - 2) ? ce.v[i] : 0.f; }
-                    else if (MD == 1) { a = (col >= 1) ? ce.v[i] : 0.f; b = (col <= g.nx - 2) ? hi.v[i] : 0.f; }
-                    else { a = (col >= 2) ? lo.v[i] : 0.f; b = (col <= g.nx - 3) ? hi.v[i] : 0.f; }
+                    T a, b;
+                    if (MD == 0) { a = (col >= 1) ? lo.v[i] : T(0); b = (col <= g.nx - 2) ? ce.v[i] : T(0); }
+                    else if (MD == 1) { a = (col >= 1) ? ce.v[i] : T(0); b = (col <= g.nx - 2) ? hi.v[i] : T(0); }
+                    else { a = (col >= 2) ? lo.v[i] : T(0); b = (col <= g.nx - 3) ? hi.v[i] : T(0); }
                     r.v[i] += a - b;
                 }
             };
@@ -290,23 +328,23 @@ __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float
                 if (g.za) {
                     V4 hi = zero;       // plane z+1 of the forward-looking (or central) channel
                     if (ZF && (S != CENTRAL || z_cen) && gz + 1 < g.nzg)
-                        hi = (z + 1 < g.nz) ? ldq(z + 1, ch_zf, inpl_t) : vload<float, 4>(qn + inpl_t);
+                        hi = (z + 1 < g.nz) ? ldq(z + 1, ch_zf, inpl_t) : vload<T, V>(qn + inpl_t);
                     if (S == UPWIND || (S == CENTRAL && !z_cen)) {
                         const V4 ce = (S == CENTRAL) ? B[t] : ldq(z, ch_zb, inpl_t);
-                        r = r + w.wz * adj_axis<0, float, 4>(gz, g.nzg, A[t], ce, zero);
+                        r = r + w.wz * adj_axis<0, T, V>(gz, g.nzg, A[t], ce, zero);
                         A[t] = ce;
                         if (S == CENTRAL) B[t] = (z + 1 < c.ze) ? ldq(z + 1, ch_zb, inpl_t) : zero;
                     } else if (S == DOWNWIND) {
-                        r = r + w.wz * adj_axis<1, float, 4>(gz, g.nzg, zero, B[t], hi);
+                        r = r + w.wz * adj_axis<1, T, V>(gz, g.nzg, zero, B[t], hi);
                         B[t] = hi;
                     } else if (S == CENTRAL) {
-                        r = r + w.wz * adj_axis<2, float, 4>(gz, g.nzg, A[t], zero, hi);
+                        r = r + w.wz * adj_axis<2, T, V>(gz, g.nzg, A[t], zero, hi);
                         A[t] = B[t];
                         B[t] = hi;
                     } else {
                         const V4 ce = ldq(z, ch_zb, inpl_t);
-                        r = r + w.wz * adj_axis<0, float, 4>(gz, g.nzg, A[t], ce, zero);
-                        r = r + w.wz * adj_axis<1, float, 4>(gz, g.nzg, zero, B[t], hi);
+                        r = r + w.wz * adj_axis<0, T, V>(gz, g.nzg, A[t], ce, zero);
+                        r = r + w.wz * adj_axis<1, T, V>(gz, g.nzg, zero, B[t], hi);
                         A[t] = ce;
                         B[t] = hi;
                     }
@@ -317,27 +355,27 @@ __global__ __launch_bounds__(256) void k_DT_march(DG g, WT<float> w, const float
                     if ((S == DOWNWIND || HY || t_cen) && t + 1 < M) hi = ldq(z, ch_tf, inpl_t + g.s_t);
                     if (S == UPWIND || (S == CENTRAL && !t_cen)) {
                         const V4 ce = (S == CENTRAL) ? t_c1 : ldq(z, ch_tb, inpl_t);
-                        rt = rt + w.wt * adj_axis<0, float, 4>(t, M, t_lo, ce, zero);
+                        rt = rt + w.wt * adj_axis<0, T, V>(t, M, t_lo, ce, zero);
                         t_lo = ce;
                         if (S == CENTRAL) t_c1 = (t + 1 < M) ? ldq(z, ch_tb, inpl_t + g.s_t) : zero;
                     } else if (S == DOWNWIND) {
-                        rt = rt + w.wt * adj_axis<1, float, 4>(t, M, zero, t_ce, hi);
+                        rt = rt + w.wt * adj_axis<1, T, V>(t, M, zero, t_ce, hi);
                         t_ce = hi;
                     } else if (S == CENTRAL) {
-                        rt = rt + w.wt * adj_axis<2, float, 4>(t, M, t_lo, zero, hi);
+                        rt = rt + w.wt * adj_axis<2, T, V>(t, M, t_lo, zero, hi);
                         t_lo = t_c1;
                         t_c1 = hi;
                     } else {
                         const V4 ce = ldq(z, ch_tb, inpl_t);
-                        rt = rt + w.wt * adj_axis<0, float, 4>(t, M, t_lo, ce, zero);
-                        rt = rt + w.wt * adj_axis<1, float, 4>(t, M, zero, t_ce, hi);
+                        rt = rt + w.wt * adj_axis<0, T, V>(t, M, t_lo, ce, zero);
+                        rt = rt + w.wt * adj_axis<1, T, V>(t, M, zero, t_ce, hi);
                         t_lo = ce;
                         t_ce = hi;
                     }
                     r = r + rt * mf;
                 }
-                if (S == HYBRID) r = Consts<float>::inv_sqrt2() * r;
-                if (S == CENTRAL) r = 0.5f * r;
+                if (S == HYBRID) r = Consts<T>::inv_sqrt2() * r;
+                if (S == CENTRAL) r = T(0.5) * r;
                 acc += epi((long long)z * g.s_z + inpl_t, r);
             }
         }
