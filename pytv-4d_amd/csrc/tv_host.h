@@ -207,7 +207,9 @@ inline bool march_ok(const tv_geom* g, const DG& d, bool vec) {
 // case where it wins: hybrid with a plain store (tv_DT, 32x8x1024x1024 fp64: 3.6 - 3.8 ms = 0.64 - 0.68 against 4.4 - 4.5 one-site; the Nd = 4
 // schemes are 10 - 20 % SLOWER marching, tv_DT_axpy is the same either way: profiles/r4_op_rooflines_f64_dt.txt)
 inline bool march_dt_ok(const tv_geom* g, const DG& d, bool vec, bool plain_store) {
-    if (g->dtype == TV_F32) return march_ok(g, d, vec);
+    // fp32: everything but the plain adjoint of the one-sided schemes, where the one-site kernel is 3 - 5 % ahead (64x8x1024x1024: upwind 2.16 - 2.18
+    // against 2.23 - 2.31 ms, downwind 2.15 - 2.19 against 2.30 - 2.39; hybrid 3.6 against 4.3 and central 2.4 - 2.5 against 2.75 the other way)
+    if (g->dtype == TV_F32) return march_ok(g, d, vec) && !(plain_store && (g->scheme == TV_UPWIND || g->scheme == TV_DOWNWIND));
     if (g->scheme != TV_HYBRID || !plain_store) return false;
     if (!vec || d.nx < 128 || d.wv != nullptr || d.pitched || env_int("TV_NO_MARCH", 0)) return false;
     if ((long long)d.s_z * 8 < (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024) return false;
