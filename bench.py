@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: fused Chambolle-Pock iterations on a synthetic (Nz, M, N, N) fp32 volume.
+"""Benchmark of the hot path: fused Chambolle-Pock iterations (default) or ADMM outer iterations (--solver admm) on a
+synthetic (Nz, M, N, N) fp32 volume.
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --solver admm --workload config4-slab --scheme upwind      (BASELINE configs[4]: the per-GPU slab of the 8-GPU job)
 
 A "step" is ONE Chambolle-Pock iteration (README.md:145-157 of the reference: fidelity-dual update,
 D + prox dual update, D^T primal update, loss) over the whole volume, state resident in HBM.  With
@@ -15,7 +17,18 @@ Workloads (--workload):
   config1    (256, 1, 512, 512)   3-D hybrid        (BASELINE.json configs[1])
   config2    (128, 8, 512, 512)   4-D hybrid        (BASELINE.json configs[2])
   small      (16, 4, 256, 256)    quick functional run
-  rehearsal  (64, 8, 1024, 1024)  the north-star frame, 64 planes: 8 test ranks sharing one GPU (tests/test_gpu_rccl.py)
+  rehearsal  (64, 8, 1024, 1024)  the north-star frame, 64 planes: 8 test ranks sharing one GPU (tests/test_gpu_rccl.py);
+             also the per-GPU slab of config3 at N = 8 ("config3-slab" is the same shape)
+  config3    (512, 8, 1024, 1024) 4-D hybrid CP, the z-slab job of BASELINE.json configs[3] (128 GiB of q: meant for N = 8, 64 planes
+             per rank; N = 1 only with --allow-single -- 192 GiB of state, placement tuner off)
+  config4    (256, 16, 1024, 1024) ADMM, all four schemes via --scheme (BASELINE.json configs[4]; N = 1 only with --allow-single and
+             only for the Nd = 4 schemes: hybrid needs 352 GiB)
+  config4-slab (32, 16, 1024, 1024) what ONE rank of config4 holds at N = 8: the single-GPU line of the ADMM path
+  admm-small (16, 4, 256, 256)    quick functional ADMM run
+
+--solver cp | admm: default = the solver the workload names (config4* / admm-small: admm, everything else: cp).  A "step" of the ADMM
+bench is ONE outer iteration of pytv.solvers.ADMM as it comes by default (one-sweep dual side tv_admm_fused + tv_admm_fixup,
+Chebyshev x-solve with --n-cg steps, keep_z=True); metric admm_outer_iters_per_sec.
 """
 import argparse
 import json
@@ -38,8 +51,15 @@ WORKLOADS = {
     # the north-star frame (8 x 1024 x 1024) with 64 planes: what 8 ranks sharing ONE GPU can hold -- the N = 8 rehearsal of
     # tests/test_gpu_rccl.py (no 8-GPU box is available to the build; the driver runs the real curve)
     "rehearsal": dict(shape=(64, 8, 1024, 1024), reg_z=1.0, reg_time=1.0),
+    "config3-slab": dict(shape=(64, 8, 1024, 1024), reg_z=1.0, reg_time=1.0),
+    # BASELINE.json configs[3] / configs[4]: the two 8-GPU jobs.  min_gpus: fewer ranks are refused unless --allow-single
+    "config3": dict(shape=(512, 8, 1024, 1024), reg_z=1.0, reg_time=1.0, min_gpus=2),
+    "config4": dict(shape=(256, 16, 1024, 1024), reg_z=1.0, reg_time=1.0, min_gpus=2, solver="admm"),
+    "config4-slab": dict(shape=(32, 16, 1024, 1024), reg_z=1.0, reg_time=1.0, solver="admm"),
+    "admm-small": dict(shape=(16, 4, 256, 256), reg_z=1.0, reg_time=1.0, solver="admm"),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+METRIC = {"cp": "chambolle_pock_iters_per_sec", "admm": "admm_outer_iters_per_sec"}
 
 
 def synth_slab(shape, z0, nz, device, seed=1234):
@@ -69,18 +89,20 @@ def synth_slab(shape, z0, nz, device, seed=1234):
     return x
 
 
-def cpu_baseline(shape, reg_z, reg_time, nd):
+def cpu_baseline(shape, reg_z, reg_time, nd, scheme="hybrid"):
     """The NumPy oracle (a single-threaded restatement of pytv.tv_CPU / tv_operators_CPU, pinned to
     the reference by tests/golden) timed on a bounded z-sub-slab of the same workload."""
     from oracle import tv_oracle as orc
     Nz, M, Ny, Nx = shape
-    nz_cpu = max(2, min(Nz, int(round(1.6e7 / (M * Ny * Nx)))))
+    # V ~ 3e7 voxels (SURVEY 8d; round-4 verdict: 2 planes made half of the z differences boundary zeros): 4 planes of the north-star
+    # frame, ~11 s per iteration of the single-threaded NumPy restatement
+    nz_cpu = max(2, min(Nz, int(round(3.3e7 / (M * Ny * Nx)))))
     sub = (nz_cpu, M, Ny, Nx)
     rng = np.random.default_rng(0)
     x0 = (100.0 * rng.random(sub)).astype(np.float32)
     n_it = 2
     t0 = time.perf_counter()
-    orc.chambolle_pock(x0, n_it, 25.0, scheme="hybrid", reg_z_over_reg=reg_z, reg_time=reg_time)
+    orc.chambolle_pock(x0, n_it, 25.0, scheme=scheme, reg_z_over_reg=reg_z, reg_time=reg_time)
     dt = (time.perf_counter() - t0) / n_it
     vox = float(np.prod(sub))
     mvox_s = vox / dt / 1e6
@@ -89,6 +111,30 @@ def cpu_baseline(shape, reg_z, reg_time, nd):
             "mvox_per_s": mvox_s,
             "sample": "oracle.chambolle_pock (NumPy, single-threaded like the reference) on a %s z-sub-slab, "
                       "%d iterations, %.1f s/iteration; it/s extrapolated linearly in Nz to %s" % (sub, n_it, dt, tuple(shape)),
+            "host_cpus": os.cpu_count(), "numpy": np.__version__}
+
+
+def cpu_baseline_admm(shape, reg_z, reg_time, scheme, rho, n_cg):
+    """oracle.admm (NumPy, single-threaded, Chebyshev x-solve: the recurrence pytv.solvers.ADMM runs by default) timed on a bounded
+    sub-volume of the same workload: 2 planes, all M frames, as many whole rows as ~20 s of NumPy allow (the restatement runs at
+    ~1 Mvoxel/s for the Nd = 4 schemes and ~0.35 for hybrid); outer iterations / s extrapolated linearly in the voxel count."""
+    from oracle import tv_oracle as orc
+    Nz, M, Ny, Nx = shape
+    target = (7.0e6 if scheme == "hybrid" else 1.8e7)
+    nz_cpu = min(Nz, 2)
+    rows = int(target / (nz_cpu * M * Nx))
+    rows = max(16, min(Ny, rows // 16 * 16))
+    sub = (nz_cpu, M, rows, Nx)
+    rng = np.random.default_rng(0)
+    x0 = (100.0 * rng.random(sub)).astype(np.float32)
+    t0 = time.perf_counter()
+    orc.admm(x0, 1, 25.0, rho, n_cg, scheme=scheme, reg_z_over_reg=reg_z, reg_time=reg_time, x_solver="chebyshev")
+    dt = time.perf_counter() - t0
+    vox = float(np.prod(sub))
+    return {"value": vox / dt / float(np.prod(shape)), "unit": "outer it/s", "cores": 1, "kind": "port", "mvox_per_s": vox / dt / 1e6,
+            "sample": "oracle.admm (NumPy, single-threaded, x_solver='chebyshev', n_cg=%d, rho=%g) on a %s sub-volume (2 planes, all frames, "
+                      "%d of %d rows), 1 outer iteration, %.1f s; outer it/s extrapolated linearly in the voxel count to %s"
+                      % (n_cg, rho, sub, rows, Ny, dt, tuple(shape)),
             "host_cpus": os.cpu_count(), "numpy": np.__version__}
 
 
@@ -127,9 +173,12 @@ def live_traffic(args):
         return None, "rocprofv3 not found"
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None, "already running under a profiler"
+    n_child = 3                                  # steps + warm-up of a child pass = launches of every once-per-step kernel
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pmc", "off",
-             "--workload", args.workload, "--scheme", args.scheme, "--pitch", args.pitch, "--tune-placement", "off"] + (["--two-kernel"] if args.two_kernel else [])
-    sums = {}
+             "--workload", args.workload, "--scheme", args.scheme, "--pitch", args.pitch, "--tune-placement", "off",
+             "--solver", args.solver, "--rho", repr(args.rho), "--n-cg", str(args.n_cg), "--nz", str(args.nz)] + (["--two-kernel"] if args.two_kernel else []) \
+        + (["--allow-single"] if args.allow_single else [])
+    sums, totals = {}, {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="tvpmc_", dir="/tmp")
@@ -155,9 +204,10 @@ def live_traffic(args):
             for k, v in per.items():
                 kib = sum(v) / len(v)
                 sums.setdefault(k, {})[counter] = (2.0 if counter == "FETCH_SIZE" else 1.0) * kib * 1024.0
+                totals.setdefault(k, {})[counter] = (2.0 if counter == "FETCH_SIZE" else 1.0) * sum(v) * 1024.0
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    out = {"fused": 0.0, "fixup": 0.0, "dual": 0.0, "primal": 0.0}
+    out = {"fused": 0.0, "fixup": 0.0, "dual": 0.0, "primal": 0.0, "xsolve": 0.0}
     for k, c in sums.items():
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             continue
@@ -170,6 +220,9 @@ def live_traffic(args):
             out["dual"] += b
         elif "CpPrimal" in k:
             out["primal"] += b
+        elif "k_normal_stream" in k or "k_cheb" in k or "k_axpby" in k:
+            # the x-solve of an ADMM outer iteration is several launches of several instantiations: bytes per OUTER ITERATION
+            out["xsolve"] += (totals[k]["FETCH_SIZE"] + totals[k]["WRITE_SIZE"]) / n_child
     note = ("LIVE: two rocprofv3 child passes of this command (--pmc FETCH_SIZE, --pmc WRITE_SIZE; --steps 2 --warmup 1) in %.0f s; "
             "bytes per launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md, HBM section; both counters are exact on "
             "kernels with known byte counts, profiles/r2_pmc_calibration.txt)" % (time.perf_counter() - t0))
@@ -182,7 +235,24 @@ def gpu_state(index=0):
     power-limited can be told from one that was not (round-3 verdict: the driver's fresh-box runs were 9 % slower than profiles/)."""
     import glob
     out = {}
-    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    # HIP device -> DRM node through the PCI bus id (a lexicographic sort of card0, card1, card10, ... is not the HIP order; round-4 advice);
+    # best effort: where the bus id cannot be had, the index into the sorted list is used and the field says so
+    cards = []
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        cards = glob.glob("/sys/bus/pci/devices/%s/drm/card[0-9]*/device/pp_dpm_sclk" % bdf)
+        if cards:
+            out["drm_node"] = "by PCI bus id %s" % bdf
+            index = 0
+    except Exception:
+        cards = []
+    if not cards:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"),
+                       key=lambda p: int("".join(ch for ch in p.split("/card")[1].split("/")[0] if ch.isdigit()) or 0))
+        if cards:
+            out["drm_node"] = "best effort: entry %d of the numerically sorted DRM cards" % min(index, len(cards) - 1)
     if not cards:
         # no sysfs view of the GPU (container): one short-lived rocm-smi child instead
         import shutil, subprocess
@@ -242,6 +312,129 @@ def series_summary(v):
             "max": round(max(v), 3)}
 
 
+def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, comm_name, x0, want_live):
+    """--solver admm: K outer iterations of pytv.solvers.ADMM (defaults: one-sweep dual side, Chebyshev x-solve, keep_z=True) between
+    barriers; HIP events at the phase boundaries of every outer iteration (x-solve | sweep | fix-up); rank 0 prints one line."""
+    import torch
+    import torch.distributed as dist
+    import pytv
+    K, W = args.steps, args.warmup
+    kw = {}
+    if args.pitch == "none":
+        kw["pitch"] = None
+    if args.tune_placement != "default":
+        kw["tune_placement"] = (args.tune_placement == "on")
+    ad = pytv.solvers.ADMM(x0, 25.0, args.rho, n_cg=args.n_cg, scheme=args.scheme, reg_z_over_reg=wl["reg_z"], reg_time=wl["reg_time"],
+                           slab=slab, **kw)
+    nd = ad.geo.nd
+    hist = torch.zeros((K + W, 2), dtype=torch.float64, device=device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(W):
+        ad.step(hist[k])
+    ad.timing = []
+    state_before = gpu_state(local_rank) if rank == 0 else None
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        ad.step(hist[W + k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    state_after = gpu_state(local_rank) if rank == 0 else None
+    marks = ad.timing[:K]
+    ad.timing = None
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    hist_r = hist if backend == "nccl" else hist.cpu()
+    rccl_ranks = 0
+    if dist.is_initialized():
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hist_r, op=dist.ReduceOp.SUM)
+        rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+    elapsed = float(tmax.item())
+    h = hist_r.cpu().numpy()
+    loss = 0.5 * h[:, 1] + 25.0 * h[:, 0]
+    V = float(np.prod(shape))
+    V_local = float(slab.nz * shape[1] * shape[2] * shape[3])
+    it_s = K / elapsed
+    torch.cuda.synchronize()
+    # phase durations from the marks: [start .. xsolve] = x-solve, [xsolve .. sweep] = tv_admm_fused, [sweep .. end] = halo + tv_admm_fixup
+    def span(a, b):
+        v = []
+        for m in marks:
+            d = dict(m)
+            if a in d and b in d:
+                v.append(d[a].elapsed_time(d[b]))
+        return v
+    s_x, s_sw, s_fx = span("start", "xsolve"), span("xsolve", "sweep"), span("sweep", "end")
+    fused_path = bool(ad.fused and ad.cheb and s_sw)
+    words_sweep = 2 * nd + 3 + (nd if ad.keep_z else 0)
+    words_x = ad.xsolve_words
+    out = {
+        "metric": METRIC["admm"], "value": it_s, "unit": "it/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %s fp32 %s ADMM" % (args.workload, "x".join(str(s) for s in shape), args.scheme),
+                   "shape": list(shape), "scheme": args.scheme, "nd": nd, "reg_z_over_reg": wl["reg_z"], "reg_time": wl["reg_time"],
+                   "lambda": 25.0, "rho": args.rho, "n_cg": args.n_cg, "x_solver": "chebyshev" if ad.cheb else "cg", "keep_z": bool(ad.keep_z),
+                   "kernels": ("one-sweep dual side: tv_admm_fused + tv_admm_fixup; x-solve: %s" % ad.xsolve_desc) if fused_path
+                              else "unfused: tv_admm_tu + tv_DT_axpy + tv_normal_op2 / tv_cheb_step",
+                   "parallelism": "z-slab x%d" % world},
+        "voxel_iterations_per_sec": it_s * V,
+        "words_per_voxel_and_outer_iteration": {"sweep": words_sweep, "xsolve": words_x, "total": words_sweep + words_x},
+        "hbm_gbps_iteration": {"algorithmic": 4.0 * (words_sweep + words_x) * V * it_s / 1e9 / world, "per": "GPU"},
+        "loss_first_last": [float(loss[W]), float(loss[-1])],
+        "placement_tuning": getattr(ad, "placement", None),
+        "rccl_ranks": rccl_ranks, "comm": comm_name,
+        "halo": {"backend": (dist.get_backend() if dist.is_initialized() else None), "bytes_per_plane": 4 * shape[1] * shape[2] * shape[3]},
+        "gpu_state": {"before": state_before, "after": state_after, "source": "sysfs (pp_dpm_*, hwmon) read by rank 0 outside the timed region"},
+    }
+    if fused_path:
+        out["series_ms"] = {"xsolve": series_summary(s_x), "sweep": series_summary(s_sw), "fixup": series_summary(s_fx),
+                            "note": "HIP events on the launch stream at the phase boundaries of every outer iteration"}
+    live, live_note = None, "--pmc off"
+    if want_live:
+        del ad, x0, hist, hist_r, marks
+        torch.cuda.empty_cache()
+        try:
+            live, live_note = live_traffic(args)
+        except Exception as e:
+            live, live_note = None, "live PMC passes failed: %r" % (e,)
+    traffic = live or {}
+    src = live_note if live is not None else "not measured in this run (%s)" % live_note
+    sharded = " (per GPU)" if world > 1 else ""
+    if fused_path:
+        t_sw, t_x, t_fx = float(np.mean(s_sw)) * 1e-3, float(np.mean(s_x)) * 1e-3, float(np.mean(s_fx)) * 1e-3
+        b_sw, b_x = 4.0 * words_sweep * V_local, 4.0 * words_x * V_local
+        # the dominant kernel of the outer iteration: the one sweep over u (z / u update + the residual of the next x-solve)
+        out["roofline"] = {"bound": "hbm", "kernel": "tv_admm_fused: k_cp_fused<S,M,...,ALG_ADMM> (group soft threshold + u update + lagged r = (x0 - x) + rho D^T t')",
+                           "achieved": b_sw / t_sw / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_sw / t_sw / 1e9 / HBM_PEAK_GBPS,
+                           "traffic": traffic.get("fused"), "traffic_source": src, "bytes_per_launch": b_sw, "ms_per_launch": 1e3 * t_sw,
+                           "note": "algorithmic bytes (2 Nd + 3%s) * 4 per voxel: u read + written, x, x0 read, r written%s; HIP events on the launch stream"
+                                   % (" + Nd" if ad.keep_z else "", ", every sample of t' written (keep_z)" if ad.keep_z else "") + sharded}
+        out["roofline_xsolve"] = {"bound": "hbm", "kernel": ad.xsolve_desc, "achieved": b_x / t_x / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": b_x / t_x / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("xsolve"), "bytes_per_outer_iteration": b_x,
+                                  "ms_per_outer_iteration": 1e3 * t_x, "launches_per_outer_iteration": ad.xsolve_launches,
+                                  "note": "all launches of the x-solve of ONE outer iteration together: %d words per voxel%s" % (words_x, sharded)}
+        out["roofline_fixup"] = {"kernel": "halo exchange of t' + tv_admm_fixup", "ms_per_launch": 1e3 * t_fx, "traffic": traffic.get("fixup")}
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0 and not args.no_cpu_baseline:
+        if not want_live:
+            del ad, x0
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline_admm(shape, wl["reg_z"], wl["reg_time"], args.scheme, args.rho, args.n_cg)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +459,27 @@ def main():
     ap.add_argument("--tune-placement", default="default", choices=["default", "on", "off"],
                     help="solvers.ChambollePock(tune_placement=...): default = the solver's own rule")
     ap.add_argument("--phases", action="store_true", help="per-phase HIP-event times of the schedule in the JSON line (always on at N > 1)")
+    ap.add_argument("--solver", default=None, choices=["cp", "admm"], help="default: what the workload names (config4* / admm-small: admm)")
+    ap.add_argument("--rho", type=float, default=0.05, help="ADMM penalty parameter")
+    ap.add_argument("--n-cg", type=int, default=5, help="ADMM: steps of the x-solve per outer iteration")
+    ap.add_argument("--nz", type=int, default=0,
+                    help="TEST knob: run the workload with this many planes instead of its own (the rehearsals of the 8-GPU configs on one "
+                         "GPU, tests/test_gpu_rccl.py); the line's config.shape and config.workload say so")
+    ap.add_argument("--allow-single", action="store_true",
+                    help="run a workload meant for several GPUs (config3, config4) on fewer ranks than it names, memory permitting")
     args = ap.parse_args()
+    if args.solver is None:
+        args.solver = WORKLOADS[args.workload].get("solver", "cp")
+    # multi-GPU workloads are refused on fewer ranks BEFORE anything touches the GPU (exit code 2, one JSON line with the reason)
+    _wl, _world = WORKLOADS[args.workload], int(os.environ.get("WORLD_SIZE", "1"))
+    if _world < _wl.get("min_gpus", 1) and not args.allow_single:
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": METRIC[args.solver], "value": None, "unit": "it/s", "n_gpus": _world, "steps": args.steps,
+                              "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                              "data": "synthetic", "config": {"workload": args.workload},
+                              "error": "workload %s %s is a multi-GPU job (>= %d ranks); pass --allow-single to run it on %d"
+                                       % (args.workload, "x".join(map(str, _wl["shape"])), _wl["min_gpus"], _world)}), flush=True)
+        sys.exit(2)
     # must be in the environment BEFORE the HIP runtime starts (the pool's driver only supports dmabuf IPC; RCCL's
     # cross-process buffer sharing fails with hipIpcGetMemHandle: invalid argument otherwise).  Round 2 set it after
     # torch.cuda.set_device(), where it could no longer take effect.
@@ -300,6 +513,8 @@ def main():
     device = torch.device("cuda", local_rank)
     wl = WORKLOADS[args.workload]
     shape = wl["shape"]
+    if args.nz > 0:
+        shape = (args.nz,) + tuple(shape[1:])
     if args.prewarm_gb > 0:
         junk = torch.empty(int(args.prewarm_gb * (1 << 30)), dtype=torch.uint8, device=device)
         junk.fill_(1)
@@ -332,7 +547,7 @@ def main():
             assert int(probe.item()) == world, "all-reduce over %d ranks returned %r" % (world, probe.item())
     except Exception as exc:              # noqa: BLE001 -- whatever the transport throws: say so in the JSON line, fail the run
         if rank == 0:
-            print(json.dumps({"metric": "chambolle_pock_iters_per_sec", "value": None, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+            print(json.dumps({"metric": METRIC[args.solver], "value": None, "unit": "it/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                               "data": "synthetic", "config": {"workload": args.workload}, "comm": comm_name,
                               "error": "communicator setup failed on rank %d of %d (backend %s, comm %s): %s: %s"
@@ -341,6 +556,9 @@ def main():
         sys.stderr.flush()
         os._exit(3)                       # every rank that fails exits non-zero at once (no destructor tries the dead communicator)
     x0 = synth_slab(shape, slab.z0, slab.nz, device)
+    if args.solver == "admm":
+        run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, comm_name, x0, want_live)
+        return
     pkw = {}
     if args.pitch == "none":
         pkw["pitch"] = None
@@ -369,8 +587,10 @@ def main():
     cp.timing = []
     want_phases = args.phases or world > 1
 
-    barrier()
+    # (sampled BEFORE the barrier: a sysfs / rocm-smi read on rank 0 between the barrier and t0 would be time the other ranks spend
+    # waiting in their first halo exchange -- round-4 advice)
     state_before = gpu_state(local_rank) if rank == 0 else None
+    barrier()
     t0 = time.perf_counter()
     cp.run_steps(hist[W:W + K])         # K iterations (+ one plain reduction for the last iterate's fidelity, inside the timed region)
     barrier()
@@ -423,7 +643,7 @@ def main():
     bytes_iter_algo = 4.0 * (8 + 3 * nd) * V            # the README's un-fused iteration
     bytes_iter_fused = 4.0 * (6 + 3 * nd) * V           # what the two fused kernels must move
     out = {
-        "metric": "chambolle_pock_iters_per_sec", "value": it_s, "unit": "it/s", "n_gpus": world, "steps": K, "warmup": W,
+        "metric": METRIC["cp"], "value": it_s, "unit": "it/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %s fp32 %s CP" % (args.workload, "x".join(str(s) for s in shape), args.scheme),
@@ -510,7 +730,7 @@ def main():
         if not want_live:
             del cp, x0
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(shape, wl["reg_z"], wl["reg_time"], nd)
+        out["cpu_baseline"] = cpu_baseline(shape, wl["reg_z"], wl["reg_time"], nd, args.scheme)
         try:
             if world == 1:      # all host cores: only when no other rank's threads share them
                 out["cpu_baseline_openmp"] = cpu_baseline_openmp(shape, wl["reg_z"], wl["reg_time"])

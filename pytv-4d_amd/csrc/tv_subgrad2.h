@@ -47,6 +47,27 @@ __device__ __forceinline__ double from_right(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
+// the same with a value for the lane that has no source (lane 0 of a shift to the right, lane 63 of a shift to the left): the
+// dpp "old" operand with bound_ctrl off -- how the ALIGNED tiles (AL, round 5) put the ring column's value next to the edge lane
+__device__ __forceinline__ float from_left(float v, float edge) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float from_right(float v, float edge) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double from_left(double v, double edge) {
+    const long long b = __double_as_longlong(v), e = __double_as_longlong(edge);
+    const int lo = __builtin_amdgcn_update_dpp((int)e, (int)b, 0x138, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(b >> 32), 0x138, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double from_right(double v, double edge) {
+    const long long b = __double_as_longlong(v), e = __double_as_longlong(edge);
+    const int lo = __builtin_amdgcn_update_dpp((int)e, (int)b, 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(b >> 32), 0x130, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 __device__ __forceinline__ float rsq_fast(float v) { return __builtin_amdgcn_rsqf(v); }
 // fp64: v_rsq_f64 is good to ~2^-26; two Newton steps y <- y (1.5 - 0.5 v y^2) bring it to ~1 ulp
 __device__ __forceinline__ double rsq_fast(double v) {
@@ -138,7 +159,13 @@ constexpr int SG2_D = TV_SG2_D;                        // depth of the x(z+1) lo
 // drops all the mathematics takes the same 1.55 ms at 64x8x1024x1024, profiles/r3_subgrad_col_pattern.txt): 256-byte row
 // segments at a 4 KiB stride are what HBM likes least.  NWX = 2 puts two 64-column wave tiles side by side in ONE block (8 waves,
 // one block per CU: the same two waves per SIMD): their rows are 496 contiguous bytes, requested within a frame of each other.
-template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false, int NWX = 1>
+// AL (round 5): ALIGNED tiles.  A wave owns 64 columns that start on a multiple of 64 (whole 128-byte lines) and STORES all of them; the
+// column ring is not a pair of idle lanes per side any more but a RING SLOT: once per plane the 64 lanes of the wave are re-read as
+// (side, row of the strip, frame) and compute, from a few 4-byte gathers, x and 1 / |Dx| (or the finished product) of the column just
+// left / right of the strip for all R rows and M frames at once; the values reach lane 0 / lane 63 of the frame loop through LDS
+// and the "old" operand of the DPP moves.  Why: profiles/r4_sgpattern.txt (a partly written line costs 2.7 whole ones; the tile
+// without its column ring runs in 0.99 instead of 1.77 ms) and profiles/r5_sgpattern_ring_slot.txt (the same with the gathers: 1.14 ms).
+template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false, int NWX = 1, bool AL = false>
 struct SgCol {
     static constexpr bool CEN = (S == CENTRAL);
     static constexpr bool UP = (S == UPWIND || S == HYBRID), DN = (S == DOWNWIND || S == HYBRID);
@@ -147,7 +174,10 @@ struct SgCol {
     // schemes whose norm looks both ways); columns: a lane's norm needs x of BOTH neighbouring lanes for hybrid / central, so
     // x is valid on lanes 0..63, 1/|Dx| on 1..62 and G on 2..61; upwind / downwind look one way only: G on 1..62
     static constexpr int RING = HALO ? 2 : 1;
-    static constexpr int RB = R * NW, UR = RB - 2, UC = 64 - 2 * RING;
+    static constexpr int RINGL = AL ? 0 : RING;                // ring LANES per side (AL: none)
+    static constexpr int RB = R * NW, UR = RB - 2, UC = 64 - 2 * RINGL;
+    static_assert(!AL || (!TWIN && 2 * R * M <= 64 && R >= 2), "ring slot: lane = (side, row, frame)");
+    static constexpr int QS = 2 * 2 * R;                       // ring-slot hand-off, elements per frame: [side][quantity][row]
     static constexpr int H = (SG2_D < M) ? SG2_D : M;          // frames of the next plane requested before a step starts
     static constexpr bool HEADS = (M % SG2_D != 0);            // M a multiple of the ring depth: the ring slot of a frame never changes, no staging registers
     static constexpr int ROWS = 2 * NW + 1, ZR = 2 * NW;       // hand-off rows per (parity, frame): two per wave + one row of zeros
@@ -158,6 +188,11 @@ struct SgCol {
         // first / last wave of the block reads instead of a neighbour: no select, no multiplier)
         T xe[NWX][XLD ? 1 : 2][XLD ? 1 : M][XLD ? 1 : ROWS][64];       // [wave column] x of plane z (parity z & 1); XLD: unused
         T ye[NWX][2][M][ROWS][64];  // row products of step z: [2 w] for the wave above, [2 w + 1] for the wave below
+        // AL: what the ring slot of a wave hands to its frame loop: x of the ring column (quantity 0) and its product / 1 / |Dx|
+        // (quantity 1), per frame, side and row; qz: zeros of the same shape (what lanes 1 .. 62 read), qdump: where the idle ring lanes write
+        alignas(16) T qb[AL ? NW * NWX : 1][AL ? M : 1][2][2][R];
+        alignas(16) T qz[AL ? M : 1][2][2][R];
+        T qdump[AL ? 64 + R : 1];
         double sm[16];
     };
 
@@ -190,7 +225,7 @@ struct SgCol {
         const int cx = (tile_x * NW + wv) * 64 + lane;
         const int yb = tile_y * R;
 #else
-        const int cx = tile_x * UC - RING + lane;
+        const int cx = tile_x * UC - RINGL + lane;
         const int yb = tile_y * UR - 1 + wv * R;               // first row of this wave's strip
 #endif
         const bool in_x = FAST || (cx >= 0 && cx < g.nx);
@@ -198,7 +233,7 @@ struct SgCol {
         // give 0), soff = where it STORES (only sites the tile owns: not the ring, not outside the frame)
         unsigned roff[R], soff[R];
         C mi, mfr, mbr, mfc, mbc, mft, cm;
-        const bool lane_ok = in_x && (TV_SG2_WIDE || (lane >= RING && lane <= 63 - RING));
+        const bool lane_ok = in_x && (TV_SG2_WIDE || (lane >= RINGL && lane <= 63 - RINGL));
 
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -220,7 +255,9 @@ struct SgCol {
                 roff[i] = (y >= 0 && y < g.ny && ca < g.rp) ? (unsigned)(((long long)y * g.rp + ca) * (long long)sizeof(T)) : SG2_OOB;
             }
 #endif
-            cm.v[i] = own ? T(1) : T(0);
+            // AL: every lane of the strip owns its columns, and a lane outside the frame holds zeros (sum of squares 0 -> norm 0 by the
+            // zero-gradient rule): the mask of the TV sum is the wave-uniform "not a ring row" (scalar registers instead of R vector ones)
+            cm.v[i] = AL ? ((!(wv == 0 && i == 0) && !(wv == NW - 1 && i == R - 1)) ? T(1) : T(0)) : (own ? T(1) : T(0));
             // border multipliers of the generic variant: mi: site exists; mfr / mbr: it has a next / previous row; mfc / mbc:
             // a next / previous column (central: both, for a difference to exist)
             const bool hn = in && (ROWS_IN || y + 1 < g.ny), hp = in && (ROWS_IN || y > 0), cn = in && (cx + 1 < g.nx), cp = in && (cx > 0);
@@ -253,6 +290,62 @@ struct SgCol {
         if (XLD && in_x) {
             if ((DN || CEN) && yb > 0 && (wv > 0 || HALO)) uoff = (unsigned)(((long long)(yb - 1) * g.rp + cx) * (long long)sizeof(T));
             if ((UP || CEN) && yb + R < g.ny && (wv < NW - 1 || HALO)) doff = (unsigned)(((long long)(yb + R) * g.rp + cx) * (long long)sizeof(T));
+        }
+        // ---- AL: the ring slot ----------------------------------------------------------------------------------------------------
+        // lane = (side, row of the strip, frame): side 0 = the column LEFT of the strip (c0 - 1), side 1 = the column RIGHT of it
+        // (c0 + 64); 8 lanes per row (frames), 32 per side.  What each scheme needs there: upwind the finished product f_c / |Dx| of
+        // the left column (and x of the right one), downwind the mirror image, central the product on both sides, hybrid the left
+        // product and 1 / |Dx| of the right column -- always x of the ring column itself.  Inputs: 4-byte gathers (one descriptor per
+        // plane, the frame offset rides in the lane offset), requested a whole plane step ahead: r?n = plane zl + 1, r? = plane zl.
+        constexpr bool R_NEED_O = AL && HALO;                    // the column beyond the ring column
+        constexpr bool R_NEED_UP = AL && (DN || CEN), R_NEED_DN = AL && (UP || CEN);
+        const int r_side = lane >> 5, r_i = (lane >> 3) & 3, r_t = lane & 7;
+        const bool r_lane = AL && r_i < R && r_t < M;
+        const int r_c0 = tile_x * 64, r_dir = r_side ? 1 : -1;
+        const int r_c = r_side ? r_c0 + 64 : r_c0 - 1, r_y = yb + r_i;
+        const bool r_in = r_lane && r_c >= 0 && r_c < g.nx && (ROWS_IN || (r_y >= 0 && r_y < g.ny));
+        // the side whose 1 / |Dx| is needed (the other side only hands x over)
+        const bool r_norm = r_in && (HALO || (UP && r_side == 0) || (DN && S != HYBRID && r_side == 1));
+        unsigned go_c = SG2_OOB, go_o = SG2_OOB, go_i = SG2_OOB, go_h = SG2_OOB;
+        T r_mi = T(0), r_mfr = T(0), r_mbr = T(0), r_mfc = T(0), r_mbc = T(0), r_mtn = T(0), r_mtp = T(0), r_wt = T(0);
+        if constexpr (AL) {
+            const unsigned fo = (unsigned)r_t * (unsigned)fbytes;
+            auto off = [&](int y, int c) -> unsigned {
+                return (c >= 0 && c < g.nx && y >= 0 && y < g.ny) ? fo + (unsigned)(((long long)y * g.rp + c) * (long long)sizeof(T)) : SG2_OOB;
+            };
+            if (r_in) go_c = off(r_y, r_c);
+            if (r_norm) {
+                if (R_NEED_O) go_o = off(r_y, r_c + r_dir);
+                go_i = off(r_y, r_c - r_dir);
+                if (R_NEED_UP && r_i == 0) go_h = off(r_y - 1, r_c);
+                if (R_NEED_DN && r_i == R - 1) go_h = off(r_y + 1, r_c);
+            }
+            const bool hn = r_in && (ROWS_IN || r_y + 1 < g.ny), hp = r_in && (ROWS_IN || r_y > 0), cn = r_in && r_c + 1 < g.nx, cp = r_in && r_c > 0;
+            r_mi = r_in ? T(1) : T(0);
+            r_mfr = (CEN ? (hn && hp) : hn) ? T(1) : T(0);
+            r_mbr = (CEN ? (hn && hp) : hp) ? T(1) : T(0);
+            r_mfc = (CEN ? (cn && cp) : cn) ? T(1) : T(0);
+            r_mbc = (CEN ? (cn && cp) : cp) ? T(1) : T(0);
+            const bool tn = r_in && (r_t + 1 < M), tp = r_in && (r_t > 0);
+            r_mtn = (CEN ? (tn && tp) : tn) ? T(1) : T(0);
+            r_mtp = (CEN ? (tn && tp) : tp) ? T(1) : T(0);
+            if (g.ta && r_in) r_wt = w.wt * ((g.mask != nullptr || g.tf != nullptr) ? mask_factor1<T>(g, w.sf, r_y, r_c) : T(1));
+        }
+        // state: rc = x(zl) of the ring site, rcn = x(zl + 1) (needed a plane early for the z difference), ro / ri / rh = the outer /
+        // inner column and the halo row of plane zl -- requested one step ahead, together with the centre of the plane after
+        T rc = T(0), ro = T(0), ri = T(0), rh = T(0), rcn = T(0), rpz = T(0);
+        auto ring_ld_c = [&](const T* plane, T& c_) { c_ = sg2_ld(sg2_rsrc<T>(plane, plane != nullptr, fbytes * M), go_c, T(0)); };
+        auto ring_ld_n = [&](const T* plane, T& o_, T& i_, T& h_) {
+            const Rsrc rs = sg2_rsrc<T>(plane, plane != nullptr, fbytes * M);
+            if (R_NEED_O) o_ = sg2_ld(rs, go_o, T(0));
+            i_ = sg2_ld(rs, go_i, T(0));
+            h_ = sg2_ld(rs, go_h, T(0));
+        };
+        // where the ring lanes put their results and where the lanes of the frame loop find them (lanes 1 .. 62: zeros)
+        T* const qw = r_lane ? &sh.qb[AL ? wid : 0][AL ? r_t : 0][r_side][0][r_i] : &sh.qdump[AL ? lane : 0];
+        const T* const qr = (lane == 0) ? &sh.qb[AL ? wid : 0][0][0][0][0] : ((lane == 63) ? &sh.qb[AL ? wid : 0][0][1][0][0] : &sh.qz[0][0][0][0]);
+        if (AL && wid == 0) {
+            for (int k = lane; k < M * QS; k += 64) (&sh.qz[0][0][0][0])[k] = T(0);
         }
         // LDS hand-off rows: own pair, the neighbour's row above / below (the zero row at the block's ends)
         const int r_own = 2 * wv, r_up = (wv > 0) ? 2 * (wv - 1) + 1 : ZR, r_dn = (wv < NW - 1) ? 2 * (wv + 1) : ZR;
@@ -316,6 +409,21 @@ struct SgCol {
 #pragma unroll
             for (int d = 0; d < H; ++d) load_rows(frame(pn, d), HEADS ? Nh[HEADS ? d : 0] : Nq[d]);
         }
+        if constexpr (AL) {
+            // plane z_lo (current), z_lo + 1 (next); the z carry of the ring column like Pz of the strip
+            const T* pp = g.za ? zplane<T>(g, x, xp, xn, 2, z_lo - 1) : nullptr;
+            const T* pc = zplane<T>(g, x, xp, xn, 2, z_lo);
+            ring_ld_c(pc, rc);
+            ring_ld_n(pc, ro, ri, rh);
+            if (PZ) {
+                const Rsrc rs = sg2_rsrc<T>(pp, pp != nullptr, fbytes * M);
+                const T pv = sg2_ld(rs, go_c, T(0));
+                const int gz0 = g.z0 + z_lo;
+                const bool zp0 = (gz0 > 0) && (gz0 < g.nzg) && g.za;
+                rpz = CEN ? pv : (zp0 ? wz_u : T(0)) * (rc - pv) * r_mi;
+            }
+            ring_ld_c(next_plane(z_lo), rcn);
+        }
         __syncthreads();
         // plane zl+1 exists in memory for this call iff it is a local plane or a supplied halo plane: same answer as zplane(),
         // but for the CURRENT plane of the next step it was already computed as this step's "next" unless the chunk did not need it
@@ -358,11 +466,64 @@ struct SgCol {
 #pragma unroll
                 for (int d = 0; d < H; ++d) Nq[d] = Nh[HEADS ? d : 0];
             }
+            if constexpr (AL) {
+                // ---- ring slot of plane zl: the same differences, masks and zero-gradient rule as a site of the strip, one site per lane
+                T x_up = T(0), x_dn = T(0);
+                if (R_NEED_UP) { const T sh_ = __shfl_up(rc, 8, 64); x_up = (r_i == 0) ? rh : sh_; }
+                if (R_NEED_DN) { const T sh_ = __shfl_down(rc, 8, 64); x_dn = (r_i == R - 1) ? rh : sh_; }
+                const T x_l = r_side ? ri : ro, x_r = r_side ? ro : ri;           // x(r_c - 1), x(r_c + 1)
+                const T xtn = from_right(rc), xtp = from_left(rc);                // frame t + 1 / t - 1: the neighbouring lanes
+                const T wti = r_wt * m_pl;
+                T ss_r, fc_r = T(0), bc_r = T(0), fz_r;
+                if (CEN) {
+                    const T fr = (x_dn - x_up) * (r_mfr * m_pl);
+                    fc_r = (x_r - x_l) * (r_mfc * m_pl);
+                    fz_r = wzn * (rcn - rpz) * r_mi;
+                    const T ft = (r_mtn * wti) * (xtn - xtp);
+                    T a_ = fr * fr + fc_r * fc_r;
+                    a_ = a_ + fz_r * fz_r;
+                    a_ = a_ + ft * ft;
+                    ss_r = a_;
+                } else {
+                    const T fr = (x_dn - rc) * (r_mfr * m_pl), br = (rc - x_up) * (r_mbr * m_pl);
+                    fc_r = (x_r - rc) * (r_mfc * m_pl);
+                    bc_r = (rc - x_l) * (r_mbc * m_pl);
+                    fz_r = wzn * (rcn - rc) * r_mi;
+                    const T bz = DN ? rpz : T(0);
+                    const T ft = (r_mtn * wti) * (xtn - rc), bt = (r_mtp * wti) * (rc - xtp);
+                    T a_ = fr * fr + fc_r * fc_r;
+                    a_ = a_ + fz_r * fz_r;
+                    a_ = a_ + ft * ft;
+                    T b_ = br * br + bc_r * bc_r;
+                    b_ = b_ + bz * bz;
+                    b_ = b_ + bt * bt;
+                    ss_r = (S == HYBRID) ? a_ + b_ : ((S == DOWNWIND) ? b_ : a_);
+                }
+                const T nn = (ss_r >= thr) ? rsq_fast(ss_r) : T(0);
+                // quantity 1: what the edge lane of the strip adds -- see the scatter code of each scheme below
+                T q2;
+                if (CEN) q2 = fc_r * nn;
+                else if (S == HYBRID) q2 = r_side ? nn : fc_r * nn;
+                else if (UP) q2 = r_side ? T(0) : fc_r * nn;
+                else q2 = r_side ? bc_r * nn : T(0);
+                qw[0] = rc;
+                qw[R] = q2;
+                // carry, rotate, request plane zl + 2
+                if (CEN) rpz = rc; else if (DN) rpz = fz_r;
+                rc = rcn;
+                ring_ld_n(pn, ro, ri, rh);           // plane zl + 1: consumed at the top of the next step
+                ring_ld_c(pn2, rcn);                 // plane zl + 2
+            }
             T xu_n = T(0), xd_n = T(0), yu_n = T(0), yd_n = T(0);
             if ((DN || CEN) && !XLD) xu_n = xe[par][0][r_up][lane];
             if ((UP || CEN) && !XLD) xd_n = xe[par][0][r_dn][lane];
             if (UP || CEN) yu_n = ye[par ^ 1][0][r_up][lane];
             if (DN || CEN) yd_n = ye[par ^ 1][0][r_dn][lane];
+            C q1_n, q2_n;                           // AL: ring values of the next frame (quantity 0: x, quantity 1: product / 1 / |Dx|)
+            if constexpr (AL) {
+                q1_n = *reinterpret_cast<const C*>(qr);
+                q2_n = *reinterpret_cast<const C*>(qr + R);
+            }
             C pf_t_prev, f_t_prev, c_old_prev;      // time-axis carries: product / forward difference / x of frame t-1
 #pragma unroll
             for (int i = 0; i < R; ++i) pf_t_prev.v[i] = f_t_prev.v[i] = c_old_prev.v[i] = T(0);
@@ -370,6 +531,15 @@ struct SgCol {
             for (int t = 0; t < M; ++t) {
                 const C c = Cc[t];
                 const C nx = Nq[t % SG2_D];          // x(zl+1, t)
+                C q1, q2;
+                if constexpr (AL) {
+                    q1 = q1_n;
+                    q2 = q2_n;
+                    if (t + 1 < M) {
+                        q1_n = *reinterpret_cast<const C*>(qr + (t + 1) * QS);
+                        q2_n = *reinterpret_cast<const C*>(qr + (t + 1) * QS + R);
+                    }
+                }
                 // ---- row neighbours across the strip's ends -----------------------------------------------------------
                 T xu = xu_n, xd = xd_n;              // read from LDS one frame ahead (two waves per SIMD do not hide an LDS round trip)
                 if (t + 1 < M && !XLD) {
@@ -412,8 +582,13 @@ struct SgCol {
                 C xr, xl;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    xr.v[i] = from_right(c.v[i]);
-                    xl.v[i] = from_left(c.v[i]);
+                    if constexpr (AL) {
+                        xr.v[i] = from_right(c.v[i], q1.v[i]);      // lane 63: x of the column right of the strip
+                        xl.v[i] = from_left(c.v[i], q1.v[i]);       // lane 0: x of the column left of it
+                    } else {
+                        xr.v[i] = from_right(c.v[i]);
+                        xl.v[i] = from_left(c.v[i]);
+                    }
                 }
                 C f_r, b_r, f_c, b_c, f_z, b_z, f_t, b_t;     // weighted channels (central: f_* only)
 #pragma unroll
@@ -536,7 +711,8 @@ struct SgCol {
                         if (i + 1 < R) gc.v[(i + 1 < R) ? i + 1 : i] += p_r; else to_dn = p_r;
                         if (i > 0) gc.v[(i > 0) ? i - 1 : 0] -= p_r; else to_up = p_r;
                         const T p_c = f_c.v[i] * n.v[i];
-                        gc.v[i] += from_left(p_c) - from_right(p_c);
+                        if constexpr (AL) gc.v[i] += from_left(p_c, q2.v[i]) - from_right(p_c, q2.v[i]);
+                        else gc.v[i] += from_left(p_c) - from_right(p_c);
                         const T p_z = f_z.v[i] * n.v[i];
                         gn.v[i] = p_z;
                         Gp[t].v[i] -= p_z;
@@ -567,8 +743,16 @@ struct SgCol {
                         gc.v[R - 1] -= to_dn;
 #pragma unroll
                         for (int i = 0; i < R; ++i) {
+                            if constexpr (AL) {
+                                // lane 63: 1 / |Dx| of the column right of the strip; lane 0: the edge from the left column = its product
+                                // f_c / |Dx| (ring slot) + the same difference over this lane's own norm
+                                const T pc_ = f_c.v[i] * (n.v[i] + from_right(n.v[i], q2.v[i]));
+                                const T e0 = b_c.v[i] * n.v[i] + q2.v[i];
+                                gc.v[i] += from_left(pc_, e0) - pc_;
+                            } else {
                             const T pc_ = f_c.v[i] * (n.v[i] + from_right(n.v[i]));
                             gc.v[i] += from_left(pc_) - pc_;
+                            }
                             const T pz_f = f_z.v[i] * n.v[i], pz_b = b_z.v[i] * n.v[i];
                             gc.v[i] += pz_b - pz_f;
                             gn.v[i] = pz_f;
@@ -595,7 +779,8 @@ struct SgCol {
                             gc.v[i] -= p_r;
                             if (i + 1 < R) gc.v[(i + 1 < R) ? i + 1 : i] += p_r; else to_dn = p_r;
                             const T p_c = f_c.v[i] * n.v[i];
-                            gc.v[i] += from_left(p_c) - p_c;
+                            if constexpr (AL) gc.v[i] += from_left(p_c, q2.v[i]) - p_c;
+                            else gc.v[i] += from_left(p_c) - p_c;
                             const T p_z = f_z.v[i] * n.v[i];
                             gc.v[i] -= p_z;
                             gn.v[i] = p_z;
@@ -611,7 +796,8 @@ struct SgCol {
                             gc.v[i] += p_r;
                             if (i > 0) gc.v[(i > 0) ? i - 1 : 0] -= p_r; else to_up = p_r;
                             const T p_c = b_c.v[i] * n.v[i];
-                            gc.v[i] += p_c - from_right(p_c);
+                            if constexpr (AL) gc.v[i] += p_c - from_right(p_c, q2.v[i]);
+                            else gc.v[i] += p_c - from_right(p_c);
                             const T p_z = b_z.v[i] * n.v[i];
                             gc.v[i] += p_z;
                             Gp[t].v[i] -= p_z;
@@ -733,11 +919,11 @@ __device__ __forceinline__ void sg2_tile(const SgTiles& tm, bool fast, long long
     }
 }
 
-template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false, int NWX = 1>
+template <int S, typename T, int M, int R, int NW, int MODE, bool TWIN, bool XLD = false, int NWX = 1, bool AL = false>
 __global__ __launch_bounds__(64 * NW * NWX, (NW * NWX >= 16) ? 1 : 2) void k_subgrad_col(DG g, WT<T> w, const T* __restrict__ x, const T* __restrict__ xp,
                                                                             const T* __restrict__ xn, T* __restrict__ G, int zchunk, int nchunks,
                                                                             double* __restrict__ partials, SgArgs2<T> sa, SgTiles tm) {
-    using K = SgCol<S, T, M, R, NW, MODE, TWIN, XLD, NWX>;
+    using K = SgCol<S, T, M, R, NW, MODE, TWIN, XLD, NWX, AL>;
     __shared__ typename K::Shared sh;
     const int Mg = TWIN ? g.m : M;
     const int nwin = TWIN ? (Mg + SG2_TWU - 1) / SG2_TWU : 1;

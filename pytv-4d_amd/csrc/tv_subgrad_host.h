@@ -67,22 +67,32 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
 #ifndef TV_SG2_NW32
 #define TV_SG2_NW32 4
 #endif
-    constexpr int R = F64 ? 2 : TV_SG2_R32, NW = F64 ? 4 : TV_SG2_NW32;
+    constexpr int R = F64 ? 2 : TV_SG2_R32;
 #ifndef TV_SG2_NWX
 #define TV_SG2_NWX 2
 #endif
-    constexpr int NWX = F64 ? 1 : TV_SG2_NWX;         // fp32: two wave tiles side by side per block (8 waves, one block per CU)
 #ifndef TV_SG2_XLD32
 #define TV_SG2_XLD32 0
 #endif
+#ifndef TV_SG2_AL
+#define TV_SG2_AL 1            // round 5: aligned 64-column tiles with a ring slot (tv_subgrad2.h, AL): 1 = instantiated for the one-sided schemes (where they win), 2 = for all four (experiments), 0 = not at all
+#endif
     constexpr bool XLD = F64 || TV_SG2_XLD32;
+    // ALIGNED tiles (round 5): fp32, every frame in registers (M <= 8), no per-voxel weight volume (the ring slot does not read one),
+    // a plane of M frames below 2^31 bytes (one buffer descriptor per plane); TV_SG_ALIGNED=0 switches back at run time (A/B).
+    // A block is then 8 waves STACKED (32 rows x 64 columns, 30 x 64 stored); otherwise the round-3 tile: 4 x 2 waves, 16 x 128.
+    // Used for UPWIND / DOWNWIND: same-box A/B (profiles/r5_subgrad_aligned_ab.txt), descent loop at 256x8x1024x1024 148 -> 166 it/s, the
+    // norms variant at 64 planes 1.61 - 1.79 -> 1.49 ms, tv_subgrad_fused unchanged (1.17 - 1.26 ms).  NOT for hybrid / central: their
+    // instantiations are at the register limit already (245 - 248 VGPRs), the ring slot's ~30 registers spill (128 / 28 B per lane) and
+    // cost more than the whole lines gain (hybrid 1.61 -> 1.95 ms, loop 142 -> 99 it/s).  TV_SG_ALIGNED=0: off; =2: every scheme a
+    // -DTV_SG2_AL=2 build instantiates.
+    const int al_opt = env_int("TV_SG_ALIGNED", 1);
+    const bool al_scheme = (g->scheme == TV_UPWIND || g->scheme == TV_DOWNWIND) ? (al_opt != 0) : (TV_SG2_AL == 2 && al_opt == 2);
+    const bool al = !F64 && TV_SG2_AL && al_scheme && d.m <= SG2_TWN && d.wv == nullptr && d.s_t * (long long)sizeof(T) * d.m < (1ll << 31);
+    const int NW = F64 ? 4 : (al ? 8 : TV_SG2_NW32), NWX = F64 ? 1 : (al ? 1 : TV_SG2_NWX);
     const long long nmax = max_partials(d);
     const bool halo = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL);
-#if TV_SG2_WIDE
-    const int UR = R, UC = 64 * NW;
-#else
-    const int UR = R * NW - 2, UC = halo ? 60 : 62;
-#endif
+    const int UR = R * NW - 2, UC = al ? 64 : (halo ? 60 : 62);
     const long long tx = (d.nx + UC - 1) / UC, ty = (d.ny + UR - 1) / UR;
     const long long nwin = (d.m > SG2_TWN) ? (d.m + SG2_TWU - 1) / SG2_TWU : 1;
     // planes per z-chunk (TV_ZCHUNK overrides): 16.  A chunk computes two extra planes of norms, so longer chunks waste less
@@ -107,8 +117,8 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
     SgTiles tm{};
     tm.tx = (int)txb; tm.ty = (int)ty;
     int ix0 = 1, ix1 = (int)((d.nx - 2 - 63 + RING) / UC), iy0 = 1, iy1 = (int)((d.ny - RB) / UR);
-    if (TV_SG2_WIDE) { ix1 = (int)tx - 1; ix0 = 0; iy0 = 0; iy1 = (int)ty - 1; }
-    else if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || d.wv != nullptr || ix1 < ix0 || iy1 < iy0 || env_int("TV_SPARE", 0) == 7) { ix0 = iy0 = 1; ix1 = iy1 = 0; }   // (TV_SPARE=7: experiment, every block generic)
+    if (al) ix1 = (d.nx - 1) / 64 - 1;          // lanes 0 .. 63 of the tile have both column neighbours: c0 >= 1 and c0 + 64 <= nx - 1
+    if (d.nx < 66 || d.ny < RB + 2 || d.mask != nullptr || d.tf != nullptr || d.wv != nullptr || ix1 < ix0 || iy1 < iy0 || env_int("TV_SPARE", 0) == 7) { ix0 = iy0 = 1; ix1 = iy1 = 0; }   // (TV_SPARE=7: experiment, every block generic)
     if (ix1 >= ix0) {            // wave-tile columns [ix0, ix1] -> block-tile columns whose NWX wave tiles all lie inside
         const int b0 = (ix0 + NWX - 1) / NWX, b1 = (ix1 + 1) / NWX - 1;
         ix0 = b0; ix1 = b1;
@@ -128,8 +138,16 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
     int rc = dispatch_sg(g->scheme, d.m > SG2_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
         constexpr int MM = (M == 0) ? SG2_TWN : M;
         constexpr bool TW = (M == 0);
-        hipLaunchKernelGGL((k_subgrad_col<S, T, MM, R, NW, MODE, TW, XLD, NWX>), dim3((unsigned)ngrid), block, 0, st, d, make_w<T>(g),
-                           (const T*)x, (const T*)x_prev, (const T*)x_next, (T*)G, zc, (int)nch, w0, sa, tm);
+        if constexpr (!F64 && !TW && (TV_SG2_AL == 2 || (TV_SG2_AL == 1 && (S == UPWIND || S == DOWNWIND)))) {
+            if (al) {
+                hipLaunchKernelGGL((k_subgrad_col<S, T, MM, R, 8, MODE, false, XLD, 1, true>), dim3((unsigned)ngrid), block, 0, st, d, make_w<T>(g),
+                                   (const T*)x, (const T*)x_prev, (const T*)x_next, (T*)G, zc, (int)nch, w0, sa, tm);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
+        }
+        hipLaunchKernelGGL((k_subgrad_col<S, T, MM, R, (F64 ? 4 : TV_SG2_NW32), MODE, TW, XLD, (F64 ? 1 : TV_SG2_NWX)>), dim3((unsigned)ngrid), block, 0, st, d,
+                           make_w<T>(g), (const T*)x, (const T*)x_prev, (const T*)x_next, (T*)G, zc, (int)nch, w0, sa, tm);
         HIP_TRY(hipGetLastError());
         return 0;
     });

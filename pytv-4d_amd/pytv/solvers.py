@@ -70,7 +70,7 @@ def auto_pitch(ny, nx, dtype, frame_pad_bytes=0):
     a quarter more bytes and measured SLOWER (256 x 4 x 100 x 100: 0.33 against 0.27 ms) -- only ragged rows (Nx not a multiple
     of the 16-byte lane) are rounded up to the lane, which takes them off the scalar-lane kernels.
     frame_pad_bytes: extra bytes between frames (round 4 measured that de-aliasing the frame pitch does NOT move the one-sweep
-    kernel: tools/bwtest4, tools/alias_probe.py, profiles/r4_stream_aliasing.txt; kept as an argument for experiments)."""
+    kernel: tools/bwtest4, tools/alias_probe.py, profiles/r4_alias_probe.txt, profiles/r4_bwtest4_frame_pitch.txt; kept as an argument for experiments)."""
     es = 4 if dtype == torch.float32 else 8
     lane = 16 // es
     nx, ny = int(nx), int(ny)
@@ -277,11 +277,13 @@ class ChambollePock(_SlabProblem):
                 # holds a slab of the single-GPU size and plays the same placement lottery)
                 tune_placement = img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
             if tune_placement:
-                keep = (self.x, self.x_alt, self.p, self.q)
+                # (q is NOT pinned here: the tuner keeps exactly one q bound at any time -- the best so far -- and at most one
+                # candidate beside it, so that a winning candidate frees the original before the next one is allocated; round-4 advice)
+                keep = (self.x, self.x_alt, self.p, self.x0)
                 try:
                     self._tune_x_placement()
                 except RuntimeError as exc:       # out of memory while holding the candidates, ...: the tuner is an optimisation, never a failure
-                    self.x, self.x_alt, self.p, self.q = keep
+                    self.x, self.x_alt, self.p, self.x0 = keep
                     self._lag = None
                     self.x.copy_(self.x0)
                     self.p.zero_()
@@ -350,16 +352,21 @@ class ChambollePock(_SlabProblem):
             # sweep (profiles/r4_bench_northstar_first_command_e.json: round trips 67.3 vs 63.5 ms)
             best_q, best_t = self.q, round_trip(x_a, x_b)
             info["q_round_trip_ms"] = [round(best_t, 3)]
-            for _ in range(2):
-                cand = self.new_grad()
-                self.q = cand
-                t2 = round_trip(x_a, x_b)
-                info["q_round_trip_ms"].append(round(t2, 3))
-                if t2 < best_t:
-                    best_q, best_t = cand, t2
+            try:
+                for _ in range(2):
+                    cand = self.new_grad()
+                    self.q = cand
+                    t2 = round_trip(x_a, x_b)
+                    info["q_round_trip_ms"].append(round(t2, 3))
+                    if t2 < best_t:
+                        best_q, best_t = cand, t2
+                    self.q = best_q                  # the loser (the original included) loses its last reference here
+                    del cand
+                    torch.cuda.empty_cache()
+            except RuntimeError as exc:              # no room for another candidate: keep the best q measured so far, go on with the images
                 self.q = best_q
-                del cand
                 torch.cuda.empty_cache()
+                info["q_error"] = str(exc)[:160]
             del best_q
         # ---- the image pair: every ordered pair of the candidates ------------------------------------------------------------------
         cands = [x_a, x_b] + [self.new_image() for _ in range(n_extra)]
@@ -656,7 +663,10 @@ class ChambollePock(_SlabProblem):
         return done
 
     def result(self):
-        return self.x
+        """The iterate as a DENSE (Nz, M, Ny, Nx) tensor: with padded state (``pitch``) a contiguous copy -- callers that ``.view(-1)``
+        it, take its ``data_ptr()`` or hand it to the dense ``tv_*`` entry points must not see pad columns (round-4 advice); ``.x``
+        stays the raw (possibly strided) view of the solver's storage."""
+        return self.x.contiguous() if self.pitch != (0, 0) else self.x
 
 
 # =================================================================================================
@@ -779,7 +789,10 @@ class ChambollePockOperator(_SlabProblem):
         return h[:, 1] + self.reg * h[:, 0]
 
     def result(self):
-        return self.x
+        """The iterate as a DENSE (Nz, M, Ny, Nx) tensor: with padded state (``pitch``) a contiguous copy -- callers that ``.view(-1)``
+        it, take its ``data_ptr()`` or hand it to the dense ``tv_*`` entry points must not see pad columns (round-4 advice); ``.x``
+        stays the raw (possibly strided) view of the solver's storage."""
+        return self.x.contiguous() if self.pitch != (0, 0) else self.x
 
 
 # =================================================================================================
@@ -986,7 +999,10 @@ class SubgradientDescent(_SlabProblem):
         return done
 
     def result(self):
-        return self.x
+        """The iterate as a DENSE (Nz, M, Ny, Nx) tensor: with padded state (``pitch``) a contiguous copy -- callers that ``.view(-1)``
+        it, take its ``data_ptr()`` or hand it to the dense ``tv_*`` entry points must not see pad columns (round-4 advice); ``.x``
+        stays the raw (possibly strided) view of the solver's storage."""
+        return self.x.contiguous() if self.pitch != (0, 0) else self.x
 
 
 # =================================================================================================
@@ -1005,7 +1021,13 @@ class ADMM(_SlabProblem):
     (t = z - u, u) so that the right-hand side reads one gradient array: 4 Nd + 11 n_cg + 5 words per voxel and outer
     iteration instead of 5 Nd + 11 n_cg + 17 (76 instead of 92 for Nd = 4, n_cg = 5).  ``single_reduction=False`` is the
     textbook recurrence of round 1 (tv_cg_step1 / tv_cg_step2).  Both are the same iteration in exact arithmetic;
-    oracle.admm restates both."""
+    oracle.admm restates both.
+
+    DEFAULTS THAT CHANGED IN ROUND 4 (existing callers get different -- equally valid -- iterates): ``x_solver=None`` runs the x-solve
+    as ``n_cg`` Chebyshev steps instead of CG (same objective to 6 - 7 digits at every outer iteration, profiles/
+    r4_admm_xsolve_study_f32.txt; ``x_solver="cg"`` is the old behaviour), ``keep_z=True`` stores every sample of t' so that ``.z`` works on
+    the one-sweep path (``keep_z=False`` moves Nd fewer words per voxel), and ``pitch="auto"`` pads ragged rows: ``.x`` is then a strided
+    view of padded storage, ``result()`` a dense copy."""
 
     def __init__(self, x0, regularization, rho, n_cg=10, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
                  mask_static=False, factor_reg_static=0, slab=None, single_reduction=True, fused=None, keep_z=True, x_solver=None,
@@ -1028,7 +1050,8 @@ class ADMM(_SlabProblem):
         if x_solver is None:
             x_solver = "chebyshev" if (self.single and self.n_cg > 0) else "cg"
         if x_solver not in ("cg", "chebyshev"):
-            raise ValueError("x_solver must be None, 'cg' or 'chebyshev'")
+            raise ValueError("x_solver must be None (the default since round 4: 'chebyshev' wherever it applies, i.e. single_reduction and "
+                             "n_cg > 0), 'cg' (the behaviour of rounds 1 - 3) or 'chebyshev'")
         self.cheb = (x_solver == "chebyshev")
         if self.cheb and not (self.single and self.n_cg > 0):
             raise ValueError("x_solver='chebyshev' needs single_reduction=True (the default) and n_cg > 0")
@@ -1070,6 +1093,8 @@ class ADMM(_SlabProblem):
         self.dots3 = torch.zeros((3, 2), dtype=torch.float64, device=self.device)
         self.dots = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.rr = torch.zeros(2, dtype=torch.float64, device=self.device)     # <r, r> of the sweep / of the fix-up
+        self.timing = None      # set to a list to collect one list of (name, HIP event) per outer iteration (bench.py --solver admm)
+        self._marks = None
         self.placement = None
         set_bytes = sum(getattr(self, k).numel() for k in self._STATE) * self.x.element_size()
         if tune_placement is None:
@@ -1079,6 +1104,32 @@ class ADMM(_SlabProblem):
             self._tune_placement()
 
     _STATE = ("x", "_zt", "u", "b", "r", "d", "Ad")      # the arrays an outer iteration streams through
+
+    # ---- what the x-solve of one outer iteration moves (bench.py's roofline_xsolve) ----------------------------------------------
+    @property
+    def xsolve_words(self):
+        """Algorithmic words per voxel of the x-solve of ONE outer iteration (every array a launch touches counted once).
+        Chebyshev, K = n_cg steps: e_1 = a0 r is never stored -- e_2 from r alone (2), a step with y = a0 r formed on the fly (3),
+        K - 4 plain steps (e_k with its stencil, r, e_{k-1} read; e_{k+1} written: 4) and a last step that adds x (5): 4 K - 6.
+        CG (single reduction): normal operator on r (2) + the fused update of four vectors (9) per step."""
+        K = self.n_cg
+        if self.cheb:
+            return 3 if K == 1 else 4 * K - 6
+        return 11 * K if self.single else 11 * K + 4
+
+    @property
+    def xsolve_launches(self):
+        K = self.n_cg
+        if self.cheb:
+            return 1 if K == 1 else K - 1
+        return 2 * K
+
+    @property
+    def xsolve_desc(self):
+        if self.cheb:
+            return ("tv_cheb_step: k_normal_stream<M,TWIN,T,CHEB> (%d launches: e_{k+1} = e_k + alpha (r - (I + rho D^T D) e_k) + beta (e_k - e_{k-1}), "
+                    "one streaming pass each)" % self.xsolve_launches)
+        return "tv_normal_op2 + tv_cg_update (%d launches)" % self.xsolve_launches
 
     def _reset_state(self):
         """Back to the state of a fresh solver (x = x0, everything else zero) in the arrays that are bound now."""
@@ -1113,11 +1164,13 @@ class ADMM(_SlabProblem):
         def bound():                                 # the buffer roles rotate inside a step: take what is bound NOW
             return {k: getattr(self, k) for k in self._STATE}
 
-        best_t = timed()
-        best = bound()
-        times = [round(best_t, 3)]
-        info = {}
+        # the WHOLE tuner is an optimisation, never a failure (round-4 advice: the baseline measurement used to sit outside the try --
+        # an out-of-memory error in a halo or Chebyshev temporary there failed the constructor)
+        best, best_t, times, info = bound(), float("inf"), [], {}
         try:
+            best_t = timed()
+            best = bound()
+            times.append(round(best_t, 3))
             for _ in range(n_sets - 1):
                 cand = dict(x=self.new_image(), _zt=self.new_grad(), u=self.new_grad(), b=self.new_image(), r=self.new_image(),
                             d=self.new_image(), Ad=self.new_image())
@@ -1139,7 +1192,7 @@ class ADMM(_SlabProblem):
             info["error"] = str(exc)[:200]
         self._reset_state()
         torch.cuda.synchronize(self.device)
-        info.update({"outer_ms": times, "chosen": times.index(min(times)), "seconds": round(_time.perf_counter() - t_begin, 3)})
+        info.update({"outer_ms": times, "chosen": times.index(min(times)) if times else None, "seconds": round(_time.perf_counter() - t_begin, 3)})
         self.placement = info
 
     @property
@@ -1310,6 +1363,7 @@ class ADMM(_SlabProblem):
                                     (1 if self.keep_z else 0) | (2 if out_fid is not None else 0),
                                     0, -1, out_tv.data_ptr(), (out_fid if out_fid is not None else self.rr[0:1]).data_ptr(),
                                     _nv.ptr(self.ws), self.stream))
+        self._mark("sweep")
         # the boundary planes of t' travel to the neighbours (as those of t = z - u do in _rhs)
         h = s.exchange(send_prev=self._zt[0, self.ch_fwd] if self.plan.g_send_prev else None,
                        send_next=self._zt[nz - 1, self.ch_back] if self.plan.g_send_next else None,
@@ -1322,7 +1376,24 @@ class ADMM(_SlabProblem):
             torch.sum(self.rr, dim=0, keepdim=True, out=self.sc[0:1])
         self._have_r = True
 
+    def _mark(self, name):
+        """A HIP event on the launch stream (torch's current stream == the stream the C-ABI enqueues on), only while ``timing`` is a list."""
+        if self._marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._marks.append((name, e))
+
     def _step_single(self, out):
+        if self.timing is None:
+            return self._step_single_body(out)
+        self._marks = []
+        self._mark("start")
+        self._step_single_body(out)
+        self._mark("end")
+        self.timing.append(self._marks)
+        self._marks = None
+
+    def _step_single_body(self, out):
         g, lib, s = self.geo, self.lib, self.slab
         sc, w, sv = self.sc, self.b, self.Ad          # w = A r lives in b (free once r is formed), s = A d in Ad
         if not (self.fused and self._have_r):
@@ -1334,6 +1405,7 @@ class ADMM(_SlabProblem):
         if self.cheb:
             if self.fused:      # the sweep that follows reads x and x0 anyway: it returns |x - x0|^2, the solve's last step skips x0
                 self._solve_cheb(None)
+                self._mark("xsolve")
                 self._zu_fused(out[0:1], out[1:2])
             else:
                 self._solve_cheb(out[1:2])

@@ -10,7 +10,7 @@
 // (8 or 16 waves) per CU.
 //
 // build: hipcc -O3 --offload-arch=gfx950 -o tools/sgpattern tools/sgpattern.hip        run: tools/sgpattern [nz m ny nx] [config ...]
-// config = LR,LC,WX,NWY,NWX,ry,rx,halo,zc,ovl,ovh,grid,xcd[,nt[,rl]]   (grid > 0: balanced mode with that many blocks, zc ignored;
+// config = LR,LC,WX,NWY,NWX,ry,rx,halo,zc,ovl,ovh,grid,xcd[,nt[,rl[,dd,dl,hd,ustride,xoff[,rg]]]]   (grid > 0: balanced mode with that many blocks, zc ignored;
 // nt: the aux (cache policy) bits of the stores -- 1 sc0, 2 nt, 16 sc1 and their sums; rl: ring columns loaded per side, the remaining ring lanes idle -- an ALIGNED tile with a narrow ring)
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -73,12 +73,14 @@ struct Geo {
     int rl;                    // ring columns actually LOADED per side (<= rx: the other ring lanes idle, their offsets out of range)
     int hd;                    // depth of the halo-row ring (0: same as dd)
     int ustride, xoff;         // EXPERIMENT: column stride / origin of the tiles other than UC / -rx (leaves columns unwritten: alignment tests)
+    int rg;                    // round 5: GATHERS per wave and plane step -- the ring columns of a wave's aligned 64-column strip fetched by a 64-lane
+                               // 'mini slot' (lane = side, row, frame) instead of by ring lanes: 4-byte loads from the neighbouring tiles' lines
     int dd, dl;                // depth of the register load ring (frames ahead); dl > 0: the LDS-DMA variant with dl ring slots per wave
     int tx, ty, nchunks;       // derived: tile grid, chunks
     float zero;
 };
 
-template <int LR, int LC, int D, int NT, int HD = D>
+template <int LR, int LC, int D, int NT, int HD = D, int RG = 0>
 __global__ __launch_bounds__(1024, 1) void k_pattern(Geo g, const float* __restrict__ x, float* __restrict__ G) {
     extern __shared__ char lds_pad[];           // occupancy: one block per CU, like the register-bound real kernel
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -132,6 +134,50 @@ __global__ __launch_bounds__(1024, 1) void k_pattern(Geo g, const float* __restr
             return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (v ? (long long)z * s_z + (long long)t * s_t : 0)), 0, v ? fbytes : 0, 0x00020000);
         };
         const int z_lo = zs - g.ovl, z_hi = ze - 1 + g.ovh;
+        // ring-column mini slot: lane = (side, row i of the strip, frame t); gather k of a plane: 0 = the ring column itself, 1 = one
+        // column further out, 2 / 3 = the rows above / below in the ring column, 4 = the strip's own edge column.  One descriptor per
+        // plane (all M frames), the frame offset rides in the per-lane offset.
+        unsigned goff[RG > 0 ? RG : 1];
+        if (RG > 0) {
+            const int side = lane >> 5, gi = (lane >> 3) & 3, gt = lane & 7;
+            const int c_edge = cx - lx * LC + (side ? g.wx * LC - 1 : 0);      // the strip's first / last column
+            const int dir = side ? 1 : -1;
+#pragma unroll
+            for (int k = 0; k < RG; ++k) {
+                if (RG <= 2) {
+                    // RG = 1 / 2: ONE 16-byte gather [ring - 1, ring, own edge, own edge + 1] (8-byte aligned, straddles the line
+                    // boundary), + (RG = 2) the halo rows of the ring column: 32 active lanes (rows -1 / LR of the strip only)
+                    int col = side ? c_edge - 1 : c_edge - 2, row = yb - ly * LR + gi;
+                    bool ok = gi < LR && col >= 0 && col + 4 <= g.nx && row >= 0 && row < g.ny;
+                    if (k == 1) {
+                        col = c_edge + dir;
+                        row = (gi == 0) ? row - 1 : row + 1;
+                        ok = (gi == 0 || gi == LR - 1) && col >= 0 && col < g.nx && row >= 0 && row < g.ny;
+                    }
+                    goff[k] = ok ? (unsigned)((long long)gt * fbytes + ((long long)row * g.nx + col) * 4) : OOB;
+                    continue;
+                }
+                int col = c_edge + dir, row = yb - ly * LR + gi;
+                if (k == 1) col += dir;
+                if (k == 2) row -= 1;
+                if (k == 3) row += 1;
+                if (k == 4) col = c_edge;
+                const bool ok = gi < LR && col >= 0 && col < g.nx && row >= 0 && row < g.ny;
+                goff[k] = ok ? (unsigned)((long long)gt * fbytes + ((long long)row * g.nx + col) * 4) : OOB;
+            }
+        }
+        auto plane_rs = [&](int z) {
+            const bool v = z >= 0 && z < g.nz && z <= z_hi;
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(x + (v ? (long long)z * s_z : 0)), 0, v ? fbytes * M : 0, 0x00020000);
+        };
+        float gq[RG > 0 ? RG : 1];
+        if (RG > 0) {
+            const Rsrc rp = plane_rs(z_lo);
+#pragma unroll
+            for (int k = 0; k < RG; ++k) gq[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, (int)goff[k], 0, 0));
+        }
+        v4i gq4 = {0, 0, 0, 0};
+        if (RG > 0 && RG <= 2) gq4 = __builtin_amdgcn_raw_buffer_load_b128(plane_rs(z_lo), (int)goff[0], 0, 0);
         Vec<LC> cur[M][LR], nq[D][LR], hq[HD];
 #pragma unroll
         for (int t = 0; t < M; ++t) {
@@ -149,6 +195,17 @@ __global__ __launch_bounds__(1024, 1) void k_pattern(Geo g, const float* __restr
         for (int d = 0; d < HD; ++d) hq[d] = ld<LC>(frame(x, z_lo, d, true), hoff);
         for (int z = z_lo; z <= z_hi; ++z) {
             const bool store = z >= zs && z < ze;
+            float gsum = 0.f;
+            if (RG > 0) {           // consume the ring values of plane z, request those of plane z + 1 (a whole step ahead)
+#pragma unroll
+                for (int k = (RG <= 2) ? 1 : 0; k < RG; ++k) gsum += gq[k];
+                if (RG <= 2) gsum += __int_as_float(gq4.x) + __int_as_float(gq4.y) + __int_as_float(gq4.z) + __int_as_float(gq4.w);
+                gsum *= g.zero;
+                const Rsrc rp = plane_rs(z + 1);
+                if (RG <= 2) gq4 = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)goff[0], 0, 0);
+#pragma unroll
+                for (int k = (RG <= 2) ? 1 : 0; k < RG; ++k) gq[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, (int)goff[k], 0, 0));
+            }
             // the halo row of frame t of plane z, requested HD frames ahead (HD = 2: what k_subgrad_col did until round 4 --
             // with ONE in-order vmcnt the wait for it is a wait for everything older, whatever the depth of the main ring)
 #pragma unroll
@@ -161,6 +218,7 @@ __global__ __launch_bounds__(1024, 1) void k_pattern(Geo g, const float* __restr
                 for (int i = 0; i < LR; ++i) {
                     Vec<LC> v = cur[t][i];
                     if (i == 0) addh<LC>(v, h, g.zero);
+                    if (RG > 0 && i == 1 && t == 0) { Vec<LC> gv; gv = v; if constexpr (LC == 1) gv.v = gsum; addh<LC>(v, gv, 1.f); }
                     st<LC, NT>(rg, soff[i], v);
                     cur[t][i] = nq[t % D][i];
                 }
@@ -346,6 +404,15 @@ template <int LR, int LC> static void launch(const Geo& g, int blocks, int threa
 #undef AUXCASE
         fprintf(stderr, "store aux %d not instantiated\n", g.nt); exit(1);
     }
+    else if (g.rg > 0) {
+        if constexpr (LR == 4 && LC == 1) {
+            if (g.rg == 1) hipLaunchKernelGGL((k_pattern<4, 1, 2, 0, 2, 1>), dim3(blocks), dim3(threads), 96 * 1024, 0, g, x, G);
+            else if (g.rg == 2) hipLaunchKernelGGL((k_pattern<4, 1, 2, 0, 2, 2>), dim3(blocks), dim3(threads), 96 * 1024, 0, g, x, G);
+            else if (g.rg == 3) hipLaunchKernelGGL((k_pattern<4, 1, 2, 0, 2, 3>), dim3(blocks), dim3(threads), 96 * 1024, 0, g, x, G);
+            else if (g.rg == 5) hipLaunchKernelGGL((k_pattern<4, 1, 2, 0, 2, 5>), dim3(blocks), dim3(threads), 96 * 1024, 0, g, x, G);
+            else { fprintf(stderr, "gathers: 1, 2, 3 or 5\n"); exit(1); }
+        } else { fprintf(stderr, "gathers: 4x1 lanes only\n"); exit(1); }
+    }
     else if (g.dd == 2 && g.hd != 8) hipLaunchKernelGGL((k_pattern<LR, LC, 2, 0>), dim3(blocks), dim3(threads), 96 * 1024, 0, g, x, G);
     else if (g.dd == 4 && g.hd == 2) hipLaunchKernelGGL((k_pattern<LR, LC, 4, 0, 2>), dim3(blocks), dim3(threads), 96 * 1024, 0, g, x, G);
     else if (g.dd == 2 && g.hd == 8) hipLaunchKernelGGL((k_pattern<LR, LC, 2, 0, 8>), dim3(blocks), dim3(threads), 96 * 1024, 0, g, x, G);
@@ -422,15 +489,15 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; ++rep)
     for (const std::string& s : cfgs) {
         Cfg c;
-        int v[20] = {0}; v[14] = -1; v[15] = 2;
+        int v[21] = {0}; v[14] = -1; v[15] = 2;
         int k = 0;
         std::string tmp = s;
-        for (char* tok = strtok(&tmp[0], ", "); tok && k < 20; tok = strtok(nullptr, ", ")) v[k++] = atoi(tok);
+        for (char* tok = strtok(&tmp[0], ", "); tok && k < 21; tok = strtok(nullptr, ", ")) v[k++] = atoi(tok);
         if (k < 13) { fprintf(stderr, "bad config %s\n", s.c_str()); return 1; }
         c.LR = v[0]; c.LC = v[1];
         Geo& g = c.g;
         g.nz = nz; g.m = m; g.ny = ny; g.nx = nx;
-        g.wx = v[2]; g.nwy = v[3]; g.nwx = v[4]; g.ry = v[5]; g.rx = v[6]; g.halo = v[7]; g.zc = v[8]; g.ovl = v[9]; g.ovh = v[10]; g.grid = v[11]; g.xcd = v[12]; g.nt = v[13]; g.rl = (v[14] < 0 || v[14] > v[6]) ? v[6] : v[14]; g.dd = v[15]; g.dl = v[16]; g.hd = v[17]; g.ustride = v[18]; g.xoff = v[19];
+        g.wx = v[2]; g.nwy = v[3]; g.nwx = v[4]; g.ry = v[5]; g.rx = v[6]; g.halo = v[7]; g.zc = v[8]; g.ovl = v[9]; g.ovh = v[10]; g.grid = v[11]; g.xcd = v[12]; g.nt = v[13]; g.rl = (v[14] < 0 || v[14] > v[6]) ? v[6] : v[14]; g.dd = v[15]; g.dl = v[16]; g.hd = v[17]; g.ustride = v[18]; g.xoff = v[19]; g.rg = v[20];
         g.zero = 0.f;
         const int wy = 64 / g.wx, TB = g.nwy * wy * c.LR, TC = g.nwx * g.wx * c.LC, UR = TB - 2 * g.ry, UC = TC - 2 * g.rx;
         g.tx = g.ustride ? (nx + g.ustride - 1) / g.ustride : (nx + UC - 1) / UC; g.ty = (ny + UR - 1) / UR;
