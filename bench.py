@@ -372,7 +372,8 @@ def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, co
         return v
     s_x, s_sw, s_fx = span("start", "xsolve"), span("xsolve", "sweep"), span("sweep", "end")
     fused_path = bool(ad.fused and ad.cheb and s_sw)
-    words_sweep = 2 * nd + 3 + (nd if ad.keep_z else 0)
+    keep_z, xs_desc, xs_launches = bool(ad.keep_z), ad.xsolve_desc, ad.xsolve_launches
+    words_sweep = 2 * nd + 3 + (nd if keep_z else 0)
     words_x = ad.xsolve_words
     out = {
         "metric": METRIC["admm"], "value": it_s, "unit": "it/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -380,8 +381,8 @@ def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, co
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %s fp32 %s ADMM" % (args.workload, "x".join(str(s) for s in shape), args.scheme),
                    "shape": list(shape), "scheme": args.scheme, "nd": nd, "reg_z_over_reg": wl["reg_z"], "reg_time": wl["reg_time"],
-                   "lambda": 25.0, "rho": args.rho, "n_cg": args.n_cg, "x_solver": "chebyshev" if ad.cheb else "cg", "keep_z": bool(ad.keep_z),
-                   "kernels": ("one-sweep dual side: tv_admm_fused + tv_admm_fixup; x-solve: %s" % ad.xsolve_desc) if fused_path
+                   "lambda": 25.0, "rho": args.rho, "n_cg": args.n_cg, "x_solver": "chebyshev" if ad.cheb else "cg", "keep_z": keep_z,
+                   "kernels": ("one-sweep dual side: tv_admm_fused + tv_admm_fixup; x-solve: %s" % xs_desc) if fused_path
                               else "unfused: tv_admm_tu + tv_DT_axpy + tv_normal_op2 / tv_cheb_step",
                    "parallelism": "z-slab x%d" % world},
         "voxel_iterations_per_sec": it_s * V,
@@ -415,10 +416,10 @@ def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, co
                            "achieved": b_sw / t_sw / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_sw / t_sw / 1e9 / HBM_PEAK_GBPS,
                            "traffic": traffic.get("fused"), "traffic_source": src, "bytes_per_launch": b_sw, "ms_per_launch": 1e3 * t_sw,
                            "note": "algorithmic bytes (2 Nd + 3%s) * 4 per voxel: u read + written, x, x0 read, r written%s; HIP events on the launch stream"
-                                   % (" + Nd" if ad.keep_z else "", ", every sample of t' written (keep_z)" if ad.keep_z else "") + sharded}
-        out["roofline_xsolve"] = {"bound": "hbm", "kernel": ad.xsolve_desc, "achieved": b_x / t_x / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   % (" + Nd" if keep_z else "", ", every sample of t' written (keep_z)" if keep_z else "") + sharded}
+        out["roofline_xsolve"] = {"bound": "hbm", "kernel": xs_desc, "achieved": b_x / t_x / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": b_x / t_x / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("xsolve"), "bytes_per_outer_iteration": b_x,
-                                  "ms_per_outer_iteration": 1e3 * t_x, "launches_per_outer_iteration": ad.xsolve_launches,
+                                  "ms_per_outer_iteration": 1e3 * t_x, "launches_per_outer_iteration": xs_launches,
                                   "note": "all launches of the x-solve of ONE outer iteration together: %d words per voxel%s" % (words_x, sharded)}
         out["roofline_fixup"] = {"kernel": "halo exchange of t' + tv_admm_fixup", "ms_per_launch": 1e3 * t_fx, "traffic": traffic.get("fixup")}
     if dist.is_initialized():

@@ -818,11 +818,10 @@ class SubgradientDescent(_SlabProblem):
         self.G = self.new_image()
         if one_pass is None:      # TV + G + step in one pass over x wherever the geometry allows (tv_subgrad_step_fused)
             one_pass = bool(self.lib.tv_subgrad_fused_supported(self.geo.ref))
-            # the round-3 kernel folds the step into its store (it divides by step * reg); a vanishing product is the round-1
-            # kernel's case, and that one needs 16-byte lanes and fp32
-            if self.step_size * self.reg < 1e-6 and (nx % 4 != 0 or self.dtype != torch.float32 or self.geo.weight_vol is not None
-                                                     or self.geo.pitched):
-                one_pass = False      # (the round-1 kernel takes no weight volume either: round-3 advice)
+            # the one-pass kernel folds the step into its store (it divides by step * reg): a vanishing product takes the two-pass path
+            # (until round 5 the round-1 kernel took that corner for fp32; it lives in csrc/variants/ now)
+            if self.step_size * self.reg < 1e-6:
+                one_pass = False
         self.one_pass = bool(one_pass)
         # one pass: TV, G and the descent step in a single kernel, x ping-ponged (G is never stored); else the
         # two-pass tv_subgrad + tv_subgrad_step

@@ -14,6 +14,9 @@ import pytest
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
+# small test volumes take the one-sweep Chambolle-Pock path too (the other GPU test modules set this at import time; this module's
+# bench.py children inherit it -- set here as well so that the module also passes when it is run on its own)
+os.environ["TV_FUSED_MIN_KVOXELS"] = "0"
 
 
 def _env(port):
