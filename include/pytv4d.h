@@ -208,7 +208,7 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
  * and needs one plain reduction for the last iterate.
  * q_in / q_out: the dual variable is read from q_in and written to q_out.  q_in == q_out is the in-place update of tv_cp_fused;
  * two arrays (ping-pong, the caller swaps them after every iteration) cost a second q but run ~9 % faster: HBM serves "read one
- * array, write another" better than a read-modify-write of the same lines (tools/bwtest4: 5.98 against 5.50 TB/s for this
+ * array, write another" better than a read-modify-write of the same lines (tools/archive/bwtest4: 5.98 against 5.50 TB/s for this
  * kernel's memory shape).  tv_cp_fixup takes q_out. */
 #define TV_CP_FID_OF_INPUT 1
 int tv_cp_sweep(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q_out, const void* x0,

@@ -58,7 +58,7 @@ template <typename T, int V> __device__ __forceinline__ void vstore(T* p, const 
     *reinterpret_cast<Vec<T, V>*>(p) = a;
 }
 // Streamed-once arrays of the epilogues: non-temporal loads AND stores (mixing nt loads with plain stores
-// is slower than either, tools/bwtest3.hip).  Which epilogue uses them was settled by A/B on the device
+// is slower than either, tools/archive/bwtest3.hip).  Which epilogue uses them was settled by A/B on the device
 // (profiles/r3_epi_nt_ab.txt): CpPrimal and AxpyDT gain 4-8 %, CpDual gains for central and loses for the
 // 8-channel schemes, StoreDT / AdmmZU lose up to 30 % for central, StoreD is neutral.
 #ifndef TV_EPI_NT

@@ -173,7 +173,7 @@ template <typename T, int V> __device__ __forceinline__ void stu_t(T* ubase, uns
     *reinterpret_cast<Vec<T, V>*>(reinterpret_cast<char*>(ubase) + voff) = v;
 }
 // streamed-once data (the dual variable q, x0, p): non-temporal loads / stores (-DTV_FUSED_NT=1: A/B of round 3 -- a copy with
-// 8 read + 8 write streams and this kernel's 512-thread blocks gains 1.3 % from it, tools/bwtest3 "mix"; mixing non-temporal loads
+// 8 read + 8 write streams and this kernel's 512-thread blocks gains 1.3 % from it, tools/archive/bwtest3 "mix"; mixing non-temporal loads
 // with plain stores LOSES 7 %)
 #ifndef TV_FUSED_NT
 #define TV_FUSED_NT 1
@@ -272,7 +272,7 @@ template <typename T> struct FusedArgsT {
                           // ALG_CP: bit 1 = the second partial is 1/2 |x_in - x0|^2 over all sites (TV_CP_FID_OF_INPUT)
     const T* q_in;        // where the dual variable is READ (round 4: q ping-pong, tv_cp_sweep; == q: in place, as before).  Reading one
                           // array and writing another is ~9 % faster than the in-place read-modify-write for this kernel's memory shape
-                          // (tools/bwtest4 variant 4: 5.98 against 5.50 TB/s) -- the price is a second q array
+                          // (tools/archive/bwtest4 variant 4: 5.98 against 5.50 TB/s) -- the price is a second q array
 };
 using FusedArgs = FusedArgsT<float>;
 
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
     // ONE PLANE AHEAD, in the same frame as the wide load of that plane -- i.e. while the neighbouring wave fetches the very
     // line they live in.  Requested a plane later (as before) the line had left the L2 again (a CU streams ~0.7 MB per plane
     // through its 128 KiB share) and two thirds of these loads went to the fabric as their own requests: 9.8 GB per sweep of
-    // the north-star volume on the read counter (tools/pmc_calib.sh shows the same +14 % on a kernel with exactly known bytes).
+    // the north-star volume on the read counter (tools/archive/pmc_calib.sh shows the same +14 % on a kernel with exactly known bytes).
     constexpr bool EA = (TV_FUSED_EA != 0) && !(XW && (TV_FUSED_XE != 0));
     const bool e_le = PREV && (c.lx == 0) && c.ok && (c.col0 > 0);
     const bool e_re = NEXT && (c.lx == CP_TL - 1) && c.ok && (c.col0 + V < g.nx);

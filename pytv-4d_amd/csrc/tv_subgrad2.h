@@ -2,7 +2,7 @@
 //
 // Same mathematics as the round-1 kernel (variants/tv_subgrad.h; the scatter form: a site hands the PRODUCTS d * 1/|Dx| of its gradient channels to
 // its neighbours, 1/|Dx| never leaves the chip, the result is a pure function of x), rebuilt around what an instruction
-// costs on a gfx950 SIMD (tools/issue_bench.hip, profiles/r3_issue_bench.txt): a plain fp32 VALU op 2 cycles, DPP / compare
+// costs on a gfx950 SIMD (tools/archive/issue_bench.hip, profiles/r3_issue_bench.txt): a plain fp32 VALU op 2 cycles, DPP / compare
 // / select / packed / fp64 4, v_rsq 6 - 8, and ds_bpermute_b32 -- what __shfl_up/down compile to -- 18 per dword.  The
 // round-1 kernel (a lane = 1 row x 4 columns, wave = 4 rows x 16 lanes) spent a third of its issue time in the 19
 // bpermutes per frame that move row neighbours between lanes.  Here

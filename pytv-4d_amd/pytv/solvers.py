@@ -70,7 +70,7 @@ def auto_pitch(ny, nx, dtype, frame_pad_bytes=0):
     a quarter more bytes and measured SLOWER (256 x 4 x 100 x 100: 0.33 against 0.27 ms) -- only ragged rows (Nx not a multiple
     of the 16-byte lane) are rounded up to the lane, which takes them off the scalar-lane kernels.
     frame_pad_bytes: extra bytes between frames (round 4 measured that de-aliasing the frame pitch does NOT move the one-sweep
-    kernel: tools/bwtest4, tools/alias_probe.py, profiles/r4_alias_probe.txt, profiles/r4_bwtest4_frame_pitch.txt; kept as an argument for experiments)."""
+    kernel: tools/archive/bwtest4, tools/archive/alias_probe.py, profiles/r4_alias_probe.txt, profiles/r4_bwtest4_frame_pitch.txt; kept as an argument for experiments)."""
     es = 4 if dtype == torch.float32 else 8
     lane = 16 // es
     nx, ny = int(nx), int(ny)
@@ -215,7 +215,7 @@ class ChambollePock(_SlabProblem):
         pitch: see ``_SlabProblem`` ("auto", the default: padded rows where that pays; None / "dense"; (row_pitch, frame_pitch)).
         q_pingpong (one-sweep path; default off): read the dual variable from one array and write it to a second one, swapping them
         every iteration, instead of updating it in place.  An arithmetic-free kernel with the sweep's memory shape gains 9 % from
-        it (tools/bwtest4, profiles/r4_bwtest4_q_pingpong.txt); the real sweep does not (tools/pp_probe.py: 33.3 against 33.4 ms in
+        it (tools/archive/bwtest4, profiles/r4_bwtest4_q_pingpong.txt); the real sweep does not (tools/archive/pp_probe.py: 33.3 against 33.4 ms in
         one pool, and one of the two directions can be 3 ms slower than the other when the arrays are separate allocations) --
         kept as an option of tv_cp_sweep, not used by default.
         tune_placement: None = on for volumes (slabs) of >= 4 GiB per image with memory to spare (see ``_tune_x_placement``)."""
@@ -1142,7 +1142,7 @@ class ADMM(_SlabProblem):
     def _tune_placement(self, n_sets=4, n_steps=2):
         """Pick WHERE the state lives by measurement, as ``ChambollePock._tune_x_placement`` does: the same
         outer iteration on the same data takes 17.5 or 19.5 ms on the configs[4] slab depending on where u, t and the image buffers
-        landed (tools/admm_placement_probe.py).  ``n_sets`` complete sets of state arrays are allocated one after the other (never
+        landed (tools/archive/admm_placement_probe.py).  ``n_sets`` complete sets of state arrays are allocated one after the other (never
         more than two alive), ``n_steps`` outer iterations are timed on each after one to warm up, the fastest set is kept and put
         back into the initial state.  Unsharded problems only (an outer iteration of a slab waits for its neighbours)."""
         import time as _time

@@ -309,7 +309,7 @@ def test_config4_admm_end_to_end_two_slabs_against_the_oracle(scheme, production
         z0, nz = ret[r]["z"]
         assert nz == 32
         # bounds = ~10 x what an fp32 run deviates from the fp64 oracle by on this problem (profiles/r3_admm_tolerances.txt,
-        # tools/admm_tolerance_probe.py: loss 3e-8 relative, x 1.1e-5 absolute at |x| <= 58, z 2.2e-5 at |z| <= 20 -- two or
+        # tools/archive/admm_tolerance_probe.py: loss 3e-8 relative, x 1.1e-5 absolute at |x| <= 58, z 2.2e-5 at |z| <= 20 -- two or
         # three units in the last place of the largest values; round 2 had 5e-5 / 5e-3 here without a measurement behind them)
         np.testing.assert_allclose(ret[r]["loss"], wloss, rtol=1e-6)
         np.testing.assert_allclose(ret[r]["x"], wx[z0:z0 + nz, :, 8:40, 300:620], rtol=2e-6, atol=1e-4)

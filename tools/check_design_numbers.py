@@ -62,7 +62,7 @@ def main():
     in_measured, misses, checked, rows = False, [], 0, 0
     for ln, line in enumerate(lines, 1):
         if line.startswith("#"):
-            in_measured = line.lstrip("#").strip().lower().startswith("measured")
+            in_measured = re.sub(r"^[\d.\s]+", "", line.lstrip("#").strip()).lower().startswith("measured")
             continue
         if not in_measured or not line.startswith("|") or re.match(r"^\|\s*-", line):
             continue
