@@ -109,6 +109,10 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
         const long long per_plane_set = ((tx + NWX - 1) / NWX) * ty * nwin;
         zc = (per_plane_set * ((d.nz + 31) / 32) >= 2048) ? 32 : 16;
         while (zc > 8 && per_plane_set * ((d.nz + zc - 1) / zc) < 1024) zc -= 4;
+        // volumes of a few planes of small frames (the reference's own shapes: pytv/tests.py:48 N = 100, README.md:76-79
+        // rand(20, 4, 100, 100)): below one block per CU the chunk overlap is cheaper than idle CUs -- 20x4x100x100 hybrid 0.063 -> 0.038 ms
+        // per descent step with 2-plane chunks, 256x4x100x100 (256 blocks at 8 planes) best as it is: profiles/r5_small_frames.txt
+        while (zc > 2 && per_plane_set * ((d.nz + zc - 1) / zc) < 256) zc -= 2;
     }
     if (zc > d.nz) zc = d.nz;
     const long long nch = (d.nz + zc - 1) / zc;
