@@ -211,6 +211,10 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
  * array, write another" better than a read-modify-write of the same lines (tools/archive/bwtest4: 5.98 against 5.50 TB/s for this
  * kernel's memory shape).  tv_cp_fixup takes q_out. */
 #define TV_CP_FID_OF_INPUT 1
+/* TV_CP_FID_BOTH (round 5; only together with TV_CP_FID_OF_INPUT): `fid` points to TWO doubles -- fid[0] as above, fid[1] = 1/2 |x_out - x0|^2 over
+ * the sites that are already complete (what the flag-less tv_cp_fused returns); the tv_cp_fixup that follows is then called WITH x0 and
+ * returns the rest.  The LAST sweep of a lagged loop uses it: the fidelity of the final iterate needs no separate reduction pass. */
+#define TV_CP_FID_BOTH 2
 int tv_cp_sweep(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q_out, const void* x0,
                 void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int32_t flags, int64_t chunk_begin,
                 int64_t chunk_count, double* tv, double* fid, void* ws, void* stream);

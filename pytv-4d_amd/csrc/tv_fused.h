@@ -273,6 +273,8 @@ template <typename T> struct FusedArgsT {
     const T* q_in;        // where the dual variable is READ (round 4: q ping-pong, tv_cp_sweep; == q: in place, as before).  Reading one
                           // array and writing another is ~9 % faster than the in-place read-modify-write for this kernel's memory shape
                           // (tools/archive/bwtest4 variant 4: 5.98 against 5.50 TB/s) -- the price is a second q array
+    double* part_fid2;    // ALG_CP, full_store bit 2 (TV_CP_FID_BOTH, round 5): per-block partials of 1/2 |x_out - x0|^2 over the complete sites, NEXT TO the
+                          // fidelity of the input -- the last sweep of a lagged block returns both, so that no separate reduction closes the block
 };
 using FusedArgs = FusedArgsT<float>;
 
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
     const VT zero = vsplat<T, V>(T(0));
     const VT mf = g.ta ? mask_factor<T, V>(g, w.sf, c.ok ? c.y : 0, c.ok ? c.col0 : 0) : vsplat<T, V>(T(1));
     const T s = (S == HYBRID) ? Consts<T>::inv_sqrt2() : (CEN ? T(0.5) : T(1));
-    double acc_tv = 0.0, acc_fid = 0.0;
+    double acc_tv = 0.0, acc_fid = 0.0, acc_fid2 = 0.0;
     // x planes z (C) and z-1 (P) live in registers; the adjoint accumulators R (plane z-1 waiting
     // for its z+1 term) and the carried z-up terms U live in LDS, private per thread ([frame][thread]:
     // conflict-free 16-byte lanes, no barrier needed) -- 4 M vectors of state do not fit the VGPR file
@@ -435,18 +437,28 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
         }
         stu_s_t<T, V>(a.p + foff, voff, pn);
         stu_s_t<T, V>(a.x_out + foff, voff, xo);
-        if (a.full_store & 2) {
+        // (the two accumulators are updated UNCONDITIONALLY with selected VALUES: selecting the accumulator instead makes the compiler keep
+        // both in a dynamically indexed stack slot -- 24 B of scratch and a load / store pair per site in every instantiation)
+        double add1 = 0.0, add2 = 0.0;
+        const bool lagged = (a.full_store & 2) != 0, both = (a.full_store & 4) != 0;       // uniform
+        if (!lagged || both) {
+            if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) { if (lagged) add2 = e2; else add1 = e2; }
+        }
+        if (lagged) {
             // fidelity of the INPUT iterate over ALL sites (round 4, tv_cp_sweep flag TV_CP_FID_OF_INPUT): x_in is complete and x0 is
             // in registers, so the fix-up no longer has to read x0 for the sites it completes -- the solver takes 1/2 |x_k - x0|^2
-            // from sweep k (README.md:157 pairs it with the TV of x_{k-1}, which sweep k - 1 delivered)
+            // from sweep k (README.md:157 pairs it with the TV of x_{k-1}, which sweep k - 1 delivered).  TV_CP_FID_BOTH (round 5): the
+            // fidelity of the OUTPUT over the complete sites goes to the second accumulator as well (the fix-up, called with x0, adds the rest)
             double f2 = 0.0;
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 const double e = (double)xv.v[i] - (double)x0v.v[i];
                 f2 += 0.5 * e * e;
             }
-            acc_fid += f2;
-        } else if (!fused_needs_fixup<S, XW, V>(g, zf, c.y, c.col0, zchunk, t0 + t)) acc_fid += e2;
+            add1 = f2;
+        }
+        acc_fid += add1;
+        acc_fid2 += add2;
     };
 
     // wait until the neighbouring waves have published `planes` planes (all waves of a block are resident and
@@ -719,6 +731,12 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
     if (threadIdx.x == 0 && threadIdx.y == 0) a.part_tv[linear_block_id()] = acc_tv;
     acc_fid = block_sum(acc_fid, sm);
     if (threadIdx.x == 0 && threadIdx.y == 0) a.part_fid[linear_block_id()] = acc_fid;
+    if constexpr (ALG == ALG_CP) {
+        if (a.full_store & 4) {               // uniform
+            acc_fid2 = block_sum(acc_fid2, sm);
+            if (threadIdx.x == 0 && threadIdx.y == 0) a.part_fid2[linear_block_id()] = acc_fid2;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

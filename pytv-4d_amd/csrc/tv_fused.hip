@@ -163,7 +163,8 @@ int tv_cp_fused(const tv_geom* g, const void* x_in, const void* x_prev, const vo
 int tv_cp_sweep(const tv_geom* g, const void* x_in, const void* x_prev, const void* x_next, const void* q_in, void* q_out, const void* x0,
                 void* p, void* x_out, double sigma_D, double lambda, double tau, double sigma_A, int32_t flags, int64_t chunk_begin,
                 int64_t chunk_count, double* tvout, double* fid, void* ws, void* stream) {
-    if (flags & ~TV_CP_FID_OF_INPUT) return fail(TV_E_ARG, "tv_cp_sweep: unknown flag");
+    if (flags & ~(TV_CP_FID_OF_INPUT | TV_CP_FID_BOTH)) return fail(TV_E_ARG, "tv_cp_sweep: unknown flag");
+    if ((flags & TV_CP_FID_BOTH) && !(flags & TV_CP_FID_OF_INPUT)) return fail(TV_E_ARG, "tv_cp_sweep: TV_CP_FID_BOTH extends TV_CP_FID_OF_INPUT");
     if (q_in == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!aligned16({q_in})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     return cp_sweep_impl(g, x_in, x_prev, x_next, q_in, q_out, x0, p, x_out, sigma_D, lambda, tau, sigma_A, flags, chunk_begin, chunk_count, tvout, fid, ws, stream);
@@ -185,21 +186,24 @@ static int cp_sweep_impl(const tv_geom* g, const void* x_in, const void* x_prev,
     if (int rc = sweep_plan(g, d, x_in, x_prev, x_next, chunk_begin, chunk_count, sp, empty)) return rc;
     if (empty) {
         HIP_TRY(hipMemsetAsync(tvout, 0, sizeof(double), st));
-        HIP_TRY(hipMemsetAsync(fid, 0, sizeof(double), st));
+        HIP_TRY(hipMemsetAsync(fid, 0, ((flags & TV_CP_FID_BOTH) ? 2 : 1) * sizeof(double), st));
         return 0;
     }
     double* w0 = (double*)ws;
     double* w1 = w0 + sp.nmax + kStage + 16;
+    double* w2 = w1 + sp.nmax + kStage + 16;          // third partial array (tv_workspace_bytes): TV_CP_FID_BOTH only
     auto sweep = [&]<typename T>() -> int {
         FusedArgsT<T> a{(const T*)x_in, (const T*)x_prev, (const T*)x_next, (T*)q, (const T*)x0, (T*)p,
                         (T*)x_out, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)), w0, w1,
-                        (flags & TV_CP_FID_OF_INPUT) ? 2 : 0, (const T*)(q_in ? q_in : q)};
+                        ((flags & TV_CP_FID_OF_INPUT) ? 2 : 0) | ((flags & TV_CP_FID_BOTH) ? 4 : 0), (const T*)(q_in ? q_in : q), w2};
         return tvm::fused_sweep<T, ALG_CP>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
     };
     const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();
     if (rc) return rc;
     if (int r2 = reduce_partials(w0, sp.lc.nblocks, sp.nmax, tvout, st)) return r2;
-    return reduce_partials(w1, sp.lc.nblocks, sp.nmax, fid, st);
+    if (int r3 = reduce_partials(w1, sp.lc.nblocks, sp.nmax, fid, st)) return r3;
+    if (flags & TV_CP_FID_BOTH) return reduce_partials(w2, sp.lc.nblocks, sp.nmax, fid + 1, st);
+    return 0;
 }
 
 int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void* q_next, void* x_out, const void* x0,

@@ -831,7 +831,7 @@ int tv_num_channels(const tv_geom* g) {
 size_t tv_workspace_bytes(const tv_geom* g) {
     DG d;
     if (make_dg(g, d, true)) return 0;
-    return (size_t)(2 * (max_partials(d) + kStage + 16)) * sizeof(double);    // two independent partial arrays
+    return (size_t)(3 * (max_partials(d) + kStage + 16)) * sizeof(double);    // three independent partial arrays (the third: tv_cp_sweep with TV_CP_FID_BOTH, round 5)
 }
 
 // ---------------------------------------------------------------------------------------------

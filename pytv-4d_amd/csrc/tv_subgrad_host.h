@@ -91,8 +91,12 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
     // -DTV_SG2_AL=2 build instantiates.
     const int al_opt = env_int("TV_SG_ALIGNED", 1);
     const bool al_scheme = (g->scheme == TV_UPWIND || g->scheme == TV_DOWNWIND) ? (al_opt != 0) : (TV_SG2_AL == 2 && al_opt == 2);
-    const bool al = !F64 && TV_SG2_AL && al_scheme && d.m <= SG2_TWN && d.wv == nullptr && d.s_t * (long long)sizeof(T) * d.m < (1ll << 31);
-    const int NW = F64 ? 4 : (al ? 8 : TV_SG2_NW32), NWX = F64 ? 1 : (al ? 1 : TV_SG2_NWX);
+    // fp64 (R = 2 rows of doubles per lane, neighbour rows from memory): the same aligned tile, 8 waves stacked = 16 rows x 64 columns, 14 x 64
+    // stored in whole lines (64 doubles = four 128-byte lines per row) instead of 8 x 64 with 6 x 60 / 62 stored
+    // (fp64 A/B, profiles/r5_f64_aligned_ab.txt: the norms variant gains 3 - 11 %, tv_subgrad_fused itself loses 2 - 5 %: MODE 1 / 2 only)
+    const bool al = TV_SG2_AL && al_scheme && d.m <= SG2_TWN && d.wv == nullptr && d.s_t * (long long)sizeof(T) * d.m < (1ll << 31) &&
+                    (!F64 || MODE != 0);
+    const int NW = al ? 8 : (F64 ? 4 : TV_SG2_NW32), NWX = (F64 || al) ? 1 : TV_SG2_NWX;
     const long long nmax = max_partials(d);
     const bool halo = (g->scheme == TV_HYBRID || g->scheme == TV_CENTRAL);
     const int UR = R * NW - 2, UC = al ? 64 : (halo ? 60 : 62);
@@ -145,7 +149,7 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
     int rc = dispatch_sg(g->scheme, d.m > SG2_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
         constexpr int MM = (M == 0) ? SG2_TWN : M;
         constexpr bool TW = (M == 0);
-        if constexpr (!F64 && !TW && (TV_SG2_AL == 2 || (TV_SG2_AL == 1 && (S == UPWIND || S == DOWNWIND)))) {
+        if constexpr (!TW && (!F64 || MODE != 0) && (TV_SG2_AL == 2 || (TV_SG2_AL == 1 && (S == UPWIND || S == DOWNWIND)))) {
             if (al) {
                 hipLaunchKernelGGL((k_subgrad_col<S, T, MM, R, 8, MODE, false, XLD, 1, true>), dim3((unsigned)ngrid), block, 0, st, d, make_w<T>(g),
                                    (const T*)x, (const T*)x_prev, (const T*)x_next, (T*)G, zc, (int)nch, w0, sa, tm);

@@ -173,14 +173,76 @@ class _SlabProblem:
             return self.geo.new_image(n)
         return torch.empty((n, m, ny, nx), dtype=self.dtype, device=self.device)
 
+    # ---- the arena (round 5, OPT-IN): ONE allocation for the arrays an iteration streams through ---------------------------------------
+    # The time of the streaming kernels depends on where their arrays sit in physical memory (EXPERIMENTS.md section 3, round 4: the
+    # "placement lottery" -- separate allocations land anywhere: 31.3 - 34.2 ms per north-star sweep from one construction to the next).
+    # Carved out of ONE allocation with 24 - 48 MiB between consecutive arrays the sweep takes the SAME time construction after
+    # construction (spread 0.4 - 0.5 % against 6 - 9 %: profiles/r5_slab_placement_probe{,2,3,4}.txt, tools/slab_placement_probe.py) --
+    # but WHICH time is decided by where the one big allocation lands: 31.1 ms on one box, 33.1 - 33.4 on three others, alternating
+    # 31.05 / 32.1 from construction to construction on a fifth; a second arena measured beside the first (``_tune_arena``) does not
+    # help where both land on the slow level (profiles/r5_bench_northstar_arena_first_command.json: 33.2 ms, 35.5 ms per iteration
+    # against 33.8 with the per-array tuner).  Deterministic, not fast: it is therefore an OPTION (``arena=True``) for callers who
+    # want run-to-run reproducible timing; the default stays separate allocations + the measuring tuner.
+    ARENA_GAP_BYTES = 32 << 20
+    _arena = None
+
+    def _image_elems(self):
+        nz, m, ny, nx = self.x0.shape
+        return nz * m * (self.pitch[1] if self.pitch != (0, 0) else ny * nx)
+
+    def _arena_open(self, n_images, n_grads, enable=None):
+        """enable: None / False = off (the default), True = on; returns whether an arena is open"""
+        img = self._image_elems()
+        es = self.x0.element_size()
+        if enable is None:
+            enable = False
+        if not enable or self.device.type != "cuda":
+            return False
+        gap = self.ARENA_GAP_BYTES // es
+        total = n_images * (img + gap) + n_grads * (img * self.geo.nd + gap)
+        try:
+            self._arena = torch.empty(total, dtype=self.dtype, device=self.device)
+        except RuntimeError:                      # no single block of that size: separate allocations (and the placement tuner)
+            self._arena = None
+            torch.cuda.empty_cache()
+            return False
+        self._arena_off, self._arena_gap = 0, gap
+        return True
+
+    def _arena_take(self, elems):
+        a = self._arena
+        if a is None or self._arena_off + elems > a.numel():
+            return None
+        v = a[self._arena_off:self._arena_off + elems]
+        self._arena_off += elems + self._arena_gap
+        return v
+
     def new_image(self, zero=True):
         """an array like x0 (this rank's planes) with the state's pitches; pads always zero"""
+        buf = self._arena_take(self._image_elems())
+        if buf is not None:
+            nz, m, ny, nx = self.x0.shape
+            if self.pitch != (0, 0):
+                buf.zero_()
+                return buf.as_strided((nz, m, ny, nx), self.geo.image_strides())
+            if zero:
+                buf.zero_()
+            return buf.view(nz, m, ny, nx)
         if self.pitch != (0, 0):
             return self.geo.new_image()
         return torch.zeros_like(self.x0) if zero else torch.empty_like(self.x0)
 
     def new_grad(self):
         """a zeroed gradient-like array (nz, Nd, M, Ny, Nx) with the state's pitches"""
+        buf = self._arena_take(self._image_elems() * self.geo.nd)
+        if buf is not None:
+            nz, m, ny, nx = self.x0.shape
+            nd = self.geo.nd
+            buf.zero_()
+            if self.pitch != (0, 0):
+                fp, rp = self.geo.frame_pitch, self.geo.row_pitch
+                return buf.as_strided((nz, nd, m, ny, nx), (nd * m * fp, m * fp, fp, rp, 1))
+            return buf.view(nz, nd, m, ny, nx)
         return self.geo.new_grad()
 
     def image_copy(self, src):
@@ -209,7 +271,7 @@ class ChambollePock(_SlabProblem):
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
                  factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch="auto",
-                 q_pingpong=False, tune_placement=None):
+                 q_pingpong=False, tune_placement=None, arena=None):
         """fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
         iteration) whenever the geometry supports it, False = always the dual + primal kernel pair.
         pitch: see ``_SlabProblem`` ("auto", the default: padded rows where that pays; None / "dense"; (row_pitch, frame_pitch)).
@@ -218,24 +280,16 @@ class ChambollePock(_SlabProblem):
         it (tools/archive/bwtest4, profiles/r4_bwtest4_q_pingpong.txt); the real sweep does not (tools/archive/pp_probe.py: 33.3 against 33.4 ms in
         one pool, and one of the two directions can be 3 ms slower than the other when the arrays are separate allocations) --
         kept as an option of tv_cp_sweep, not used by default.
-        tune_placement: None = on for volumes (slabs) of >= 4 GiB per image with memory to spare (see ``_tune_x_placement``)."""
+        arena (round 5, default off): True = x, x_alt, p, a private copy of x0 and q are carved out of ONE allocation with 32 MiB
+        between them (``_SlabProblem._arena_open``): the sweep then takes the same time in every construction (spread 0.5 % instead
+        of 6 - 9 %) -- on whatever level that allocation landed, which is the slow one more often than not; see the comment there.
+        tune_placement: None = on for volumes (slabs) of >= 4 GiB per image with memory to spare and no arena (see
+        ``_tune_x_placement``)."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg = float(regularization)
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
         self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time,
                                                                     self.geo.time_weight_max)
-        self.x = self.image_copy(self.x0)
-        self.p = self.new_image()
-        self.q = self.new_grad()
-        self.ws = self.geo.workspace()
-        self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
-        pl = self.plan
-        sh = pl.on
-        self.ch_back, self.ch_fwd = pl.ch_back, pl.ch_fwd
-        self.xh_prev = self.new_plane() if pl.x_need_prev else None
-        self.xh_next = self.new_plane() if pl.x_need_next else None
-        self.qh_prev = self.new_plane() if pl.g_need_prev else None
-        self.qh_next = self.new_plane() if pl.g_need_next else None
         if fused is None:
             # one-sweep kernel where supported -- except on volumes too small to fill the GPU with its blocks (8 rows x 256
             # columns x >= 8 planes x all frames each: a block holds >= 16 k x M voxels and a CU takes 8 / M of them, so
@@ -249,11 +303,19 @@ class ChambollePock(_SlabProblem):
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
             raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry (tv_cp_fused_supported: "
                              "fp32, Nx % 4 == 0, Nx >= 64, Ny * Nx <= 2^30; any number of frames)")
-        self.x_alt = self.new_image() if self.fused else None      # ping-pong partner of x
-        self.q_alt = None
-        if self.fused:
-            if q_pingpong:
-                self.q_alt = self.new_grad()
+        # the arrays of the iteration, in the order the arena was measured with: x, x_alt, p, x0 (the solver's own copy), q
+        self._x0_src, self._q_pingpong, self._arena_want = self.x0, bool(q_pingpong), arena
+        self.arena = False
+        self._alloc_state()
+        self.ws = self.geo.workspace()
+        self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
+        pl = self.plan
+        sh = pl.on
+        self.ch_back, self.ch_fwd = pl.ch_back, pl.ch_fwd
+        self.xh_prev = self.new_plane() if pl.x_need_prev else None
+        self.xh_next = self.new_plane() if pl.x_need_next else None
+        self.qh_prev = self.new_plane() if pl.g_need_prev else None
+        self.qh_next = self.new_plane() if pl.g_need_next else None
         self.overlap = bool(overlap) and sh and self.slab.nz >= 3 and not self.fused
         self.hist = None
         self.it = 0
@@ -261,7 +323,9 @@ class ChambollePock(_SlabProblem):
         self.phase_timing = None  # set to a list to collect one (name, event) list per step: every phase boundary of the schedule
         self._scratch = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
         self._lag = None                 # None: every step returns its own fidelity; else: lagged-fidelity block (see run_steps)
+        self._final = False              # the block's last iteration: its sweep returns BOTH fidelities (TV_CP_FID_BOTH), its fix-up reads x0
         self._lag_void = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._both = torch.zeros((self.SLOTS, 2), dtype=torch.float64, device=self.device)     # [slot][input, output] of the final sweeps
         self._cur_out = self._scratch
         if self.fused:
             self.zchunk = int(self.lib.tv_cp_zchunk(self.geo.ref))
@@ -269,13 +333,20 @@ class ChambollePock(_SlabProblem):
             # interior-first scheduling of the one-sweep path needs an interior: >= 3 chunks and >= 3 planes
             self.overlap_fused = bool(overlap) and sh and self.nchunks >= 3 and self.slab.nz >= 3
         self.placement = None
+        if self.fused and self.arena and tune_placement is None:
+            # an arena of >= 4 GiB images with room for a second one: measure two, keep the faster (never on a sharded slab's behalf of others:
+            # local sweeps only)
+            img_bytes = self.x.numel() * self.x.element_size()
+            free, _total = torch.cuda.mem_get_info(self.device)
+            if img_bytes >= (4 << 30) and free >= self._arena.numel() * self._arena.element_size() + (8 << 30):
+                self._tune_arena()
         if self.fused:
             img_bytes = self.x.numel() * self.x.element_size()
             if tune_placement is None:
                 free, _total = torch.cuda.mem_get_info(self.device)
                 # (sharded slabs too: the tuner launches local kernels only, no rank waits for another; every rank of a weak-scaling run
                 # holds a slab of the single-GPU size and plays the same placement lottery)
-                tune_placement = img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
+                tune_placement = (not self.arena) and img_bytes >= (4 << 30) and free >= 3 * img_bytes + (8 << 30)
             if tune_placement:
                 # (q is NOT pinned here: the tuner keeps exactly one q bound at any time -- the best so far -- and at most one
                 # candidate beside it, so that a winning candidate frees the original before the next one is allocated; round-4 advice)
@@ -291,6 +362,77 @@ class ChambollePock(_SlabProblem):
                     torch.cuda.empty_cache()
                     self.placement = {"error": str(exc)[:200]}
                 del keep
+
+    def _alloc_state(self):
+        """(Re)allocate x, x_alt, p, the private copy of x0, q [, q_alt] -- out of a fresh arena when one can be had -- and put them
+        into the initial state (x = x0, p = q = 0)."""
+        self._arena = None
+        want = self._arena_want
+        self.arena = self._arena_open(4 if self.fused else 3, 2 if (self.fused and self._q_pingpong) else 1, want) if (self.fused or want) else False
+        self.x0 = self._x0_src
+        self.x = self.image_copy(self.x0)
+        self.x_alt = self.new_image() if self.fused else None      # ping-pong partner of x
+        self.p = self.new_image()
+        if self.arena:
+            self.x0 = self.image_copy(self._x0_src)
+        self.q = self.new_grad()
+        self.q_alt = self.new_grad() if (self.fused and self._q_pingpong) else None
+
+    def _tune_arena(self, reps=2):
+        """Two arenas, measured with the real sweep, the faster one kept (round 5).  WHERE one big allocation lands decides the level
+        of every sweep that runs on it -- 31.0 or 32.1 ms on one box, 31.2 or 33.1 on others, the same for every construction that gets
+        the same region and independent of the gap between the arrays (profiles/r5_slab_placement_probe{3,4}.txt) -- and two
+        allocations made one after the other land in different regions.  Costs one more arena for a moment and ~8 sweeps; the state
+        is re-initialised afterwards, results do not depend on it."""
+        import time as _time
+        t_begin = _time.perf_counter()
+        out = torch.zeros(self.SLOTS, dtype=torch.float64, device=self.device)
+
+        def round_trip():
+            hp = self.x[0:1] if self.plan.x_need_prev else None
+            hn = self.x[0:1] if self.plan.x_need_next else None
+            ts = []
+            for r in range(reps + 1):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self._sweep(0, -1, hp, hn, out[0:1], out[self.F:self.F + 1])
+                self.x, self.x_alt = self.x_alt, self.x
+                self._sweep(0, -1, hp, hn, out[0:1], out[self.F:self.F + 1])
+                self.x, self.x_alt = self.x_alt, self.x
+                b.record()
+                ts.append((a, b))
+            torch.cuda.synchronize(self.device)
+            return min(a.elapsed_time(b) for a, b in ts[1:])
+
+        names = ("_arena", "_arena_off", "_arena_gap", "x", "x_alt", "p", "x0", "q", "q_alt")
+        t0 = round_trip()
+        first = {k: getattr(self, k) for k in names}
+        info = {"round_trip_ms": [round(t0, 3)]}
+        try:
+            self._alloc_state()
+            if not self.arena:
+                raise RuntimeError("no second arena")
+            t1 = round_trip()
+            info["round_trip_ms"].append(round(t1, 3))
+            if t0 <= t1:                         # keep the first: the second loses its last references here
+                for k, v in first.items():
+                    setattr(self, k, v)
+        except RuntimeError as exc:              # out of memory for a second arena, ...: an optimisation, never a failure
+            for k, v in first.items():
+                setattr(self, k, v)
+            self.arena = True
+            info["error"] = str(exc)[:160]
+        del first
+        torch.cuda.empty_cache()
+        self.x.copy_(self.x0)
+        self.p.zero_()
+        self.q.zero_()
+        if self.q_alt is not None:
+            self.q_alt.zero_()
+        torch.cuda.synchronize(self.device)
+        info["chosen"] = int(len(info["round_trip_ms"]) == 2 and info["round_trip_ms"][1] < info["round_trip_ms"][0])
+        info["seconds"] = round(_time.perf_counter() - t_begin, 3)
+        self.placement = {"arena": info}
 
     # ---- one phase on local planes [a, b) -----------------------------------------------------
     def _dual(self, a, b, xp, xn, out):
@@ -427,21 +569,31 @@ class ChambollePock(_SlabProblem):
         sites -- the fidelity of the iterate the PREVIOUS step produced -- into the previous step's slot, and the fix-up reads no x0."""
         g = self.geo
         flags = 0
+        own_slot, both = fid_slot, None
         if self._lag is not None:
             flags = 1                                    # TV_CP_FID_OF_INPUT
+            i = fid_slot.storage_offset() - self._cur_out.storage_offset()
             if self._lag is False:
                 fid_slot = self._lag_void                # first sweep of a block: nobody waits for its input's fidelity
             else:                                        # the same slot index, one row back
-                i = fid_slot.storage_offset() - self._cur_out.storage_offset()
                 fid_slot = self._lag[i:i + 1]
+            if self._final:
+                # last iteration of the block (round 5): the sweep returns the fidelity of its input AND of its output (complete sites), the
+                # fix-up -- called with x0 -- the rest: no reduction pass over x and x0 closes the block any more
+                flags = 3                                # TV_CP_FID_OF_INPUT | TV_CP_FID_BOTH
+                both, prev_slot = self._both[i], fid_slot
+                fid_slot = both
         _nv.check(self.lib.tv_cp_sweep(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.q),
                                        _nv.ptr(self.q_alt if self.q_alt is not None else self.q), _nv.ptr(self.x0),
                                        _nv.ptr(self.p), _nv.ptr(self.x_alt), self.sigma_D, self.reg, self.tau, self.sigma_A, flags,
                                        c0, cn, tv_slot.data_ptr(), fid_slot.data_ptr(), _nv.ptr(self.ws), self.stream))
+        if both is not None:
+            prev_slot.copy_(both[0:1])
+            own_slot.copy_(both[1:2])
 
     def _fixup(self, z0, zn, qp, qn, fid_slot):
         g = self.geo
-        lag = self._lag is not None
+        lag = self._lag is not None and not self._final
         _nv.check(self.lib.tv_cp_fixup(g.ref, _nv.ptr(self.q_alt if self.q_alt is not None else self.q), _nv.ptr(qp), _nv.ptr(qn), _nv.ptr(self.x_alt),
                                        None if lag else _nv.ptr(self.x0), self.tau, z0, zn,
                                        (self._lag_void if lag else fid_slot).data_ptr(), _nv.ptr(self.ws), self.stream))
@@ -617,8 +769,9 @@ class ChambollePock(_SlabProblem):
     def run_steps(self, rows):
         """Enqueue ``len(rows)`` iterations, row k of the (n, SLOTS) fp64 device tensor ``rows`` receiving the scalars of iteration k.
         One-sweep path (round 4): the fidelity 1/2 |x_{k+1} - x0|^2 of row k is delivered by the sweep of iteration k+1 (it has
-        x_{k+1} and x0 in registers: tv_cp_sweep, TV_CP_FID_OF_INPUT), so the fix-up reads no x0; the last row's fidelity comes from
-        one plain reduction at the end of the block.  The rows must be zero on entry (slots are written once each)."""
+        x_{k+1} and x0 in registers: tv_cp_sweep, TV_CP_FID_OF_INPUT), so the fix-up reads no x0; the LAST iteration's sweep returns the
+        fidelity of its output as well (TV_CP_FID_BOTH, round 5: over the complete sites; its fix-up, called with x0, adds the rest).
+        The rows must be zero on entry (slots are written once each)."""
         n = rows.shape[0]
         if n == 0:
             return
@@ -629,13 +782,11 @@ class ChambollePock(_SlabProblem):
         self._lag = False                # first sweep of the block: its input's fidelity belongs to nobody
         try:
             for k in range(n):
+                self._final = (k == n - 1)       # the last sweep returns both fidelities (round 4: one more pass over x and x0 closed the block)
                 self.step(rows[k])
         finally:
             self._lag = None
-        # fidelity of the last iterate: |x - x0|^2 by the flat helper, as a pure reduction (out = NULL: two words read, none written)
-        _nv.check(self.lib.tv_axpby(self.geo.ref, 1.0, _nv.ptr(self.x), 0.0, None, _nv.ptr(self.x0), None,
-                                    self._lag_void.data_ptr(), _nv.ptr(self.ws), self.stream))
-        rows[n - 1, self.F] = 0.5 * self._lag_void[0]
+            self._final = False
 
     def _run_graphed_from(self, hist, first, n_iter):
         """Capture GRAPH_BLOCK iterations (not executed during capture) and replay them over hist[first:]."""

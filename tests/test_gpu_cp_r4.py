@@ -131,3 +131,26 @@ def test_admm_placement_tuner_changes_nothing_but_the_buffers(scheme, x_solver):
     la, lb = a.run(5, graph=False), b.run(5, graph=False)
     assert np.array_equal(la, lb)
     assert torch.equal(a.result(), b.result()) and torch.equal(a.u, b.u) and torch.equal(a.z, b.z)
+
+
+@pytest.mark.parametrize("shape,pitch", [((6, 3, 32, 64), "auto"), ((5, 3, 33, 250), "auto")])
+def test_arena_option_changes_nothing_but_the_buffers(shape, pitch):
+    """ChambollePock(arena=True) (round 5, opt-in): x, x_alt, p, a private copy of x0 and q carved out of ONE allocation -- the run must be
+    bit-identical to the default (separate allocations), the caller's x0 untouched, dense and padded state alike."""
+    import torch
+    import pytv
+    rng = np.random.default_rng(11)
+    x0 = torch.as_tensor((orc.phantom(shape, dtype=np.float64) + 100 * rng.random(shape)).astype(np.float32)).cuda()
+    keep = x0.clone()
+    kw = dict(scheme="hybrid", reg_z_over_reg=0.7, reg_time=1.3, fused=True, pitch=pitch)
+    a = pytv.solvers.ChambollePock(x0, 20.0, **kw)
+    b = pytv.solvers.ChambollePock(x0, 20.0, arena=True, **kw)
+    assert b.arena and b._arena is not None and not a.arena
+    base = b._arena.data_ptr()
+    for t in (b.x, b.x_alt, b.p, b.x0, b.q):
+        assert base <= t.data_ptr() < base + b._arena.numel() * 4
+    b._tune_arena()                                   # the two-candidate measurement leaves the initial state behind
+    la, lb = a.run(6), b.run(6)
+    assert torch.equal(a.result(), b.result()) and torch.equal(a.q, b.q) and torch.equal(a.p, b.p)
+    np.testing.assert_allclose(lb, la, rtol=1e-13)
+    assert torch.equal(x0, keep)
