@@ -173,8 +173,11 @@ def live_traffic(args):
         return None, "rocprofv3 not found"
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None, "already running under a profiler"
-    n_child = 3                                  # steps + warm-up of a child pass = launches of every once-per-step kernel
-    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pmc", "off",
+    # the child passes run the SAME block structure as the timed region (one block of W, one of K iterations): since round 5 the last
+    # iteration of a block differs from the others (its fix-up reads x0: TV_CP_FID_BOTH), a 2 + 1 child would average 2 such fix-ups in 3
+    c_steps, c_warm = (min(args.steps, 24), min(args.warmup, 6)) if args.solver == "cp" else (2, 1)
+    n_child = c_steps + c_warm                   # launches of every once-per-step kernel in a child pass
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(c_steps), "--warmup", str(c_warm), "--no-cpu-baseline", "--pmc", "off",
              "--workload", args.workload, "--scheme", args.scheme, "--pitch", args.pitch, "--tune-placement", "off",
              "--solver", args.solver, "--rho", repr(args.rho), "--n-cg", str(args.n_cg), "--nz", str(args.nz)] + (["--two-kernel"] if args.two_kernel else []) \
         + (["--allow-single"] if args.allow_single else [])
@@ -223,9 +226,9 @@ def live_traffic(args):
         elif "k_normal_stream" in k or "k_cheb" in k or "k_axpby" in k:
             # the x-solve of an ADMM outer iteration is several launches of several instantiations: bytes per OUTER ITERATION
             out["xsolve"] += (totals[k]["FETCH_SIZE"] + totals[k]["WRITE_SIZE"]) / n_child
-    note = ("LIVE: two rocprofv3 child passes of this command (--pmc FETCH_SIZE, --pmc WRITE_SIZE; --steps 2 --warmup 1) in %.0f s; "
+    note = ("LIVE: two rocprofv3 child passes of this command (--pmc FETCH_SIZE, --pmc WRITE_SIZE; --steps %d --warmup %d) in %.0f s; "
             "bytes per launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md, HBM section; both counters are exact on "
-            "kernels with known byte counts, profiles/r2_pmc_calibration.txt)" % (time.perf_counter() - t0))
+            "kernels with known byte counts, profiles/r2_pmc_calibration.txt)" % (c_steps, c_warm, time.perf_counter() - t0))
     return {k: (v if v > 0 else None) for k, v in out.items()}, note
 
 
@@ -593,7 +596,7 @@ def main():
     state_before = gpu_state(local_rank) if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
-    cp.run_steps(hist[W:W + K])         # K iterations (+ one plain reduction for the last iterate's fidelity, inside the timed region)
+    cp.run_steps(hist[W:W + K])         # K iterations; the last sweep returns the final iterate's fidelity too (TV_CP_FID_BOTH): no extra pass
     barrier()
     elapsed = time.perf_counter() - t0
     state_after = gpu_state(local_rank) if rank == 0 else None

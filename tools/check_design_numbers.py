@@ -52,6 +52,8 @@ def file_has(path, token):
                 pass
     else:       # text / csv evidence: any longer decimal that rounds to the quoted one
         vals = [float(m) for m in re.findall(r"(?<![\w.])\d+\.\d+(?:[eE][-+]?\d+)?", txt)]
+        if path.endswith(".csv"):       # rocprofv3 kernel_stats.csv stores nanoseconds: a table may quote them as microseconds / milliseconds
+            vals += [v * 1e-3 for v in vals] + [v * 1e-6 for v in vals]
     want = float(token)
     return any(abs(round(v, nd) - want) < 0.5 * 10 ** (-nd) * 1e-6 + 1e-12 or ("%.*f" % (nd, v)) == token for v in vals)
 
@@ -69,7 +71,10 @@ def main():
         cells = [c.strip() for c in line.strip().strip("|").split("|")]
         if len(cells) < 2:
             continue
-        files = re.findall(r"`([^`]+\.(?:txt|json|csv))`", cells[-1])
+        files = []
+        for f in re.findall(r"`([^`]+\.(?:txt|json|csv))`", cells[-1]):      # `a_{x,y}.json` stands for a_x.json and a_y.json
+            m = re.search(r"\{([^{}]+)\}", f)
+            files += [f[:m.start()] + alt + f[m.end():] for alt in m.group(1).split(",")] if m else [f]
         if not files:
             continue                      # header row or a row without evidence files
         rows += 1
