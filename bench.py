@@ -27,7 +27,7 @@ Workloads (--workload):
   admm-small (16, 4, 256, 256)    quick functional ADMM run
 
 --solver cp | admm: default = the solver the workload names (config4* / admm-small: admm, everything else: cp).  A "step" of the ADMM
-bench is ONE outer iteration of pytv.solvers.ADMM as it comes by default (one-sweep dual side tv_admm_fused + tv_admm_fixup,
+bench is ONE outer iteration of pytv.solvers.ADMM as it comes by default (one-sweep dual side tv_admm_sweep + tv_admm_fixup,
 Chebyshev x-solve with --n-cg steps, keep_z=True); metric admm_outer_iters_per_sec.
 """
 import argparse
@@ -376,7 +376,7 @@ def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, co
     s_x, s_sw, s_fx = span("start", "xsolve"), span("xsolve", "sweep"), span("sweep", "end")
     fused_path = bool(ad.fused and ad.cheb and s_sw)
     keep_z, xs_desc, xs_launches = bool(ad.keep_z), ad.xsolve_desc, ad.xsolve_launches
-    words_sweep = 2 * nd + 3 + (nd if keep_z else 0)
+    words_sweep = 2 * nd + 3        # u read + written, x, x0 read, r written (since round 5 also with keep_z: z is rebuilt on demand from a second u array)
     words_x = ad.xsolve_words
     out = {
         "metric": METRIC["admm"], "value": it_s, "unit": "it/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -418,8 +418,8 @@ def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, co
         out["roofline"] = {"bound": "hbm", "kernel": "tv_admm_fused: k_cp_fused<S,M,...,ALG_ADMM> (group soft threshold + u update + lagged r = (x0 - x) + rho D^T t')",
                            "achieved": b_sw / t_sw / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": b_sw / t_sw / 1e9 / HBM_PEAK_GBPS,
                            "traffic": traffic.get("fused"), "traffic_source": src, "bytes_per_launch": b_sw, "ms_per_launch": 1e3 * t_sw,
-                           "note": "algorithmic bytes (2 Nd + 3%s) * 4 per voxel: u read + written, x, x0 read, r written%s; HIP events on the launch stream"
-                                   % (" + Nd" if keep_z else "", ", every sample of t' written (keep_z)" if keep_z else "") + sharded}
+                           "note": "algorithmic bytes (2 Nd + 3) * 4 per voxel: u read + written%s, x, x0 read, r written; HIP events on the launch stream"
+                                   % (" (ping-pong: keep_z rebuilds z on demand)" if keep_z else "") + sharded}
         out["roofline_xsolve"] = {"bound": "hbm", "kernel": xs_desc, "achieved": b_x / t_x / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": b_x / t_x / 1e9 / HBM_PEAK_GBPS, "traffic": traffic.get("xsolve"), "bytes_per_outer_iteration": b_x,
                                   "ms_per_outer_iteration": 1e3 * t_x, "launches_per_outer_iteration": xs_launches,

@@ -239,6 +239,13 @@ int tv_admm_zu(const tv_geom* g, const void* x, const void* x_prev, const void* 
 int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* u, void* t, const void* x0, void* r,
                   double thresh, double rho, int32_t full_store, int64_t chunk_begin, int64_t chunk_count, double* tv, double* rr,
                   void* ws, void* stream);
+/* tv_admm_fused with separate arrays for the dual variable (round 5): u_in is read, u_out written (equal: tv_admm_fused).  A caller that
+ * keeps both and swaps them after every outer iteration can rebuild the split variable z = shrink(D x + u_in, thresh) whenever it is
+ * asked for (tv_admm_zu on a copy of u_in), so the sweep need not store every sample of t' (full_store bit 0 clear): Nd words per voxel
+ * and outer iteration less than the z-preserving form of tv_admm_fused.  Replaces: nothing in the reference (README.md:26,135). */
+int tv_admm_sweep(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, const void* u_in, void* u_out, void* t,
+                  const void* x0, void* r, double thresh, double rho, int32_t full_store, int64_t chunk_begin, int64_t chunk_count,
+                  double* tv, double* rr, void* ws, void* stream);
 int tv_admm_fixup(const tv_geom* g, const void* t, const void* t_prev, const void* t_next, void* r, double rho, int64_t z_begin,
                   int64_t z_count, double* rr, void* ws, void* stream);
 /* One-sweep form of Chambolle-Pock with a data-fidelity operator A (README.md:2,148 with A != I; same geometries as tv_cp_fused):

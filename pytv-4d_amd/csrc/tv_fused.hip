@@ -240,14 +240,22 @@ int tv_cp_fixup(const tv_geom* g, const void* q, const void* q_prev, const void*
 int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, void* u, void* t, const void* x0, void* r,
                   double thresh, double rho, int32_t full_store, int64_t chunk_begin, int64_t chunk_count, double* tvout, double* rr, void* ws,
                   void* stream) {
+    return tv_admm_sweep(g, x, x_prev, x_next, u, u, t, x0, r, thresh, rho, full_store, chunk_begin, chunk_count, tvout, rr, ws, stream);
+}
+
+// tv_admm_fused with the dual variable read from u_in and written to u_out (round 5; equal: in place).  A solver that keeps both -- swapping
+// them every outer iteration -- can rebuild z = shrink(D x + u_in) on demand, so the sweep need not store every sample of t' (Nd words less)
+int tv_admm_sweep(const tv_geom* g, const void* x, const void* x_prev, const void* x_next, const void* u_in, void* u, void* t, const void* x0,
+                  void* r, double thresh, double rho, int32_t full_store, int64_t chunk_begin, int64_t chunk_count, double* tvout, double* rr,
+                  void* ws, void* stream) {
     DG d;
     if (int rc = make_dg(g, d, true)) return rc;
-    if (!x || !u || !t || !x0 || !r || !tvout || !rr || !ws) return fail(TV_E_ARG, "NULL array");
+    if (!x || !u_in || !u || !t || !x0 || !r || !tvout || !rr || !ws) return fail(TV_E_ARG, "NULL array");
     if (x == r || x0 == r) return fail(TV_E_ARG, "r must not alias x or x0");
-    if (u == t) return fail(TV_E_ARG, "u and t must be different arrays");
+    if (u == t || u_in == t) return fail(TV_E_ARG, "u and t must be different arrays");
     if (!(thresh >= 0.0)) return fail(TV_E_ARG, "thresh must be >= 0");
     if (!tv_cp_fused_supported(g)) return fail(TV_E_ARG, "geometry not supported by the one-sweep path");
-    if (!aligned16({x, x_prev, x_next, u, t, x0, r, d.wv})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
+    if (!aligned16({x, x_prev, x_next, u_in, u, t, x0, r, d.wv})) return fail(TV_E_ARG, "arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     SweepPlan sp;
     bool empty = false;
@@ -261,7 +269,7 @@ int tv_admm_fused(const tv_geom* g, const void* x, const void* x_prev, const voi
     double* w1 = w0 + sp.nmax + kStage + 16;
     auto sweep = [&]<typename T>() -> int {
         FusedArgsT<T> a{(const T*)x, (const T*)x_prev, (const T*)x_next, (T*)u, (const T*)x0, (T*)t,
-                        (T*)r, (T)thresh, (T)0, (T)rho, (T)0, (T)0, w0, w1, (int)(full_store & 3), (const T*)u};
+                        (T*)r, (T)thresh, (T)0, (T)rho, (T)0, (T)0, w0, w1, (int)(full_store & 3), (const T*)u_in};
         return tvm::fused_sweep<T, ALG_ADMM>(g, d, sp.lc, st, a, sp.zc, sp.chunk0, sp.xw, sp.force_win);
     };
     const int rc = (g->dtype == TV_F32) ? sweep.template operator()<float>() : sweep.template operator()<double>();

@@ -95,6 +95,8 @@ _SIGNATURES = {
     "tv_axpby": (ctypes.c_int, [_G, ctypes.c_double, _c_void_p, ctypes.c_double, _c_void_p, _c_void_p, _c_void_p, _c_double_p, _c_void_p, _c_void_p]),
     "tv_admm_fused": (ctypes.c_int, [_G] + [_c_void_p] * 7 + [ctypes.c_double, ctypes.c_double, ctypes.c_int32] + [ctypes.c_int64] * 2
                       + [_c_double_p] * 2 + [_c_void_p, _c_void_p]),
+    "tv_admm_sweep": (ctypes.c_int, [_G] + [_c_void_p] * 8 + [ctypes.c_double, ctypes.c_double, ctypes.c_int32] + [ctypes.c_int64] * 2
+                      + [_c_double_p] * 2 + [_c_void_p, _c_void_p]),
     "tv_admm_fixup": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [ctypes.c_double] + [ctypes.c_int64] * 2 + [_c_double_p, _c_void_p, _c_void_p]),
     "tv_DT_axpy": (ctypes.c_int, [_G] + [_c_void_p] * 5 + [ctypes.c_double, _c_void_p, _c_void_p]),
     "tv_DT_axpy2": (ctypes.c_int, [_G] + [_c_void_p] * 6 + [ctypes.c_double, ctypes.c_double, _c_void_p, _c_void_p]),

@@ -1208,10 +1208,11 @@ class ADMM(_SlabProblem):
         L = normal_spectral_bound(scheme, self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time, self.geo.time_weight_max)
         self._cheb_coef = chebyshev_coefficients(1.0 + self.rho * L, self.n_cg) if self.cheb else None
         # one-sweep dual side (round 3): z / u update + the residual of the next x-solve in one pass over u
-        # (tv_admm_fused + tv_admm_fixup: 2 Nd + 3 words per voxel instead of the 4 Nd + 6 of tv_admm_tu + tv_DT_axpy +
-        # tv_normal_op2).  keep_z=True (default since round 4: ``.z`` keeps working as it did before the one-sweep path existed) stores
-        # every sample of t' = (z - u) - D x; keep_z=False only the samples the fix-up reads (2 Nd -> Nd + 0.3 written words: the
-        # benchmarks' setting) -- the split variable z is then not recoverable and ``.z`` raises, naming this flag.
+        # (tv_admm_sweep + tv_admm_fixup: 2 Nd + 3 words per voxel instead of the 4 Nd + 6 of tv_admm_tu + tv_DT_axpy +
+        # tv_normal_op2).  keep_z=True (default since round 4: ``.z`` keeps working as it did before the one-sweep path existed): round 5
+        # keeps a SECOND u array instead of every sample of t' -- u is ping-ponged and z = shrink(D x + u_old) is rebuilt when ``.z`` is
+        # asked for, so the sweep moves the same 2 Nd + 3 words as with keep_z=False (round 4: 3 Nd + 3); keep_z=False saves the memory
+        # of that array -- the split variable z is then not recoverable and ``.z`` raises, naming this flag.
         can_fuse = self.single and self.n_cg > 0 and bool(self.lib.tv_cp_fused_supported(self.geo.ref))
         if fused and not can_fuse:
             raise ValueError("fused=True needs single_reduction, n_cg > 0 and a geometry tv_cp_fused_supported() accepts")
@@ -1221,6 +1222,10 @@ class ADMM(_SlabProblem):
         self.x = self.image_copy(self.x0)
         self._zt = self.new_grad()                   # z, or t = z - u (single_reduction)
         self.u = self.new_grad()
+        # round 5: on the one-sweep path keep_z costs MEMORY, not traffic -- u is ping-ponged (tv_admm_sweep reads u, writes u_alt, the roles
+        # swap), so z = shrink(D x + u_old) can be rebuilt whenever ``.z`` is asked for and the sweep stores t' sparsely as with
+        # keep_z=False: 2 Nd + 3 words per voxel instead of 3 Nd + 3 (round 4 stored every sample of t' = z - u - D x)
+        self.u_alt = self.new_grad() if (self.fused and self.keep_z) else None
         self.b = self.new_image()
         self.r = self.new_image()
         self.d = self.new_image()
@@ -1286,6 +1291,8 @@ class ADMM(_SlabProblem):
         self.x.copy_(self.x0)
         for k in self._STATE[1:]:
             getattr(self, k).zero_()
+        if self.u_alt is not None:
+            self.u_alt.zero_()
         for t in (self.sc, self.dots3, self.dots, self.rr):
             t.zero_()
         self._have_r = False
@@ -1311,8 +1318,10 @@ class ADMM(_SlabProblem):
             torch.cuda.synchronize(self.device)
             return a.elapsed_time(b) / n_steps
 
+        names = self._STATE + (("u_alt",) if self.u_alt is not None else ())
+
         def bound():                                 # the buffer roles rotate inside a step: take what is bound NOW
-            return {k: getattr(self, k) for k in self._STATE}
+            return {k: getattr(self, k) for k in names}
 
         # the WHOLE tuner is an optimisation, never a failure (round-4 advice: the baseline measurement used to sit outside the try --
         # an out-of-memory error in a halo or Chebyshev temporary there failed the constructor)
@@ -1324,6 +1333,8 @@ class ADMM(_SlabProblem):
             for _ in range(n_sets - 1):
                 cand = dict(x=self.new_image(), _zt=self.new_grad(), u=self.new_grad(), b=self.new_image(), r=self.new_image(),
                             d=self.new_image(), Ad=self.new_image())
+                if self.u_alt is not None:
+                    cand["u_alt"] = self.new_grad()
                 for k, v in cand.items():
                     setattr(self, k, v)
                 t = timed()
@@ -1353,11 +1364,16 @@ class ADMM(_SlabProblem):
             if not self.keep_z:
                 raise RuntimeError("ADMM(..., keep_z=False) stores only the samples of z - u - D x its fix-up reads: z is not available; "
                                    "construct the solver with keep_z=True (the default)")
-            d = self.new_grad()
+            # rebuilt on demand from x and the dual variable the last sweep READ (u_alt after the swap): z = shrink(D x + u_old)
+            z = self.new_grad()
+            u_old = self.new_grad()                  # (not .clone(): a clone of a pitched view is dense)
+            u_old.copy_(self.u_alt)
+            tv_ = torch.zeros(1, dtype=torch.float64, device=self.device)
             hp, hn = self._halo2(self.x)
-            _nv.check(self.lib.tv_D(self.geo.ref, _nv.ptr(self.x), _nv.ptr(hp[1:2] if hp is not None else None),
-                                    _nv.ptr(hn[0:1] if hn is not None else None), _nv.ptr(d), self.stream))
-            return self._zt + self.u + d
+            _nv.check(self.lib.tv_admm_zu(self.geo.ref, _nv.ptr(self.x), _nv.ptr(hp[1:2] if hp is not None else None),
+                                          _nv.ptr(hn[0:1] if hn is not None else None), _nv.ptr(z), _nv.ptr(u_old), self.reg / self.rho,
+                                          tv_.data_ptr(), _nv.ptr(self.ws), self.stream))
+            return z
         return self._zt + self.u if self.single else self._zt
 
     def _halo2(self, v):
@@ -1508,11 +1524,14 @@ class ADMM(_SlabProblem):
         hp, hn = self._halo2(self.x)
         xp = hp[1:2] if hp is not None else None      # plane z0-1
         xn = hn[0:1] if hn is not None else None      # plane z0+nz
-        _nv.check(lib.tv_admm_fused(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.u), _nv.ptr(self._zt),
+        u_out = self.u_alt if self.u_alt is not None else self.u          # keep_z: ping-pong (z is rebuilt from the array that was READ)
+        _nv.check(lib.tv_admm_sweep(g.ref, _nv.ptr(self.x), _nv.ptr(xp), _nv.ptr(xn), _nv.ptr(self.u), _nv.ptr(u_out), _nv.ptr(self._zt),
                                     _nv.ptr(self.x0), _nv.ptr(self.r), self.reg / self.rho, self.rho,
-                                    (1 if self.keep_z else 0) | (2 if out_fid is not None else 0),
+                                    (2 if out_fid is not None else 0),
                                     0, -1, out_tv.data_ptr(), (out_fid if out_fid is not None else self.rr[0:1]).data_ptr(),
                                     _nv.ptr(self.ws), self.stream))
+        if self.u_alt is not None:
+            self.u, self.u_alt = self.u_alt, self.u
         self._mark("sweep")
         # the boundary planes of t' travel to the neighbours (as those of t = z - u do in _rhs)
         h = s.exchange(send_prev=self._zt[0, self.ch_fwd] if self.plan.g_send_prev else None,
@@ -1616,6 +1635,7 @@ class ADMM(_SlabProblem):
         # one and the roles are swapped): a capture that fails part-way must not leave them pointing at buffers whose kernels
         # never ran (round-3 advice; ChambollePock._run_graphed_from does the same for x / x_alt)
         saved = (self.x, self.d, self.Ad, self.b, self.r, self._have_r)
+        saved_u = (self.u, self.u_alt)
         try:
             buf = torch.zeros((K, 2), dtype=torch.float64, device=self.device)
             graph = torch.cuda.CUDAGraph()
@@ -1624,11 +1644,13 @@ class ADMM(_SlabProblem):
                     self.step(buf[k])
         except Exception:
             self.x, self.d, self.Ad, self.b, self.r, self._have_r = saved
+            self.u, self.u_alt = saved_u
             return 0                             # nothing ran: undo the bookkeeping, stay eager
-        if (self.x is not saved[0]) or (self.d is not saved[1]) or (self.Ad is not saved[2]) or (self.b is not saved[3]):
+        if (self.x is not saved[0]) or (self.d is not saved[1]) or (self.Ad is not saved[2]) or (self.b is not saved[3]) or (self.u is not saved_u[0]):
             # the block does not return the buffers to their roles (odd number of role swaps): replaying it would not be the
             # same iteration twice -- cannot happen with GRAPH_BLOCK even, checked all the same
             self.x, self.d, self.Ad, self.b, self.r, self._have_r = saved
+            self.u, self.u_alt = saved_u
             return 0
         done = 0
         for r in range(nrep):

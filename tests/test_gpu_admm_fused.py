@@ -78,6 +78,15 @@ def test_admm_fused_calls_match_numpy(nvlib, scheme, shape, zchunk, tvopt):
                 np.testing.assert_allclose(td.cpu().numpy(), t - dx, rtol=0, atol=tol * 10)
             else:
                 assert (td == 7.0).float().mean().item() > 0.3          # most samples are never written
+            # tv_admm_sweep (round 5): the same sweep reading u from one array and writing another -- bit-identical u', r, t', scalars,
+            # the array it read untouched (what lets solvers.ADMM rebuild z = shrink(D x + u_in) on demand)
+            u_in, u_out = torch.as_tensor(u).cuda(), torch.full_like(ud, 3.0)
+            td2, rd2, sc2 = torch.full_like(ud, 7.0), torch.empty_like(xd), torch.zeros(3, dtype=torch.float64, device="cuda")
+            nv.check(lib.tv_admm_sweep(g.ref, nv.ptr(xd), None, None, nv.ptr(u_in), nv.ptr(u_out), nv.ptr(td2), nv.ptr(x0d), nv.ptr(rd2), thresh,
+                                       rho, full, 0, -1, sc2[0:1].data_ptr(), sc2[1:2].data_ptr(), nv.ptr(ws), st))
+            nv.check(lib.tv_admm_fixup(g.ref, nv.ptr(td2), None, None, nv.ptr(rd2), rho, 0, -1, sc2[2:3].data_ptr(), nv.ptr(ws), st))
+            assert torch.equal(u_out, ud) and torch.equal(rd2, rd) and torch.equal(td2, td) and torch.equal(sc2, sc)
+            assert torch.equal(u_in, torch.as_tensor(u).cuda())
         # bit 1 of full_store: the second partial is |x - x0|^2 over all sites (what the Chebyshev x-solve asks for)
         ud = torch.as_tensor(u).cuda()
         nv.check(lib.tv_admm_fused(g.ref, nv.ptr(xd), None, None, nv.ptr(ud), nv.ptr(td), nv.ptr(x0d), nv.ptr(rd), thresh, rho, 2,

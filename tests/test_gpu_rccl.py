@@ -171,7 +171,7 @@ def test_bench_admm_line_on_one_gpu():
     assert out["config"]["workload"].startswith("admm-small 16x4x256x256") and out["config"]["x_solver"] == "chebyshev"
     nd, n_cg = out["config"]["nd"], out["config"]["n_cg"]
     w = out["words_per_voxel_and_outer_iteration"]
-    assert w["sweep"] == 3 * nd + 3 and w["total"] == w["sweep"] + w["xsolve"] and 0 < w["xsolve"] <= 4 * n_cg - 6
+    assert w["sweep"] == 2 * nd + 3 and w["total"] == w["sweep"] + w["xsolve"] and 0 < w["xsolve"] <= 4 * n_cg - 6
     r = out["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["bytes_per_launch"] == 4.0 * w["sweep"] * 16 * 4 * 256 * 256
     assert 0 < out["roofline_xsolve"]["frac"] < 1 and out["roofline_xsolve"]["launches_per_outer_iteration"] >= 1
