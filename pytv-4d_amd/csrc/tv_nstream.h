@@ -63,7 +63,9 @@ __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long f
                                             double& acc0, double& acc1) {
     Vec<T, V> o;
     if constexpr (CHEB) {
-        const Vec<T, V> bv = NLDU<T, V>(a.b + fo, voff);
+        // b == x (the first step of a Chebyshev solve: e_2 from r alone, x = b = r): the value is in registers already -- one stream less
+        // (uniform branch; round 5: that launch moved 3 streams for its 2 words)
+        const Vec<T, V> bv = (a.b == a.x) ? xm : NLDU<T, V>(a.b + fo, voff);
         Vec<T, V> yv = vsplat<T, V>(T(0)), av = vsplat<T, V>(T(0)), rv = xm;
         if (a.y != nullptr) yv = NLDU<T, V>(a.y + fo, voff);            // no y: y = yscale * b (0 after e_0 = 0)
         else yv = a.yscale * bv;
@@ -200,6 +202,17 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                 E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu1_t<T>(pc + foff(t), eoff) : T(0);
             }
         }
+        // TWIN (M > 8: windows of 8 frames): the frames just outside the window, x(z, t0 - 1) and x(z, t0 + M), are needed for the time
+        // differences of the window's first / last frame.  Round 5: they are REQUESTED A PLANE AHEAD like everything else (Wp / Wn);
+        // until then each was a load issued where it was consumed -- two exposed memory round trips per plane step, which is what held
+        // every launch of the M = 16 Chebyshev solve at >= 1.58 ms whatever it moved (profiles/r5c_admm_config4slab_upwind_kernel_stats.csv)
+        const bool w_prev = TWIN && g.ta && t0 > 0, w_next = TWIN && g.ta && t0 + M < Mg;
+        VT Wp = zero, Wn = zero;
+        {
+            const T* pc = plane(zs);
+            if (w_prev && pc != nullptr && ok) Wp = ldu_t<T, V>(pc + foff(-1), voff);
+            if (w_next && pc != nullptr && ok) Wn = ldu_t<T, V>(pc + foff(M), voff);
+        }
         for (int z = zs; z <= ze; ++z) {              // step ze only finishes plane ze - 1
             st_sync_plane();
             const bool in_chunk = (z < ze), next_in = (z + 1 < ze);
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
             // plane requested now (consumed at step z + 1); the step behind the chunk needs the centre vectors only
             const T* pn = (next_in || (g.za && z + 1 == ze)) ? plane(z + 1) : nullptr;
             VT cold = zero;
-            if (TWIN && g.ta && t0 > 0 && in_chunk) cold = ok ? ldu_t<T, V>(pc + foff(-1), voff) : zero;
+            if (w_prev && in_chunk) cold = Wp;
 #pragma unroll
             for (int t = 0; t < M; ++t) {
                 if (TWIN && !fvalid(t)) break;
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                         VT tt = zero;
                         if (tg > 0) tt = tt + (c - cold);
                         if (t + 1 < M) { if (tg + 1 < Mg) tt = tt - (C[(t + 1 < M) ? t + 1 : t] - c); }
-                        else if (TWIN && tg + 1 < Mg) tt = tt - ((ok ? ldu_t<T, V>(pc + foff(t + 1), voff) : zero) - c);
+                        else if (TWIN && tg + 1 < Mg) tt = tt - (Wn - c);
                         r = r + mf2 * tt;
                     }
                     R[t] = ns_add<T, V>(r, dz);
@@ -253,6 +266,8 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                 C[t] = load_c(pn, t);
                 H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pn + foff(t), hoff) : zero;
                 E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu1_t<T>(pn + foff(t), eoff) : T(0);
+                if (w_prev && t == 0) Wp = (pn != nullptr && next_in && ok) ? ldu_t<T, V>(pn + foff(-1), voff) : zero;       // consumed at the start of step z + 1
+                if (w_next && t == M - 1) Wn = (pn != nullptr && next_in && ok) ? ldu_t<T, V>(pn + foff(M), voff) : zero;  // ... at its end
                 // ---- epilogue of plane z-1 --------------------------------------------------------------------------------
                 if (!ok || z == zs) continue;
                 const long long fo = (long long)(z - 1) * g.s_z + foff(t);
