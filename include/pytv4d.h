@@ -286,6 +286,8 @@ int tv_normal_op2(const tv_geom* g, const void* x, const void* x_prev, const voi
  *   (x may be b itself: with e_1 = a_0 b never stored, the first two steps are  e_2 = b + a' (b - A b) + b' b  and a step with
  *   y = a_0 b -- 2 + 3 words instead of 2 + 3 + 4)
  *   dots[0] = |b - A x|^2,  dots[1] = |out - ref|^2 if ref is given, else |x|^2      (device fp64, local planes)
+ *   dots may be NULL (round 5): no dot products -- the streaming kernel drops their fp64 arithmetic and the two reduction launches
+ *   (the ADMM x-solve needs none of them unless it is asked for the fidelity of its last step); ref needs dots.
  * out must not alias an input.  x_prev / x_next: TWO halo planes each, as in tv_normal_op.  The coefficients of step k follow from
  * the spectral interval [1, 1 + rho L] alone (pytv/solvers.py::chebyshev_coefficients restates the recurrence).
  * tv_axpby: out = a x + b y (y NULL: a x); *dist2 (or NULL, then ref and ws may be NULL too) = |out - ref|^2; out NULL (with ref):

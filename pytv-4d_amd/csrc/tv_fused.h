@@ -226,6 +226,38 @@ template <typename T, int V> __device__ __forceinline__ void stu_s_t(T* ubase, u
     *p = v;
 #endif
 }
+// ---- raw buffer access (round 5, streaming kernels) ---------------------------------------------------------------------------------
+// A wave-uniform descriptor (base = one frame of one plane of one stream, num_records = bytes of a frame, 0 when the frame / plane /
+// stream does not exist) + a per-lane byte offset (BUF_OOB for lanes that must not take part).  The hardware's range check is the
+// predicate: such a load returns 0, such a store is dropped -- NO branch and NO phi around a memory operation.  That is what lets the
+// compiler count (s_waitcnt vmcnt(n)): a load under a uniform branch reaches its consumer through a copy that has to wait for the load
+// where it was ISSUED, which with one in-order counter means vmcnt(0) once per frame (tv_subgrad2.h found the same for its kernel).
+using Rsrc = __amdgpu_buffer_rsrc_t;
+constexpr unsigned BUF_OOB = 0x80000000u;        // beyond any frame (the hosts send frames of >= 2^31 bytes to other kernels)
+typedef int buf_v4i __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ Rsrc buf_rsrc(const T* base, bool valid, int nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, valid ? nbytes : 0, 0x00020000);
+}
+template <typename T, int V, int AUX = 0> __device__ __forceinline__ Vec<T, V> buf_ld(Rsrc r, unsigned off) {
+    static_assert(sizeof(Vec<T, V>) == 16, "16-byte lanes");
+    const buf_v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX);
+    return __builtin_bit_cast(Vec<T, V>, v);
+}
+template <typename T, int AUX = 0> __device__ __forceinline__ T buf_ld1(Rsrc r, unsigned off) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, AUX));
+    } else {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, AUX);
+        return __builtin_bit_cast(T, v);
+    }
+}
+template <typename T, int V, int AUX = 0> __device__ __forceinline__ void buf_st(Rsrc r, unsigned off, const Vec<T, V>& v) {
+    static_assert(sizeof(Vec<T, V>) == 16, "16-byte lanes");
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_v4i, v), r, (int)off, 0, AUX);
+}
+constexpr int BUF_NT = 2;                        // aux bit 1 = nt on gfx950 (what __builtin_nontemporal_load / _store emit)
+
 __device__ __forceinline__ void stu(float* ubase, unsigned voff, const F4& v) {
     *reinterpret_cast<F4*>(reinterpret_cast<char*>(ubase) + voff) = v;
 }
@@ -358,7 +390,7 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
     // so its waves waited ~77 % of the time with too few bytes in flight: sweep 26.6 - 27.4 -> 21.2 - 23.0 ms on the
     // north-star volume (0.52 -> 0.63 of peak; profiles/r2_ab_pfq.txt).  Measured for upwind / downwind too: 3 - 7 % SLOWER
     // there (they already request plane z+1 of x a step ahead), so it stays off; hybrid has no registers for it.
-    constexpr bool PFQ = (TV_FUSED_PFQ != 0) && (S == CENTRAL) && (!TWIN || TV_FUSED_PFQ_TWIN != 0);
+    constexpr bool PFQ = (TV_FUSED_PFQ != 0) && (S == CENTRAL || (TV_FUSED_PFQ == 2 && S != HYBRID)) && (!TWIN || TV_FUSED_PFQ_TWIN != 0);      // 2: EXPERIMENT every Nd = 4 scheme
     VT qpre[PFQ ? 4 : 1];
     if (PFQ) {
 #pragma unroll

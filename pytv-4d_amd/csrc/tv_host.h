@@ -172,7 +172,7 @@ template <typename F> inline int dispatch(int scheme, int dtype, bool vec, F&& f
 // dispatch changed behind its back.  An option that was never set (neither way) takes the call site's default.
 struct TvOption { const char* name; std::atomic<int> has; std::atomic<int> value; };
 inline TvOption g_options[] = {
-    {"TV_NO_MARCH", 0, 0}, {"TV_MARCH_MIN_PLANE_KB", 0, 0}, {"TV_ZCHUNK", 0, 0}, {"TV_MARCH_D", 0, 0},
+    {"TV_NO_MARCH", 0, 0}, {"TV_MARCH_MIN_PLANE_KB", 0, 0}, {"TV_ZCHUNK", 0, 0}, {"TV_NS_ZCHUNK", 0, 0}, {"TV_MARCH_D", 0, 0},
     {"TV_NO_MARCH_SUBGRAD", 0, 0}, {"TV_NO_MARCH_NORMAL", 0, 0}, {"TV_SCALAR_GATHER", 0, 0}, {"TV_NO_FUSED", 0, 0},
     {"TV_NO_FUSED_TWIN", 0, 0}, {"TV_FUSED_XW", 0, 0}, {"TV_FUSED_FORCE_TWIN", 0, 0}, {"TV_NO_FUSED_SUBGRAD", 0, 0},
     {"TV_NORMAL_KERNEL", 0, 0}, {"TV_D_KERNEL", 0, 0}, {"TV_DT_KERNEL", 0, 0}, {"TV_FUSED_MIN_KVOXELS", 0, 0}, {"TV_SG_KERNEL", 0, 0}, {"TV_SPARE", 0, 0}, {"TV_SG_ALIGNED", 0, 0},

@@ -1289,7 +1289,8 @@ int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void
                  double yscale, const void* add, const void* ref, double alpha, double beta, void* out, double* dots, void* ws, void* stream) {
     DG d;
     if (int rc = make_dg(g, d, true)) return rc;
-    if (x == nullptr || b == nullptr || out == nullptr || dots == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
+    if (x == nullptr || b == nullptr || out == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
+    if (ref != nullptr && dots == nullptr) return fail(TV_E_ARG, "ref without a place for |out - ref|^2");
     if (out == x || out == y || out == b || out == add || out == ref) return fail(TV_E_ARG, "out must not alias an input");
     if (y != nullptr && yscale != 0.0) return fail(TV_E_ARG, "yscale is the stand-in for a missing y (y = yscale * b)");
     const int e_lo = (g->z0 > 0) ? 1 : 0, e_hi = (g->z0 + g->nz < g->nz_global) ? 1 : 0;
@@ -1303,11 +1304,14 @@ int tv_cheb_step(const tv_geom* g, const void* x, const void* x_prev, const void
     if (env_int("TV_NORMAL_KERNEL", 2) == 2 && tvm::N_stream_ok(g, d, vec)) {
         long long nb;
         const tvm::NCheb c{y, add, ref, alpha, beta, yscale};
-        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, b, out, nullptr, rho, st, &nb, w0, w1, &c)) return rc;
+        if (int rc = tvm::N_stream(g, d, x, x_prev, x_next, b, out, nullptr, rho, st, &nb, dots ? w0 : nullptr, dots ? w1 : nullptr, &c)) return rc;
+        if (dots == nullptr) return 0;
         if (int rc = reduce_partials(w0, nb, nmax, dots, st)) return rc;
         return reduce_partials(w1, nb, nmax, dots + 1, st);
     }
     // composition: out <- A x with the operator of this geometry, then one flat pass
+    double* const scratch_dots = w1 + nmax + kStage + 16;        // dots == NULL: the partial sums still exist on this path, their totals go nowhere
+    if (dots == nullptr) dots = scratch_dots;
     if (int rc = tv_normal_op(g, x, x_prev, x_next, rho, out, dots, ws, stream)) return rc;
     TV_FLAT_LAUNCH(k_cheb_combine, g->dtype, nvox(d), ({x, b, y, add, ref, out}), (const T*)x, (const T*)b, (const T*)y, (const T*)add,
                    (const T*)ref, (T*)out, (T)alpha, (T)beta, (T)yscale, w0, w1);

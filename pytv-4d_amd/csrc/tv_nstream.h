@@ -10,6 +10,7 @@
 //                     b != nullptr:  out = b - A x (and out2 = out when given: r and the first search direction of CG),
 //                                    dots = { <out, out>, <x, x> }
 #pragma once
+#include <type_traits>
 #include "tv_device.h"
 #include "tv_stencil.h"
 #include "tv_fused.h"
@@ -58,26 +59,50 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> NLDU(const T* 
     return ldu_t<T, V>(ubase, voff);
 #endif
 }
+// The streamed operands of one site-vector's epilogue.  Round 5 (late): they are REQUESTED ONE FRAME AHEAD of the epilogue that consumes
+// them (ns_epi_load at the end of frame t for frame t + 1).  Loaded where they were consumed they were the youngest loads in flight, so
+// every frame ended in s_waitcnt vmcnt(0): a full memory round trip per frame with nothing else to do, which also drained the plane-ahead
+// requests of the stencil -- the kernel ran at the latency of memory, not its bandwidth (Chebyshev step 0.54 of peak at 8 waves per CU).
+template <typename T, int V> struct NsEpiIn { Vec<T, V> b, y, add, ref; };
+// k_normal_stream (radius-1 schemes): every stream through a frame descriptor (tv_fused.h, "raw buffer access") -- absent streams and
+// absent frames have num_records = 0, so the four loads are unconditional and the frame loop is straight-line code
 template <typename T, int V, bool CHEB>
-__device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long fo, unsigned voff, const Vec<T, V>& xm, const Vec<T, V>& ax,
-                                            double& acc0, double& acc1) {
-    Vec<T, V> o;
+__device__ __forceinline__ void ns_epi_load_buf(const NormalArgsT<T>& a, long long fo, bool valid, int fbytes, unsigned boff, NsEpiIn<T, V>& in) {
+    constexpr int NT = TV_NSTREAM_NT ? BUF_NT : 0;
     if constexpr (CHEB) {
         // b == x (the first step of a Chebyshev solve: e_2 from r alone, x = b = r): the value is in registers already -- one stream less
-        // (uniform branch; round 5: that launch moved 3 streams for its 2 words)
-        const Vec<T, V> bv = (a.b == a.x) ? xm : NLDU<T, V>(a.b + fo, voff);
-        Vec<T, V> yv = vsplat<T, V>(T(0)), av = vsplat<T, V>(T(0)), rv = xm;
-        if (a.y != nullptr) yv = NLDU<T, V>(a.y + fo, voff);            // no y: y = yscale * b (0 after e_0 = 0)
-        else yv = a.yscale * bv;
-        if (a.add != nullptr) av = NLDU<T, V>(a.add + fo, voff);
-        if (a.ref != nullptr) rv = NLDU<T, V>(a.ref + fo, voff);
+        in.b = buf_ld<T, V, NT>(buf_rsrc<T>(a.b + fo, valid && a.b != a.x, fbytes), boff);
+        in.y = buf_ld<T, V, NT>(buf_rsrc<T>(a.y + fo, valid && a.y != nullptr, fbytes), boff);
+        in.add = buf_ld<T, V, NT>(buf_rsrc<T>(a.add + fo, valid && a.add != nullptr, fbytes), boff);
+        in.ref = buf_ld<T, V, NT>(buf_rsrc<T>(a.ref + fo, valid && a.ref != nullptr, fbytes), boff);
+    }
+    // (the CG forms load b where they use it, inside the branch that tells them apart: tv_normal_op without b has no operand at all, and a
+    // load from an absent stream still takes its slot in the queue -- measured: + 10 % on the 2-word operator)
+}
+// BUF: the stores go through descriptors too (fbytes, boff), lanes outside the frame drop theirs
+template <typename T, int V, bool CHEB, bool BUF = false>
+__device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long fo, unsigned voff, const Vec<T, V>& xm, const Vec<T, V>& ax,
+                                            const NsEpiIn<T, V>& in, double& acc0, double& acc1, int fbytes = 0) {
+    constexpr int NT = TV_NSTREAM_NT ? BUF_NT : 0;
+    Vec<T, V> o;
+    if constexpr (CHEB) {
+        const Vec<T, V> bv = (a.b == a.x) ? xm : in.b;
+        const Vec<T, V> yv = (a.y != nullptr) ? in.y : a.yscale * bv;          // no y: y = yscale * b (0 after e_0 = 0)
+        const Vec<T, V> av = (a.add != nullptr) ? in.add : vsplat<T, V>(T(0));
+        const Vec<T, V> rv = (a.ref != nullptr) ? in.ref : xm;
+        Vec<T, V> res;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const T res = bv.v[i] - ax.v[i];
-            o.v[i] = av.v[i] + ((xm.v[i] + a.alpha * res) + a.beta * (xm.v[i] - yv.v[i]));
-            acc0 += (double)res * (double)res;
-            const double e = (a.ref != nullptr) ? (double)o.v[i] - (double)rv.v[i] : (double)xm.v[i];
-            acc1 += e * e;
+            res.v[i] = bv.v[i] - ax.v[i];
+            o.v[i] = av.v[i] + ((xm.v[i] + a.alpha * res.v[i]) + a.beta * (xm.v[i] - yv.v[i]));
+        }
+        if (a.part0 != nullptr) {          // the dot products on request only (tv_cheb_step, dots == NULL: ~ 10 % of the frame's instructions)
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                acc0 += (double)res.v[i] * (double)res.v[i];
+                const double e = (a.ref != nullptr) ? (double)o.v[i] - (double)rv.v[i] : (double)xm.v[i];
+                acc1 += e * e;
+            }
         }
     } else if (a.b == nullptr) {
 #pragma unroll
@@ -87,16 +112,22 @@ __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long f
             acc1 += (double)xm.v[i] * (double)xm.v[i];
         }
     } else {
-        const Vec<T, V> bv = NLDU<T, V>(a.b + fo, voff);
+        Vec<T, V> bv;
+        if constexpr (BUF) bv = buf_ld<T, V, NT>(buf_rsrc<T>(a.b + fo, true, fbytes), voff);
+        else bv = NLDU<T, V>(a.b + fo, voff);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             o.v[i] = bv.v[i] - ax.v[i];
             acc0 += (double)o.v[i] * (double)o.v[i];
             acc1 += (double)xm.v[i] * (double)xm.v[i];
         }
-        if (a.out2 != nullptr) NSTU<T, V>(a.out2 + fo, voff, o);
+        if (a.out2 != nullptr) {
+            if constexpr (BUF) buf_st<T, V, NT>(buf_rsrc<T>(a.out2 + fo, true, fbytes), voff, o);
+            else NSTU<T, V>(a.out2 + fo, voff, o);
+        }
     }
-    NSTU<T, V>(a.out + fo, voff, o);
+    if constexpr (BUF) buf_st<T, V, NT>(buf_rsrc<T>(a.out + fo, true, fbytes), voff, o);
+    else NSTU<T, V>(a.out + fo, voff, o);
 }
 
 constexpr int NS_TWN = TV_TWN;
@@ -178,7 +209,8 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
         // so one predicated load per lane is enough (row 0 reads y-1, row 3 reads y+1)
         const bool want_le = (lx == 0) && ok && (col0 > 0), want_re = (lx == 15) && ok && (col0 + V < g.nx);
         const unsigned eoff = want_le ? voff - (unsigned)sizeof(T) : voff + 16u;
-        auto fvalid = [&](int t) { return !TWIN || (t0 + t < Mg); };
+        const int NV = ((TWIN ? Mg : g.m) - t0 < M) ? (TWIN ? Mg : g.m) - t0 : M;          // frames of this window (non-TWIN: M, but the compiler must not know -- see the frame loop)
+        auto fvalid = [&](int t) { return t < NV; };
         auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };
         // State: plane z (C), plane z-1 (P), the result of plane z-1 still waiting for its forward z term (R), the halo rows /
         // border elements of plane z (H, E).  The z term is SHARED: dz(z) = wz^2 (x(z) - x(z-1)) is the backward term of plane z
@@ -186,49 +218,69 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
         // the step.  That lets the centre vectors, halo rows and border elements of plane z+1 all be requested in the same
         // frame of step z -- the moment the owners of those lines request them (round 2: requested one step apart they cost
         // a second trip to memory, 17 GB read for an 8.6 GB image).
-        VT C[M], P[M], R[M], H[M];
+        // Registers: XA / XB hold planes z and z - 1 in turn.  The z loop is unrolled by two steps with the roles swapped: plane z + 1 is loaded
+        // into the slot of plane z - 1 once its epilogue is through.  (With one step per iteration P[t] <- C[t] <- load is a rotation through
+        // three registers that the compiler closes with copies at the loop's end -- copies of values still in flight, i.e. a wait for the
+        // youngest loads once per step.)
+        VT XA[M], XB[M], R[M], H[M];
         T E[M];
         auto plane = [&](int zl) { return g.za ? zplane<T>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
-        auto load_c = [&](const T* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu_t<T, V>(pl + foff(t), voff) : zero; };
+        // every access: frame descriptor + per-lane offset (tv_fused.h, "raw buffer access"); lanes / frames / planes that do not take part
+        // are out of range for the hardware, not branched around
+        const int fbytes = (int)(g.s_t * (long long)sizeof(T));
+        const unsigned boff = ok ? voff : BUF_OOB;
+        const unsigned bhoff = (want_up || want_dn) ? hoff : BUF_OOB, beoff = (want_le || want_re) ? eoff : BUF_OOB;
+        auto frame = [&](const T* pl, int t, bool valid) { return buf_rsrc<T>(pl + foff(t), pl != nullptr && valid && fvalid(t), fbytes); };
+        // TWIN (M > 8: windows of 8 frames): the frames just outside the window, x(z, t0 - 1) and x(z, t0 + M), are needed for the time
+        // differences of the window's first / last frame.  Round 5: they are REQUESTED A PLANE AHEAD like everything else (Wp / Wn);
+        // until then each was a load issued where it was consumed -- two exposed memory round trips per plane step.
+        // (Ahead of the other prologue loads: the counter is in-order and the loop's first wait for Wp must not drain them.)
+        const bool w_prev = TWIN && g.ta && t0 > 0, w_next = TWIN && g.ta && t0 + M < Mg;
+        VT Wp = zero, Wn = zero;
+        if (TWIN) {
+            const T* pc = plane(zs);
+            Wp = buf_ld<T, V>(buf_rsrc<T>(pc + foff(-1), w_prev && pc != nullptr, fbytes), boff);
+            Wn = buf_ld<T, V>(buf_rsrc<T>(pc + foff(M), w_next && pc != nullptr, fbytes), boff);
+        }
         {
             const T* pp = g.za ? plane(zs - 1) : nullptr;
             const T* pc = plane(zs);
 #pragma unroll
             for (int t = 0; t < M; ++t) {
-                P[t] = load_c(pp, t);
-                C[t] = load_c(pc, t);
+                XB[t] = buf_ld<T, V>(frame(pp, t, true), boff);
+                const Rsrc rc = frame(pc, t, true);
+                XA[t] = buf_ld<T, V>(rc, boff);
                 R[t] = zero;
-                H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pc + foff(t), hoff) : zero;
-                E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu1_t<T>(pc + foff(t), eoff) : T(0);
+                H[t] = buf_ld<T, V>(rc, bhoff);
+                E[t] = buf_ld1<T>(rc, beoff);
             }
         }
-        // TWIN (M > 8: windows of 8 frames): the frames just outside the window, x(z, t0 - 1) and x(z, t0 + M), are needed for the time
-        // differences of the window's first / last frame.  Round 5: they are REQUESTED A PLANE AHEAD like everything else (Wp / Wn);
-        // until then each was a load issued where it was consumed -- two exposed memory round trips per plane step, which is what held
-        // every launch of the M = 16 Chebyshev solve at >= 1.58 ms whatever it moved (profiles/r5c_admm_config4slab_upwind_kernel_stats.csv)
-        const bool w_prev = TWIN && g.ta && t0 > 0, w_next = TWIN && g.ta && t0 + M < Mg;
-        VT Wp = zero, Wn = zero;
-        {
-            const T* pc = plane(zs);
-            if (w_prev && pc != nullptr && ok) Wp = ldu_t<T, V>(pc + foff(-1), voff);
-            if (w_next && pc != nullptr && ok) Wn = ldu_t<T, V>(pc + foff(M), voff);
-        }
-        for (int z = zs; z <= ze; ++z) {              // step ze only finishes plane ze - 1
+        NsEpiIn<T, V> ein{zero, zero, zero, zero};         // operands of the NEXT epilogue, requested a frame ahead (the first one belongs to step zs + 1, frame 0)
+        // one plane step: Cc = plane z, Pp = plane z - 1 (finished and stored here, then overwritten by plane z + 1).  FIRST: step zs, no epilogue
+        auto step = [&](auto first_tag, int z, VT (&Cc)[M], VT (&Pp)[M]) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             st_sync_plane();
             const bool in_chunk = (z < ze), next_in = (z + 1 < ze);
             const int gz = g.z0 + z;
             const T mz = (g.za && gz > 0 && gz < g.nzg) ? wz2 : T(0);
-            const T* pc = in_chunk ? plane(z) : nullptr;
             // plane requested now (consumed at step z + 1); the step behind the chunk needs the centre vectors only
             const T* pn = (next_in || (g.za && z + 1 == ze)) ? plane(z + 1) : nullptr;
             VT cold = zero;
             if (w_prev && in_chunk) cold = Wp;
 #pragma unroll
             for (int t = 0; t < M; ++t) {
-                if (TWIN && !fvalid(t)) break;
+                // A step leaves its frame loop early in the short last window of a volume whose frame count is not a multiple of 8 -- and, as
+                // far as the compiler can tell, anywhere (NV is computed from a kernel argument in every instantiation).  Deliberate: the early
+                // exits are edges into ONE block behind the step, so every register a frame loads into (plane z + 1, halo row, border element,
+                // epilogue operands) is a phi of "loaded" and "kept" there and has to be the register it was: loads IN PLACE.  Written without
+                // the exits (straight-line frames, or exits that do anything on their way) the same kernel takes 256 VGPRs + 300 - 900 B of
+                // scratch at M = 8 and runs at half the speed (tv_cheb_step 3.4 ms against 1.7 at 64x8x1024x1024).
+                // The price: s_waitcnt counts along the shortest static path from a load to its consumer, and the path "leave after frame 0"
+                // is short -- frame 0 of every step waits for (nearly) everything in flight.  Once per step, not once per frame.
+                if (t >= NV) break;
                 st_sync_frame();
                 const int tg = t0 + t;
-                const VT c = C[t], h = H[t], xm = P[t];
+                const VT c = Cc[t], h = H[t], xm = Pp[t];
                 const VT dz = ns_mul<T, V>(mz, c, xm);
                 const VT rfin = ns_sub<T, V>(R[t], dz);            // plane z-1 is complete
                 if (in_chunk) {
@@ -254,30 +306,47 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                     if (g.ta) {
                         VT tt = zero;
                         if (tg > 0) tt = tt + (c - cold);
-                        if (t + 1 < M) { if (tg + 1 < Mg) tt = tt - (C[(t + 1 < M) ? t + 1 : t] - c); }
+                        if (t + 1 < M) { if (tg + 1 < Mg) tt = tt - (Cc[(t + 1 < M) ? t + 1 : t] - c); }
                         else if (TWIN && tg + 1 < Mg) tt = tt - (Wn - c);
                         r = r + mf2 * tt;
                     }
                     R[t] = ns_add<T, V>(r, dz);
                 }
-                // ---- rotate the planes, request the next one (before the stores of this frame) ---------------------------
                 cold = c;
-                P[t] = c;
-                C[t] = load_c(pn, t);
-                H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pn + foff(t), hoff) : zero;
-                E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu1_t<T>(pn + foff(t), eoff) : T(0);
-                if (w_prev && t == 0) Wp = (pn != nullptr && next_in && ok) ? ldu_t<T, V>(pn + foff(-1), voff) : zero;       // consumed at the start of step z + 1
-                if (w_next && t == M - 1) Wn = (pn != nullptr && next_in && ok) ? ldu_t<T, V>(pn + foff(M), voff) : zero;  // ... at its end
-                // ---- epilogue of plane z-1 --------------------------------------------------------------------------------
-                if (!ok || z == zs) continue;
-                const long long fo = (long long)(z - 1) * g.s_z + foff(t);
-                VT ax;
+                // ---- epilogue of plane z-1 --------------------------------------------------------------------------------------------
+                if constexpr (!FIRST) {
+                    const long long fo = (long long)(z - 1) * g.s_z + foff(t);
+                    VT ax;
 #pragma unroll
-                for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * rfin.v[i];
-                ns_epilogue<T, V, CHEB>(a, fo, voff, xm, ax, acc0, acc1);
+                    for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * rfin.v[i];
+                    ns_epilogue<T, V, CHEB, true>(a, fo, boff, xm, ax, ein, acc0, acc1, fbytes);
+                }
+                // ---- the operands of the next epilogue: frame t + 1 of this step, or frame 0 of the next one.  FIRST in the queue: the counter is
+                // in-order and these are needed a frame from now, the plane loads below a step from now ------------------------------------
+                {
+                    const bool more = (t + 1 < M) && fvalid((t + 1 < M) ? t + 1 : t);
+                    const long long fo_n = more ? (long long)(z - 1) * g.s_z + foff(t + 1) : (long long)z * g.s_z + foff(0);
+                    if constexpr (CHEB) ns_epi_load_buf<T, V, CHEB>(a, fo_n, more ? !FIRST : (z < ze), fbytes, boff, ein);
+                }
+                // ---- plane z + 1 into the slot of plane z - 1, its halo row / border element, the seam frames ---------------------------
+                {
+                    Pp[t] = buf_ld<T, V>(frame(pn, t, true), boff);
+                    const Rsrc rn = frame(pn, t, next_in);
+                    H[t] = buf_ld<T, V>(rn, bhoff);
+                    E[t] = buf_ld1<T>(rn, beoff);
+                    if (TWIN && t == 0) Wp = buf_ld<T, V>(buf_rsrc<T>(pn + foff(-1), w_prev && pn != nullptr && next_in, fbytes), boff);     // consumed at the start of step z + 1
+                    if (TWIN && t == M - 1) Wn = buf_ld<T, V>(buf_rsrc<T>(pn + foff(M), w_next && pn != nullptr && next_in, fbytes), boff);  // ... at its end
+                }
             }
+        };
+        step(std::true_type{}, zs, XA, XB);
+        for (int z = zs + 1; z <= ze; z += 2) {              // step ze only finishes plane ze - 1
+            step(std::false_type{}, z, XB, XA);
+            if (z + 1 > ze) break;
+            step(std::false_type{}, z + 1, XA, XB);
         }
     }
+    if (a.part0 == nullptr) return;          // (Chebyshev step without dot products)
     acc0 = block_sum(acc0, sm);
     if (threadIdx.x == 0 && threadIdx.y == 0) a.part0[blockIdx.x] = acc0;
     acc1 = block_sum(acc1, sm);
@@ -310,6 +379,19 @@ template <typename T> struct E2 { T a, b; };
 template <typename T> __device__ __forceinline__ E2<T> ldu_e2(const T* ubase, unsigned voff) {
     const Vec<T, 2> v = *reinterpret_cast<const Vec<T, 2>*>(reinterpret_cast<const char*>(ubase) + voff);
     return E2<T>{v.v[0], v.v[1]};
+}
+
+template <typename T> __device__ __forceinline__ E2<T> buf_ld_e2(Rsrc r, unsigned off) {
+    if constexpr (sizeof(T) == 4) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+        // through ONE 64-bit integer: read as v.x / v.y the compiler narrows the load to its first dword (hipcc 7.2, -O3) and .b is garbage
+        const unsigned long long q = __builtin_bit_cast(unsigned long long, v);
+        return E2<T>{__builtin_bit_cast(T, (unsigned)q), __builtin_bit_cast(T, (unsigned)(q >> 32))};
+    } else {
+        const Vec<T, 2> v = buf_ld<T, 2>(r, off);
+        return E2<T>{v.v[0], v.v[1]};
+    }
 }
 
 // T: float (4 columns per 16-byte lane) or -- round 4 -- double (2 columns: the +-2 column neighbours are then whole neighbour lanes)
@@ -357,46 +439,61 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
         const unsigned hoff = want_up ? voff - 2u * row_bytes : voff + 2u * row_bytes;
         const bool want_le = (lx == 0) && ok && (col0 >= 2), want_re = (lx == 15) && ok && (col0 + V < g.nx);
         const unsigned eoff = want_le ? voff - 2u * (unsigned)sizeof(T) : voff + 16u;
-        auto fvalid = [&](int t) { return !TWIN || (t0 + t < Mg); };
+        const int NV = ((TWIN ? Mg : g.m) - t0 < M) ? (TWIN ? Mg : g.m) - t0 : M;          // frames of this window (k_normal_stream: why it is opaque)
+        auto fvalid = [&](int t) { return t < NV; };
         auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };
         auto plane = [&](int zl) { return g.za ? zplane<T>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
-        auto load_c = [&](const T* pl, int t) { return (pl != nullptr && ok && fvalid(t)) ? ldu_t<T, V>(pl + foff(t), voff) : zero; };
+        // Round 5 (late): the structure of k_normal_stream -- frame descriptors instead of branches around loads, planes loaded in place
+        // (XA / XB swap roles, two steps per loop iteration), epilogue operands and the window's seam frames requested ahead of their use.
+        const int fbytes = (int)(g.s_t * (long long)sizeof(T));
+        const unsigned boff = ok ? voff : BUF_OOB;
+        const unsigned bhoff = (want_up || want_dn) ? hoff : BUF_OOB, beoff = (want_le || want_re) ? eoff : BUF_OOB;
+        auto frame = [&](const T* pl, int t, bool valid) { return buf_rsrc<T>(pl + foff(t), pl != nullptr && valid && fvalid(t), fbytes); };
+        // the frames outside a window that its time differences reach: t0 - 2, t0 - 1 (Wp2, Wp1), t0 + M, t0 + M + 1 (Wn1, Wn2)
+        const bool w_prev = TWIN && g.ta && t0 > 0;
+        auto seam = [&](const T* pl, int t, bool valid) { return buf_rsrc<T>(pl + foff(t), pl != nullptr && valid && TWIN && g.ta && t0 + t >= 0 && t0 + t < Mg, fbytes); };
         // same delayed-store structure as k_normal_stream, on each of the two stride-2 plane lattices: step z finishes plane z-2
-        VT C[M], P[M], R[M], H[M];
+        VT XA[M], XB[M], R[M], H[M];
         E2<T> E[M];
         for (int par = 0; par < 2; ++par) {
             const int zfirst = zs + par;
             if (zfirst >= ze) break;
+            VT Wp1 = zero, Wp2 = zero, Wn1 = zero, Wn2 = zero;
             {
                 const T* pp = g.za ? plane(zfirst - 2) : nullptr;
                 const T* pc = plane(zfirst);
+                if (TWIN) {
+                    Wp2 = buf_ld<T, V>(seam(pc, -2, true), boff);
+                    Wp1 = buf_ld<T, V>(seam(pc, -1, true), boff);
+                    Wn1 = buf_ld<T, V>(seam(pc, M, true), boff);
+                    Wn2 = buf_ld<T, V>(seam(pc, M + 1, true), boff);
+                }
 #pragma unroll
                 for (int t = 0; t < M; ++t) {
-                    P[t] = load_c(pp, t);
-                    C[t] = load_c(pc, t);
+                    XB[t] = buf_ld<T, V>(frame(pp, t, true), boff);
+                    const Rsrc rc = frame(pc, t, true);
+                    XA[t] = buf_ld<T, V>(rc, boff);
                     R[t] = zero;
-                    H[t] = (pc != nullptr && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pc + foff(t), hoff) : zero;
-                    E[t] = (pc != nullptr && (want_le || want_re) && fvalid(t)) ? ldu_e2<T>(pc + foff(t), eoff) : E2<T>{T(0), T(0)};
+                    H[t] = buf_ld<T, V>(rc, bhoff);
+                    E[t] = buf_ld_e2<T>(rc, beoff);
                 }
             }
-            for (int z = zfirst; z < ze + 2; z += 2) {          // the step behind the chunk only finishes the lattice's last plane
+            NsEpiIn<T, V> ein{zero, zero, zero, zero};
+            auto step = [&](auto first_tag, int z, VT (&Cc)[M], VT (&Pp)[M]) __attribute__((always_inline)) {
+                constexpr bool FIRST = decltype(first_tag)::value;
                 st_sync_plane();
                 const bool in_chunk = (z < ze), next_in = (z + 2 < ze);
                 const int gz = g.z0 + z;
                 const T mz = (g.za && gz >= 2 && gz < g.nzg) ? wz2 : T(0);
-                const T* pc = in_chunk ? plane(z) : nullptr;
                 const T* pn = (next_in || (g.za && in_chunk)) ? plane(z + 2) : nullptr;
                 VT cold1 = zero, cold2 = zero;         // x(z, t-1), x(z, t-2)
-                if (TWIN && g.ta && ok && in_chunk) {
-                    if (t0 >= 1) cold1 = ldu_t<T, V>(pc + foff(-1), voff);
-                    if (t0 >= 2) cold2 = ldu_t<T, V>(pc + foff(-2), voff);
-                }
+                if (w_prev && in_chunk) { cold1 = Wp1; cold2 = Wp2; }
 #pragma unroll
                 for (int t = 0; t < M; ++t) {
-                    if (TWIN && !fvalid(t)) break;
+                    if (t >= NV) break;                 // (k_normal_stream: what the early exit is for)
                     st_sync_frame();
                     const int tg = t0 + t;
-                    const VT c = C[t], h = H[t], xm = P[t];
+                    const VT c = Cc[t], h = H[t], xm = Pp[t];
                     const VT dz = ns_mul<T, V>(mz, c, xm);
                     const VT rfin = ns_sub<T, V>(R[t], dz);
                     if (in_chunk) {
@@ -421,8 +518,8 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                             VT tt = zero;
                             if (tg >= 2) tt = tt + (c - cold2);
                             if (tg + 2 < Mg) {
-                                if (t + 2 < M) tt = tt - (C[(t + 2 < M) ? t + 2 : t] - c);
-                                else if (TWIN) tt = tt - ((ok ? ldu_t<T, V>(pc + foff(t + 2), voff) : zero) - c);
+                                if (t + 2 < M) tt = tt - (Cc[(t + 2 < M) ? t + 2 : t] - c);
+                                else if (TWIN) tt = tt - (((t + 2 == M) ? Wn1 : Wn2) - c);
                             }
                             r = r + mf2 * tt;
                         }
@@ -430,20 +527,44 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                     }
                     cold2 = cold1;
                     cold1 = c;
-                    P[t] = c;
-                    C[t] = load_c(pn, t);
-                    H[t] = (pn != nullptr && next_in && (want_up || want_dn) && fvalid(t)) ? ldu_t<T, V>(pn + foff(t), hoff) : zero;
-                    E[t] = (pn != nullptr && next_in && (want_le || want_re) && fvalid(t)) ? ldu_e2<T>(pn + foff(t), eoff) : E2<T>{T(0), T(0)};
-                    if (!ok || z == zfirst) continue;
-                    const long long fo = (long long)(z - 2) * g.s_z + foff(t);
-                    VT ax;
+                    // ---- epilogue of plane z-2 ----------------------------------------------------------------------------------------
+                    if constexpr (!FIRST) {
+                        const long long fo = (long long)(z - 2) * g.s_z + foff(t);
+                        VT ax;
 #pragma unroll
-                    for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * (T(0.25) * rfin.v[i]);
-                    ns_epilogue<T, V, CHEB>(a, fo, voff, xm, ax, acc0, acc1);
+                        for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * (T(0.25) * rfin.v[i]);
+                        ns_epilogue<T, V, CHEB, true>(a, fo, boff, xm, ax, ein, acc0, acc1, fbytes);
+                    }
+                    // ---- operands of the next epilogue (frame t + 1 of this step or frame 0 of the lattice's next step), then plane z + 2 into
+                    // the slot of plane z - 2 with its halo rows / border elements and the seam frames ---------------------------------------
+                    {
+                        const bool more = (t + 1 < M) && fvalid((t + 1 < M) ? t + 1 : t);
+                        const long long fo_n = more ? (long long)(z - 2) * g.s_z + foff(t + 1) : (long long)z * g.s_z + foff(0);
+                        if constexpr (CHEB) ns_epi_load_buf<T, V, CHEB>(a, fo_n, more ? !FIRST : (z < ze), fbytes, boff, ein);
+                    }
+                    {
+                        Pp[t] = buf_ld<T, V>(frame(pn, t, true), boff);
+                        const Rsrc rn = frame(pn, t, next_in);
+                        H[t] = buf_ld<T, V>(rn, bhoff);
+                        E[t] = buf_ld_e2<T>(rn, beoff);
+                        if (TWIN && t == 0) {
+                            Wp2 = buf_ld<T, V>(seam(pn, -2, next_in), boff);
+                            Wp1 = buf_ld<T, V>(seam(pn, -1, next_in), boff);
+                        }
+                        if (TWIN && t == M - 2) Wn1 = buf_ld<T, V>(seam(pn, M, next_in), boff);
+                        if (TWIN && t == M - 1) Wn2 = buf_ld<T, V>(seam(pn, M + 1, next_in), boff);
+                    }
                 }
+            };
+            step(std::true_type{}, zfirst, XA, XB);
+            for (int z = zfirst + 2; z < ze + 2; z += 4) {          // the step behind the chunk only finishes the lattice's last plane
+                step(std::false_type{}, z, XB, XA);
+                if (z + 2 >= ze + 2) break;
+                step(std::false_type{}, z + 2, XA, XB);
             }
         }
     }
+    if (a.part0 == nullptr) return;          // (Chebyshev step without dot products)
     acc0 = block_sum(acc0, sm);
     if (threadIdx.x == 0 && threadIdx.y == 0) a.part0[blockIdx.x] = acc0;
     acc1 = block_sum(acc1, sm);

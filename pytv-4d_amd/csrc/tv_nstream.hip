@@ -14,7 +14,7 @@ bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
     if (!vec || d.nx < 64 || d.wv != nullptr) return false;
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return false;   // two-point axes: forward stencil
     const long long eb = (g->dtype == TV_F32) ? 4 : 8;
-    if (d.s_t * eb > (1ll << 32)) return false;      // 32-bit per-lane byte offsets inside a frame
+    if (d.s_t * eb >= (1ll << 31)) return false;     // frame descriptors: num_records and the out-of-range offset (tv_fused.h, BUF_OOB)
     if (env_int("TV_NO_MARCH", 0) || env_int("TV_NO_MARCH_NORMAL", 0)) return false;
     // small planes: the z / t neighbours of the one-site kernel stay in L2 (same threshold as the other streaming kernels)
     return (long long)d.s_z * eb >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;
@@ -24,16 +24,24 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
              double rho, hipStream_t st, long long* nblocks, double* part0, double* part1, const NCheb* cheb) {
     const int V = (g->dtype == TV_F32) ? 4 : 2;
     const long long tx = ((d.nx + V - 1) / V + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
-    int zc = env_int("TV_ZCHUNK", 0);
+    const long long nwin = (d.m > NS_TWN) ? (d.m + NS_TWN - 1) / NS_TWN : 1;
+    int zc = env_int("TV_NS_ZCHUNK", 0);          // (this kernel family alone; TV_ZCHUNK: every z-chunked kernel)
+    if (zc <= 0) zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
-        const long long want = (4096 + tx * ty - 1) / (tx * ty);
+        // >= ~2048 blocks (4 rounds of 256 CUs x 2), counting the time windows.  A chunk reads two planes it does not write and starts with
+        // a prologue nothing overlaps: on the configs[4] slab (nz = 32, two windows) the Chebyshev solve takes 6.54 / 6.15 / 5.93 ms in
+        // chunks of 8 / 16 / 32 planes (profiles/r5d_nstream_zchunk.txt); until round 5 the rule asked for 4096 blocks without counting
+        // the windows and chose 8.
+        // The central kernel (two plane lattices per chunk) on ONE window is the exception: 64x8x1024x1024 takes 1.68 ms per Chebyshev
+        // step in chunks of 16 and 1.92 in chunks of 32 (profiles/r5d_zchunk_sensitivity.txt) -- it keeps the 4096.
+        const long long target = (g->scheme == TV_CENTRAL && nwin == 1) ? 4096 : 2048;
+        const long long want = (target + tx * ty * nwin - 1) / (tx * ty * nwin);
         zc = (int)(d.nz / (want > 0 ? want : 1));
         if (zc > 32) zc = 32;
         if (zc < 8) zc = 8;
     }
     if (zc > d.nz) zc = d.nz;
     const long long nch = (d.nz + zc - 1) / zc;
-    const long long nwin = (d.m > NS_TWN) ? (d.m + NS_TWN - 1) / NS_TWN : 1;
     const long long nb = tx * ty * nch * nwin, per_xcd = (nb + 7) / 8;
     const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, ST_NWX * ST_NWY, 1);
     *nblocks = 8 * per_xcd;
@@ -49,8 +57,8 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
     do {                                                                                                               \
         if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL)                                                             \
             hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, double>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
-        else if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
         else if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, float>), grid, block, 0, st, d, w, a, zc, (int)nch); \
+        else if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
         else hipLaunchKernelGGL((k_normal_stream<MM, TW, float, CH>), grid, block, 0, st, d, w, a, zc, (int)nch);       \
     } while (0)
     // the Chebyshev epilogue is its own instantiation (tv_nstream.h, ns_epilogue)

@@ -88,7 +88,7 @@ __device__ __forceinline__ double rsq_fast(double v) {
 // matters beyond the instruction count: gfx950 has one in-order vmcnt for loads and stores, and with control flow around
 // memory operations the compiler can only wait with vmcnt(0), i.e. for every outstanding store and look-ahead load, once
 // per frame (the first version of this kernel did: 53 % of its wave cycles waiting).  Straight-line code gets counted waits.
-using Rsrc = __amdgpu_buffer_rsrc_t;
+// (Rsrc: tv_fused.h)
 constexpr unsigned SG2_OOB = 0x80000000u;         // beyond any frame (frames are < 2^31 bytes: sg2_supported)
 typedef int sg2_v2i __attribute__((ext_vector_type(2)));
 template <typename T> __device__ __forceinline__ Rsrc sg2_rsrc(const T* base, bool valid, int nbytes) {

@@ -1410,20 +1410,24 @@ class ADMM(_SlabProblem):
         g = self.geom(a, b)
         sl = lambda t_: _nv.ptr(t_[a:b]) if t_ is not None else None      # noqa: E731
         _nv.check(self.lib.tv_cheb_step(g.ref, _nv.ptr(v[a:b]), _nv.ptr(hp), _nv.ptr(hn), self.rho, _nv.ptr(self.r[a:b]), sl(y), yscale,
-                                        sl(add), sl(ref), alpha, beta, _nv.ptr(out[a:b]), dots.data_ptr(), _nv.ptr(self.ws), self.stream))
+                                        sl(add), sl(ref), alpha, beta, _nv.ptr(out[a:b]), dots.data_ptr() if dots is not None else None,
+                                        _nv.ptr(self.ws), self.stream))
 
     def _cheb_step(self, v, y, yscale, add, ref, out, alpha, beta, dots):
         """out = [add +] v + alpha (r - A v) + beta (v - y) on the slab (y None: y = yscale r); the two-plane halo exchange of v hides
-        behind the interior planes exactly as in _normal; dots <- [|r - A v|^2, |out - ref|^2 or |v|^2] summed over the launches."""
+        behind the interior planes exactly as in _normal; dots (or None: not wanted) <- [|r - A v|^2, |out - ref|^2 or |v|^2] summed over the
+        launches."""
         nz = self.slab.nz
         args = (y, yscale, add, ref, out, alpha, beta)
         if self.sh and nz >= 5:
             h = self.plan.exchange_image2(v, self.h2_prev, self.h2_next)
-            self._cheb_range(v, *args, 2, nz - 2, v[0:2], v[nz - 2:nz], self.dots3[0])
+            d3 = self.dots3 if dots is not None else (None, None, None)
+            self._cheb_range(v, *args, 2, nz - 2, v[0:2], v[nz - 2:nz], d3[0])
             self.slab.wait(h)
-            self._cheb_range(v, *args, 0, 2, self.h2_prev, v[2:4], self.dots3[1])
-            self._cheb_range(v, *args, nz - 2, nz, v[nz - 4:nz - 2], self.h2_next, self.dots3[2])
-            torch.sum(self.dots3, dim=0, out=dots)
+            self._cheb_range(v, *args, 0, 2, self.h2_prev, v[2:4], d3[1])
+            self._cheb_range(v, *args, nz - 2, nz, v[nz - 4:nz - 2], self.h2_next, d3[2])
+            if dots is not None:
+                torch.sum(self.dots3, dim=0, out=dots)
         else:
             hp, hn = self._halo2(v)
             self._cheb_range(v, *args, 0, nz, hp, hn, dots)
@@ -1447,12 +1451,14 @@ class ADMM(_SlabProblem):
             ap = al1 * a0
             bp = a0 + al1 + be1 * a0 - 1.0 - ap
             fin = (K == 2)
-            self._cheb_step(self.r, None, 0.0, self.x if fin else None, ref if fin else None, bufs[0], ap, bp, self.dots)
+            # the dot products of a step (|r - A e_k|^2, |out - x0|^2) are asked for where they are used: by the last step, for the fidelity
+            want = lambda fin_: self.dots if (fin_ and ref is not None) else None      # noqa: E731
+            self._cheb_step(self.r, None, 0.0, self.x if fin else None, ref if fin else None, bufs[0], ap, bp, want(fin))
             for k in range(2, K):         # e_k lives in bufs[(k - 2) % 3]
                 fin = (k + 1 == K)
                 alpha, beta = coef[k]
                 self._cheb_step(bufs[(k - 2) % 3], bufs[(k - 3) % 3] if k >= 3 else None, a0 if k == 2 else 0.0,
-                                self.x if fin else None, ref if fin else None, bufs[(k - 1) % 3], alpha, beta, self.dots)
+                                self.x if fin else None, ref if fin else None, bufs[(k - 1) % 3], alpha, beta, want(fin))
             if fid_slot is not None:
                 fid_slot.copy_(self.dots[1:2])
             last = (K - 2) % 3

@@ -179,6 +179,15 @@ def test_cheb_step_matches_numpy(nvlib, scheme, shape):
             s_ = sc.cpu().numpy()
             np.testing.assert_allclose(s_[0], np.sum(res * res), rtol=tol * 100)
             np.testing.assert_allclose(s_[1], np.sum((want - ref) ** 2) if use_ref else np.sum(x64 * x64), rtol=tol * 100)
+            # dots = NULL (round 5): the same output bit for bit, no dot products (refused together with ref, which exists for one of them)
+            od2 = torch.full_like(xd, float("nan"))
+            rc = lib.tv_cheb_step(g.ref, nv.ptr(xd), None, None, rho, nv.ptr(bd), nv.ptr(yd) if use_y else None, yscale,
+                                  nv.ptr(addd) if use_add else None, nv.ptr(refd) if use_ref else None, alpha, beta, nv.ptr(od2), None, nv.ptr(ws), st)
+            if use_ref:
+                assert rc != 0 and b"ref" in lib.tv_last_error()
+            else:
+                nv.check(rc)
+                assert torch.equal(od2, od)
         # x may be b itself (the fused first two steps of the solver)
         od = torch.empty_like(xd)
         nv.check(lib.tv_cheb_step(g.ref, nv.ptr(bd), None, None, rho, nv.ptr(bd), None, 0.0, None, None, alpha, beta, nv.ptr(od),
