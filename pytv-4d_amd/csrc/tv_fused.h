@@ -238,23 +238,26 @@ typedef int buf_v4i __attribute__((ext_vector_type(4)));
 template <typename T> __device__ __forceinline__ Rsrc buf_rsrc(const T* base, bool valid, int nbytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, valid ? nbytes : 0, 0x00020000);
 }
-template <typename T, int V, int AUX = 0> __device__ __forceinline__ Vec<T, V> buf_ld(Rsrc r, unsigned off) {
+// soff: a wave-uniform byte offset added to the descriptor's base (the frame inside a plane: one descriptor per plane and stream instead of one
+// per frame -- fewer scalar instructions and live SGPRs).  The descriptors that take it span the whole plane, so a lane is in range
+// whether or not the hardware counts soff in its range check.
+template <typename T, int V, int AUX = 0> __device__ __forceinline__ Vec<T, V> buf_ld(Rsrc r, unsigned off, int soff = 0) {
     static_assert(sizeof(Vec<T, V>) == 16, "16-byte lanes");
-    const buf_v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX);
+    const buf_v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, soff, AUX);
     return __builtin_bit_cast(Vec<T, V>, v);
 }
-template <typename T, int AUX = 0> __device__ __forceinline__ T buf_ld1(Rsrc r, unsigned off) {
+template <typename T, int AUX = 0> __device__ __forceinline__ T buf_ld1(Rsrc r, unsigned off, int soff = 0) {
     if constexpr (sizeof(T) == 4) {
-        return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, AUX));
+        return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, soff, AUX));
     } else {
         typedef int v2i __attribute__((ext_vector_type(2)));
-        const v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, AUX);
+        const v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, soff, AUX);
         return __builtin_bit_cast(T, v);
     }
 }
-template <typename T, int V, int AUX = 0> __device__ __forceinline__ void buf_st(Rsrc r, unsigned off, const Vec<T, V>& v) {
+template <typename T, int V, int AUX = 0> __device__ __forceinline__ void buf_st(Rsrc r, unsigned off, const Vec<T, V>& v, int soff = 0) {
     static_assert(sizeof(Vec<T, V>) == 16, "16-byte lanes");
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_v4i, v), r, (int)off, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(buf_v4i, v), r, (int)off, soff, AUX);
 }
 constexpr int BUF_NT = 2;                        // aux bit 1 = nt on gfx950 (what __builtin_nontemporal_load / _store emit)
 

@@ -64,39 +64,43 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> NLDU(const T* 
 // every frame ended in s_waitcnt vmcnt(0): a full memory round trip per frame with nothing else to do, which also drained the plane-ahead
 // requests of the stencil -- the kernel ran at the latency of memory, not its bandwidth (Chebyshev step 0.54 of peak at 8 waves per CU).
 template <typename T, int V> struct NsEpiIn { Vec<T, V> b, y, add, ref; };
-// k_normal_stream (radius-1 schemes): every stream through a frame descriptor (tv_fused.h, "raw buffer access") -- absent streams and
-// absent frames have num_records = 0, so the four loads are unconditional and the frame loop is straight-line code
+// Every stream goes through ONE descriptor per plane (tv_fused.h, "raw buffer access": base = frame 0 of the plane, num_records = the plane's
+// bytes, 0 for an absent stream or plane) + the frame's byte offset as the instruction's scalar offset (`soff`): the four loads are
+// unconditional, the frame loop is straight-line code, and a frame costs no descriptor arithmetic.
+// po: element offset of the plane, valid: the plane's epilogue will run
 template <typename T, int V, bool CHEB>
-__device__ __forceinline__ void ns_epi_load_buf(const NormalArgsT<T>& a, long long fo, bool valid, int fbytes, unsigned boff, NsEpiIn<T, V>& in) {
+__device__ __forceinline__ void ns_epi_load_buf(const NormalArgsT<T>& a, long long po, bool valid, int pbytes, unsigned boff, int soff, NsEpiIn<T, V>& in) {
     constexpr int NT = TV_NSTREAM_NT ? BUF_NT : 0;
     if constexpr (CHEB) {
         // b == x (the first step of a Chebyshev solve: e_2 from r alone, x = b = r): the value is in registers already -- one stream less
-        in.b = buf_ld<T, V, NT>(buf_rsrc<T>(a.b + fo, valid && a.b != a.x, fbytes), boff);
-        in.y = buf_ld<T, V, NT>(buf_rsrc<T>(a.y + fo, valid && a.y != nullptr, fbytes), boff);
-        in.add = buf_ld<T, V, NT>(buf_rsrc<T>(a.add + fo, valid && a.add != nullptr, fbytes), boff);
-        in.ref = buf_ld<T, V, NT>(buf_rsrc<T>(a.ref + fo, valid && a.ref != nullptr, fbytes), boff);
+        in.b = buf_ld<T, V, NT>(buf_rsrc<T>(a.b + po, valid && a.b != a.x, pbytes), boff, soff);
+        in.y = buf_ld<T, V, NT>(buf_rsrc<T>(a.y + po, valid && a.y != nullptr, pbytes), boff, soff);
+        in.add = buf_ld<T, V, NT>(buf_rsrc<T>(a.add + po, valid && a.add != nullptr, pbytes), boff, soff);
+        in.ref = buf_ld<T, V, NT>(buf_rsrc<T>(a.ref + po, valid && a.ref != nullptr, pbytes), boff, soff);
     }
     // (the CG forms load b where they use it, inside the branch that tells them apart: tv_normal_op without b has no operand at all, and a
-    // load from an absent stream still takes its slot in the queue -- measured: + 10 % on the 2-word operator)
+    // load from an absent stream still takes its slot in the queue)
 }
-// BUF: the stores go through descriptors too (fbytes, boff), lanes outside the frame drop theirs
+// BUF: the stores go through descriptors too (plane offset po, plane bytes, frame offset soff; voff = the lane's offset or BUF_OOB: lanes
+// outside the frame drop their store); otherwise fo = po + the frame's element offset and plain global accesses
 template <typename T, int V, bool CHEB, bool BUF = false>
 __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long fo, unsigned voff, const Vec<T, V>& xm, const Vec<T, V>& ax,
-                                            const NsEpiIn<T, V>& in, double& acc0, double& acc1, int fbytes = 0) {
+                                            const NsEpiIn<T, V>& in, double& acc0, double& acc1, int pbytes = 0, int soff = 0) {
     constexpr int NT = TV_NSTREAM_NT ? BUF_NT : 0;
     Vec<T, V> o;
     if constexpr (CHEB) {
         const Vec<T, V> bv = (a.b == a.x) ? xm : in.b;
-        const Vec<T, V> yv = (a.y != nullptr) ? in.y : a.yscale * bv;          // no y: y = yscale * b (0 after e_0 = 0)
-        const Vec<T, V> av = (a.add != nullptr) ? in.add : vsplat<T, V>(T(0));
-        const Vec<T, V> rv = (a.ref != nullptr) ? in.ref : xm;
+        // no y: y = yscale * b (0 after e_0 = 0).  An absent stream reads as 0 and yscale is 0 next to a real y (tv_cheb_step checks), so one
+        // fma covers both cases without a select; `add` likewise needs none
         Vec<T, V> res;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
+            const T yv = in.y.v[i] + a.yscale * bv.v[i];
             res.v[i] = bv.v[i] - ax.v[i];
-            o.v[i] = av.v[i] + ((xm.v[i] + a.alpha * res.v[i]) + a.beta * (xm.v[i] - yv.v[i]));
+            o.v[i] = in.add.v[i] + ((xm.v[i] + a.alpha * res.v[i]) + a.beta * (xm.v[i] - yv));
         }
         if (a.part0 != nullptr) {          // the dot products on request only (tv_cheb_step, dots == NULL: ~ 10 % of the frame's instructions)
+            const Vec<T, V> rv = (a.ref != nullptr) ? in.ref : xm;
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 acc0 += (double)res.v[i] * (double)res.v[i];
@@ -113,7 +117,7 @@ __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long f
         }
     } else {
         Vec<T, V> bv;
-        if constexpr (BUF) bv = buf_ld<T, V, NT>(buf_rsrc<T>(a.b + fo, true, fbytes), voff);
+        if constexpr (BUF) bv = buf_ld<T, V, NT>(buf_rsrc<T>(a.b + fo, true, pbytes), voff, soff);
         else bv = NLDU<T, V>(a.b + fo, voff);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
@@ -122,14 +126,17 @@ __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long f
             acc1 += (double)xm.v[i] * (double)xm.v[i];
         }
         if (a.out2 != nullptr) {
-            if constexpr (BUF) buf_st<T, V, NT>(buf_rsrc<T>(a.out2 + fo, true, fbytes), voff, o);
+            if constexpr (BUF) buf_st<T, V, NT>(buf_rsrc<T>(a.out2 + fo, true, pbytes), voff, o, soff);
             else NSTU<T, V>(a.out2 + fo, voff, o);
         }
     }
-    if constexpr (BUF) buf_st<T, V, NT>(buf_rsrc<T>(a.out + fo, true, fbytes), voff, o);
+    if constexpr (BUF) buf_st<T, V, NT>(buf_rsrc<T>(a.out + fo, true, pbytes), voff, o, soff);
     else NSTU<T, V>(a.out + fo, voff, o);
 }
 
+#ifndef TV_NS_EXIT_FROM
+#define TV_NS_EXIT_FROM(M) ((M) / 2)
+#endif
 constexpr int NS_TWN = TV_TWN;
 
 // The shared z term is added to one plane at one step and subtracted from its neighbour at the next, possibly by a different
@@ -163,8 +170,10 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> ns_sub(const V
     return r;
 }
 
-template <int M, bool TWIN, typename T = float, bool CHEB = false>
+// RAGGED (windows only): the frame count of the volume is not a multiple of 8, the last window is short (see the frame loop)
+template <int M, bool TWIN, typename T = float, bool CHEB = false, bool RAGGED = false>
 __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3)) void k_normal_stream(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
+    static_assert(TWIN || !RAGGED, "only windows can be ragged");
     constexpr int V = 16 / (int)sizeof(T);          // columns per 16-byte lane: 4 floats / 2 doubles (round 3)
     using VT = Vec<T, V>;
     __shared__ double sm[16];
@@ -225,12 +234,13 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
         VT XA[M], XB[M], R[M], H[M];
         T E[M];
         auto plane = [&](int zl) { return g.za ? zplane<T>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
-        // every access: frame descriptor + per-lane offset (tv_fused.h, "raw buffer access"); lanes / frames / planes that do not take part
-        // are out of range for the hardware, not branched around
-        const int fbytes = (int)(g.s_t * (long long)sizeof(T));
+        // every access: plane descriptor + the frame's scalar offset + per-lane offset (tv_fused.h, "raw buffer access"); lanes / planes that do
+        // not take part are out of range for the hardware, not branched around (frames t >= NV are never reached)
+        const int fbytes = (int)(g.s_t * (long long)sizeof(T)), pbytes = (int)(g.s_z * (long long)sizeof(T));
         const unsigned boff = ok ? voff : BUF_OOB;
         const unsigned bhoff = (want_up || want_dn) ? hoff : BUF_OOB, beoff = (want_le || want_re) ? eoff : BUF_OOB;
-        auto frame = [&](const T* pl, int t, bool valid) { return buf_rsrc<T>(pl + foff(t), pl != nullptr && valid && fvalid(t), fbytes); };
+        auto pdesc = [&](const T* pl, bool valid) { return buf_rsrc<T>(pl, pl != nullptr && valid, pbytes); };
+        auto soff = [&](int t) { return (t0 + t) * fbytes; };
         // TWIN (M > 8: windows of 8 frames): the frames just outside the window, x(z, t0 - 1) and x(z, t0 + M), are needed for the time
         // differences of the window's first / last frame.  Round 5: they are REQUESTED A PLANE AHEAD like everything else (Wp / Wn);
         // until then each was a load issued where it was consumed -- two exposed memory round trips per plane step.
@@ -239,20 +249,21 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
         VT Wp = zero, Wn = zero;
         if (TWIN) {
             const T* pc = plane(zs);
-            Wp = buf_ld<T, V>(buf_rsrc<T>(pc + foff(-1), w_prev && pc != nullptr, fbytes), boff);
-            Wn = buf_ld<T, V>(buf_rsrc<T>(pc + foff(M), w_next && pc != nullptr, fbytes), boff);
+            Wp = buf_ld<T, V>(pdesc(pc, w_prev), boff, soff(-1));
+            Wn = buf_ld<T, V>(pdesc(pc, w_next), boff, soff(M));
         }
         {
             const T* pp = g.za ? plane(zs - 1) : nullptr;
             const T* pc = plane(zs);
+            const Rsrc rp = pdesc(pp, true), rc = pdesc(pc, true);
 #pragma unroll
             for (int t = 0; t < M; ++t) {
-                XB[t] = buf_ld<T, V>(frame(pp, t, true), boff);
-                const Rsrc rc = frame(pc, t, true);
-                XA[t] = buf_ld<T, V>(rc, boff);
+                const bool fv = fvalid(t);          // (the prologue is not part of the frame loop: frames beyond the window load nothing)
+                XB[t] = buf_ld<T, V>(rp, fv ? boff : BUF_OOB, soff(t));
+                XA[t] = buf_ld<T, V>(rc, fv ? boff : BUF_OOB, soff(t));
                 R[t] = zero;
-                H[t] = buf_ld<T, V>(rc, bhoff);
-                E[t] = buf_ld1<T>(rc, beoff);
+                H[t] = buf_ld<T, V>(rc, fv ? bhoff : BUF_OOB, soff(t));
+                E[t] = buf_ld1<T>(rc, fv ? beoff : BUF_OOB, soff(t));
             }
         }
         NsEpiIn<T, V> ein{zero, zero, zero, zero};         // operands of the NEXT epilogue, requested a frame ahead (the first one belongs to step zs + 1, frame 0)
@@ -265,6 +276,8 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
             const T mz = (g.za && gz > 0 && gz < g.nzg) ? wz2 : T(0);
             // plane requested now (consumed at step z + 1); the step behind the chunk needs the centre vectors only
             const T* pn = (next_in || (g.za && z + 1 == ze)) ? plane(z + 1) : nullptr;
+            // descriptors of plane z + 1: the centre vectors, and (the plane belongs to the chunk) its halo rows / border elements / seam frames
+            const Rsrc rn_c = pdesc(pn, true), rn_h = pdesc(pn, next_in), rn_wp = pdesc(pn, next_in && w_prev), rn_wn = pdesc(pn, next_in && w_next);
             VT cold = zero;
             if (w_prev && in_chunk) cold = Wp;
 #pragma unroll
@@ -276,8 +289,11 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                 // the exits (straight-line frames, or exits that do anything on their way) the same kernel takes 256 VGPRs + 300 - 900 B of
                 // scratch at M = 8 and runs at half the speed (tv_cheb_step 3.4 ms against 1.7 at 64x8x1024x1024).
                 // The price: s_waitcnt counts along the shortest static path from a load to its consumer, and the path "leave after frame 0"
-                // is short -- frame 0 of every step waits for (nearly) everything in flight.  Once per step, not once per frame.
-                if (t >= NV) break;
+                // is short -- with an exit in front of every frame, frame 0 of every step waits for (nearly) everything in flight.  So the exits
+                // start at frame M / 2 (frames 0 .. M/2 - 1 are straight-line; still no spills), where the shortest path is half a step long:
+                // one drain per TWO steps is left (the loop header's), from one per step.  A volume whose last window may be shorter than
+                // that is the RAGGED instantiation: exits from frame 1 on.
+                if (t >= (RAGGED ? 1 : TV_NS_EXIT_FROM(M)) && t >= NV) break;
                 st_sync_frame();
                 const int tg = t0 + t;
                 const VT c = Cc[t], h = H[t], xm = Pp[t];
@@ -315,27 +331,26 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                 cold = c;
                 // ---- epilogue of plane z-1 --------------------------------------------------------------------------------------------
                 if constexpr (!FIRST) {
-                    const long long fo = (long long)(z - 1) * g.s_z + foff(t);
                     VT ax;
 #pragma unroll
                     for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * rfin.v[i];
-                    ns_epilogue<T, V, CHEB, true>(a, fo, boff, xm, ax, ein, acc0, acc1, fbytes);
+                    ns_epilogue<T, V, CHEB, true>(a, (long long)(z - 1) * g.s_z, boff, xm, ax, ein, acc0, acc1, pbytes, soff(t));
                 }
                 // ---- the operands of the next epilogue: frame t + 1 of this step, or frame 0 of the next one.  FIRST in the queue: the counter is
                 // in-order and these are needed a frame from now, the plane loads below a step from now ------------------------------------
                 {
                     const bool more = (t + 1 < M) && fvalid((t + 1 < M) ? t + 1 : t);
-                    const long long fo_n = more ? (long long)(z - 1) * g.s_z + foff(t + 1) : (long long)z * g.s_z + foff(0);
-                    if constexpr (CHEB) ns_epi_load_buf<T, V, CHEB>(a, fo_n, more ? !FIRST : (z < ze), fbytes, boff, ein);
+                    if constexpr (CHEB)
+                        ns_epi_load_buf<T, V, CHEB>(a, (long long)(more ? z - 1 : z) * g.s_z, more ? !FIRST : (z < ze), pbytes, boff,
+                                                    __builtin_amdgcn_readfirstlane(soff(more ? t + 1 : 0)), ein);      // (uniform; said so, or the compiler loops over its values)
                 }
                 // ---- plane z + 1 into the slot of plane z - 1, its halo row / border element, the seam frames ---------------------------
                 {
-                    Pp[t] = buf_ld<T, V>(frame(pn, t, true), boff);
-                    const Rsrc rn = frame(pn, t, next_in);
-                    H[t] = buf_ld<T, V>(rn, bhoff);
-                    E[t] = buf_ld1<T>(rn, beoff);
-                    if (TWIN && t == 0) Wp = buf_ld<T, V>(buf_rsrc<T>(pn + foff(-1), w_prev && pn != nullptr && next_in, fbytes), boff);     // consumed at the start of step z + 1
-                    if (TWIN && t == M - 1) Wn = buf_ld<T, V>(buf_rsrc<T>(pn + foff(M), w_next && pn != nullptr && next_in, fbytes), boff);  // ... at its end
+                    Pp[t] = buf_ld<T, V>(rn_c, boff, soff(t));
+                    H[t] = buf_ld<T, V>(rn_h, bhoff, soff(t));
+                    E[t] = buf_ld1<T>(rn_h, beoff, soff(t));
+                    if (TWIN && t == 0) Wp = buf_ld<T, V>(rn_wp, boff, soff(-1));          // consumed at the start of step z + 1
+                    if (TWIN && t == M - 1) Wn = buf_ld<T, V>(rn_wn, boff, soff(M));       // ... at its end
                 }
             }
         };
@@ -443,8 +458,10 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
         auto fvalid = [&](int t) { return t < NV; };
         auto foff = [&](int t) { return (long long)(t0 + t) * g.s_t; };
         auto plane = [&](int zl) { return g.za ? zplane<T>(g, a.x, a.xp, a.xn, 2, zl) : ((zl >= 0 && zl < g.nz) ? a.x + (long long)zl * g.s_z : nullptr); };
-        // Round 5 (late): the structure of k_normal_stream -- frame descriptors instead of branches around loads, planes loaded in place
-        // (XA / XB swap roles, two steps per loop iteration), epilogue operands and the window's seam frames requested ahead of their use.
+        // Round 5 (late): the structure of k_normal_stream -- descriptors instead of branches around loads, planes loaded in place (XA / XB
+        // swap roles, two steps per loop iteration), epilogue operands and the window's seam frames requested ahead of their use.  One
+        // descriptor per FRAME here: with k_normal_stream's per-plane descriptors + scalar frame offsets the M = 8 instantiations of this
+        // kernel need 256 VGPRs and 28 - 72 B of scratch (they hold four more seam frames and two-element border loads).
         const int fbytes = (int)(g.s_t * (long long)sizeof(T));
         const unsigned boff = ok ? voff : BUF_OOB;
         const unsigned bhoff = (want_up || want_dn) ? hoff : BUF_OOB, beoff = (want_le || want_re) ? eoff : BUF_OOB;
@@ -533,14 +550,14 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                         VT ax;
 #pragma unroll
                         for (int i = 0; i < V; ++i) ax.v[i] = xm.v[i] + a.rho * (T(0.25) * rfin.v[i]);
-                        ns_epilogue<T, V, CHEB, true>(a, fo, boff, xm, ax, ein, acc0, acc1, fbytes);
+                        ns_epilogue<T, V, CHEB, true>(a, fo, boff, xm, ax, ein, acc0, acc1, fbytes, 0);          // (per-frame descriptors here: this kernel has no SGPRs to spare, see below)
                     }
                     // ---- operands of the next epilogue (frame t + 1 of this step or frame 0 of the lattice's next step), then plane z + 2 into
                     // the slot of plane z - 2 with its halo rows / border elements and the seam frames ---------------------------------------
                     {
                         const bool more = (t + 1 < M) && fvalid((t + 1 < M) ? t + 1 : t);
                         const long long fo_n = more ? (long long)(z - 2) * g.s_z + foff(t + 1) : (long long)z * g.s_z + foff(0);
-                        if constexpr (CHEB) ns_epi_load_buf<T, V, CHEB>(a, fo_n, more ? !FIRST : (z < ze), fbytes, boff, ein);
+                        if constexpr (CHEB) if constexpr (CHEB) ns_epi_load_buf<T, V, CHEB>(a, fo_n, more ? !FIRST : (z < ze), fbytes, boff, 0, ein);
                     }
                     {
                         Pp[t] = buf_ld<T, V>(frame(pn, t, true), boff);

@@ -14,7 +14,7 @@ bool N_stream_ok(const tv_geom* g, const DG& d, bool vec) {
     if (!vec || d.nx < 64 || d.wv != nullptr) return false;
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return false;   // two-point axes: forward stencil
     const long long eb = (g->dtype == TV_F32) ? 4 : 8;
-    if (d.s_t * eb >= (1ll << 31)) return false;     // frame descriptors: num_records and the out-of-range offset (tv_fused.h, BUF_OOB)
+    if (d.s_z * eb >= (1ll << 31)) return false;     // plane descriptors: num_records and the out-of-range offset (tv_fused.h, BUF_OOB)
     if (env_int("TV_NO_MARCH", 0) || env_int("TV_NO_MARCH_NORMAL", 0)) return false;
     // small planes: the z / t neighbours of the one-site kernel stay in L2 (same threshold as the other streaming kernels)
     return (long long)d.s_z * eb >= (long long)env_int("TV_MARCH_MIN_PLANE_KB", 4096) * 1024;
@@ -25,6 +25,7 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
     const int V = (g->dtype == TV_F32) ? 4 : 2;
     const long long tx = ((d.nx + V - 1) / V + ST_BCV - 1) / ST_BCV, ty = (d.ny + ST_BR - 1) / ST_BR;
     const long long nwin = (d.m > NS_TWN) ? (d.m + NS_TWN - 1) / NS_TWN : 1;
+    const bool ragged = (d.m > NS_TWN) && (d.m % NS_TWN != 0);
     int zc = env_int("TV_NS_ZCHUNK", 0);          // (this kernel family alone; TV_ZCHUNK: every z-chunked kernel)
     if (zc <= 0) zc = env_int("TV_ZCHUNK", 0);
     if (zc <= 0) {
@@ -58,6 +59,10 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
         if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL)                                                             \
             hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, double>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
         else if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, float>), grid, block, 0, st, d, w, a, zc, (int)nch); \
+        else if (TW && ragged) {          /* tv_nstream.h, RAGGED: the last window is short */                       \
+            if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH, TW>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
+            else hipLaunchKernelGGL((k_normal_stream<MM, TW, float, CH, TW>), grid, block, 0, st, d, w, a, zc, (int)nch); \
+        }                                                                                                              \
         else if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
         else hipLaunchKernelGGL((k_normal_stream<MM, TW, float, CH>), grid, block, 0, st, d, w, a, zc, (int)nch);       \
     } while (0)

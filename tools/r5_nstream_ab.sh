@@ -1,10 +1,10 @@
 #!/bin/bash
 # round 5, late: the Chebyshev step / normal operator after the straight-line rewrite (frame descriptors, operands a frame ahead, planes loaded in
-# place), A/B against the library of the commit before on ONE box:  PYTV4D_LIB=.../libpytv4d_hip_base.so (built from a worktree of that commit)
+# place), A/B against the library of the commit before on ONE box:  PYTV4D_LIB=.../libpytv4d_hip_base.so (built from a worktree of that commit, or a copy of the product library of the commit before)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; O=$R/gpurun_out; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_admm_fused.py tests/test_gpu_admm_ops.py tests/test_gpu_parity.py tests/test_gpu_pitch.py tests/test_gpu_configs.py tests/test_gpu_multirank.py -x -q 2>&1 | tail -5
 BASE=$R/pytv-4d_amd/pytv/libpytv4d_hip_base.so
-for rep in 1; do
+for rep in 1 2; do
 for lib in new base; do
   [ $lib = base ] && [ ! -f $BASE ] && continue
   for s in upwind downwind central hybrid; do
