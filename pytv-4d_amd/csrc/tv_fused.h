@@ -50,7 +50,7 @@ using F4 = Vec<float, 4>;
 #define TV_FUSED_PFQ_TWIN 1      // the central dual prefetch (PFQ) in the windowed (M > 8) instantiations too (round 3)
 #endif
 #ifndef TV_FUSED_PFQ
-#define TV_FUSED_PFQ 1
+#define TV_FUSED_PFQ 2
 #endif
 #ifndef TV_FUSED_XE
 #define TV_FUSED_XE 0
@@ -393,7 +393,12 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
     // so its waves waited ~77 % of the time with too few bytes in flight: sweep 26.6 - 27.4 -> 21.2 - 23.0 ms on the
     // north-star volume (0.52 -> 0.63 of peak; profiles/r2_ab_pfq.txt).  Measured for upwind / downwind too: 3 - 7 % SLOWER
     // there (they already request plane z+1 of x a step ahead), so it stays off; hybrid has no registers for it.
-    constexpr bool PFQ = (TV_FUSED_PFQ != 0) && (S == CENTRAL || (TV_FUSED_PFQ == 2 && S != HYBRID)) && (!TWIN || TV_FUSED_PFQ_TWIN != 0);      // 2: EXPERIMENT every Nd = 4 scheme
+    // Round 5: upwind / downwind too, on wide fp32 frames (XW) -- re-measured on the kernel as it is now, one box, product against
+    // -DTV_FUSED_PFQ=2 (profiles/r5f_pfq_ab.txt): ADMM sweep of the configs[4] slab 5.18 -> 4.52 ms (upwind), 5.09 -> 4.51 (downwind);
+    // CP sweep of the north-star volume 20.10 -> 19.36 (upwind), 20.85 -> 19.70 (downwind).  Not on narrow frames (XW false: the M >= 5
+    // downwind instantiations spill up to 484 B with it) and not in fp64 (unmeasured).  TV_FUSED_PFQ: 0 off, 1 central only, 2 (default) this.
+    constexpr bool PFQ = (TV_FUSED_PFQ != 0) && (S == CENTRAL || (TV_FUSED_PFQ == 2 && S != HYBRID && XW && sizeof(T) == 4)) &&
+                         (!TWIN || TV_FUSED_PFQ_TWIN != 0);
     VT qpre[PFQ ? 4 : 1];
     if (PFQ) {
 #pragma unroll

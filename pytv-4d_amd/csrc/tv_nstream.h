@@ -410,7 +410,7 @@ template <typename T> __device__ __forceinline__ E2<T> buf_ld_e2(Rsrc r, unsigne
 }
 
 // T: float (4 columns per 16-byte lane) or -- round 4 -- double (2 columns: the +-2 column neighbours are then whole neighbour lanes)
-template <int M, bool TWIN, bool CHEB = false, typename T = float>
+template <int M, bool TWIN, bool CHEB = false, typename T = float, bool RAGGED = false>
 __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3)) void k_normal_stream_cen(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
     constexpr int V = 16 / (int)sizeof(T);
     using VT = Vec<T, V>;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                 if (w_prev && in_chunk) { cold1 = Wp1; cold2 = Wp2; }
 #pragma unroll
                 for (int t = 0; t < M; ++t) {
-                    if (t >= NV) break;                 // (k_normal_stream: what the early exit is for)
+                    if (t >= (RAGGED ? 1 : TV_NS_EXIT_FROM(M)) && t >= NV) break;                 // (k_normal_stream: what the early exits are for)
                     st_sync_frame();
                     const int tg = t0 + t;
                     const VT c = Cc[t], h = H[t], xm = Pp[t];

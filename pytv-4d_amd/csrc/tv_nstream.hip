@@ -56,7 +56,11 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
                            (const double*)c.y, (const double*)c.add, (const double*)c.ref, c.alpha, c.beta, cheb ? 1 : 0, c.yscale};
 #define TV_NS_LAUNCH1(MM, TW, CH)                                                                                       \
     do {                                                                                                               \
-        if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL)                                                             \
+        if (g->scheme == TV_CENTRAL && TW && ragged) {                                                                 \
+            if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, double, TW>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
+            else hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, float, TW>), grid, block, 0, st, d, w, a, zc, (int)nch); \
+        }                                                                                                              \
+        else if (g->dtype == TV_F64 && g->scheme == TV_CENTRAL)                                                        \
             hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, double>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
         else if (g->scheme == TV_CENTRAL) hipLaunchKernelGGL((k_normal_stream_cen<MM, TW, CH, float>), grid, block, 0, st, d, w, a, zc, (int)nch); \
         else if (TW && ragged) {          /* tv_nstream.h, RAGGED: the last window is short */                       \
