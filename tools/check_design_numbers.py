@@ -52,7 +52,8 @@ def file_has(path, token):
                 pass
     else:       # text / csv evidence: any longer decimal that rounds to the quoted one
         vals = [float(m) for m in re.findall(r"(?<![\w.])\d+\.\d+(?:[eE][-+]?\d+)?", txt)]
-        if path.endswith(".csv"):       # rocprofv3 kernel_stats.csv stores nanoseconds: a table may quote them as microseconds / milliseconds
+        if path.endswith(".csv"):       # rocprofv3 kernel_stats.csv stores nanoseconds (averages with decimals, min / max as integers): a table
+            vals += [float(m) for m in re.findall(r"(?<![\w.])\d{4,}(?![\w.])", txt)]      # may quote them as microseconds / milliseconds
             vals += [v * 1e-3 for v in vals] + [v * 1e-6 for v in vals]
     want = float(token)
     return any(abs(round(v, nd) - want) < 0.5 * 10 ** (-nd) * 1e-6 + 1e-12 or ("%.*f" % (nd, v)) == token for v in vals)
