@@ -187,8 +187,10 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
     const long long lid = (long long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;       // XCD-aware order (tv_dstream.h)
     double acc0 = 0.0, acc1 = 0.0;
     if (lid < total) {
-        const int win = (int)(lid / (ntiles * nchunks));
-        const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
+        // (64-bit divisions run on the vector unit: say that the results are wave-uniform, or descriptors and scalar offsets derived from them
+        // are wrapped in a loop over their values)
+        const int win = __builtin_amdgcn_readfirstlane((int)(lid / (ntiles * nchunks)));
+        const int chunk = __builtin_amdgcn_readfirstlane((int)((lid / ntiles) % nchunks)), tile = __builtin_amdgcn_readfirstlane((int)(lid % ntiles));
         const int t0 = TWIN ? win * NS_TWN : 0;
         const int bx = tile % tiles_x, by = tile / tiles_x;
         const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * V, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
@@ -425,8 +427,10 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
     const long long lid = (long long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     double acc0 = 0.0, acc1 = 0.0;
     if (lid < total) {
-        const int win = (int)(lid / (ntiles * nchunks));
-        const int chunk = (int)((lid / ntiles) % nchunks), tile = (int)(lid % ntiles);
+        // (64-bit divisions run on the vector unit: say that the results are wave-uniform, or descriptors and scalar offsets derived from them
+        // are wrapped in a loop over their values)
+        const int win = __builtin_amdgcn_readfirstlane((int)(lid / (ntiles * nchunks)));
+        const int chunk = __builtin_amdgcn_readfirstlane((int)((lid / ntiles) % nchunks)), tile = __builtin_amdgcn_readfirstlane((int)(lid % ntiles));
         const int t0 = TWIN ? win * NS_TWN : 0;
         const int bx = tile % tiles_x, by = tile / tiles_x;
         const int col0 = (bx * ST_BCV + (wave % ST_NWX) * 16 + lx) * V, y = (by * ST_NWY + wave / ST_NWX) * 4 + row;
