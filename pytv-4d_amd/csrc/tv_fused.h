@@ -52,6 +52,9 @@ using F4 = Vec<float, 4>;
 #ifndef TV_FUSED_PFQ
 #define TV_FUSED_PFQ 2
 #endif
+#ifndef TV_FUSED_PFX
+#define TV_FUSED_PFX 1
+#endif
 #ifndef TV_FUSED_XE
 #define TV_FUSED_XE 0
 #endif
@@ -431,7 +434,15 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
     if (XW) __syncthreads();      // counters zeroed, the first plane's x edges published
 
     // finalise plane zf (its x values are in `xv`), adjoint accumulator `racc` (un-scaled)
-    auto finalize = [&](int zf, int t, const VT& xv, VT racc) {
+    // PFX (round 5): the operands of the lagged primal update (x0, p of plane z - 1) are requested at the TOP of the frame that finalises them,
+    // through frame descriptors (no branch), instead of inside finalize() behind everything else: one exposed memory round trip per frame
+    // less.  pre0 / pre1: those operands when `pre` is set (x0 and p; ADMM: x0; CPOP: A^T p).  Measured with the product library and a
+    // -DTV_FUSED_PFX=1 variant interleaved on one box, 24 constructions of the north-star problem each (profiles/r5i_pfx_ab.txt): hybrid
+    // sweep 32.8 -> 31.8 ms on average, best allocation 31.0 -> 30.7; ADMM hybrid 14.11 -> 14.01 ms, upwind 10.66 -> 10.48.  Not for central
+    // (its M = 8 instantiations spill 36 - 100 B with it) nor the hybrid single-window instantiations for 6 - 8 frames (12 - 88 B).
+    constexpr bool PFX = (TV_FUSED_PFX != 0) && XW && sizeof(T) == 4 &&
+                         (S == UPWIND || S == DOWNWIND || (S == HYBRID && (TWIN || M <= 5)));
+    auto finalize = [&](int zf, int t, const VT& xv, VT racc, bool pre = false, const VT& pre0 = VT{}, const VT& pre1 = VT{}) {
         if (!c.ok || t0 + t >= Mg) return;
         const int eb = (zf - c.zs) & 1;
         if (XW) {
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
         }
         const long long foff = (long long)zf * g.s_z + (long long)(t0 + t) * g.s_t;      // uniform
         if constexpr (ALG == ALG_ADMM) {      // r = (x0 - x) + rho D^T t'
-            const VT x0v = ldu_s_t<T, V>(a.x0 + foff, voff);
+            const VT x0v = (PFX && pre) ? pre0 : ldu_s_t<T, V>(a.x0 + foff, voff);
             VT ro;
             double r2 = 0.0, f2 = 0.0;
 #pragma unroll
@@ -458,14 +469,14 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
             return;
         }
         if constexpr (ALG == ALG_CPOP) {      // x_out = (x - tau A^T p) - tau D^T q'   (the arithmetic of tv_DT_axpy2)
-            const VT atp = ldu_s_t<T, V>(a.p + foff, voff);
+            const VT atp = (PFX && pre) ? pre0 : ldu_s_t<T, V>(a.p + foff, voff);
             VT xo;
 #pragma unroll
             for (int i = 0; i < V; ++i) xo.v[i] = (xv.v[i] - a.tau * atp.v[i]) - a.tau * (s * racc.v[i]);
             stu_s_t<T, V>(a.x_out + foff, voff, xo);
             return;
         }
-        const VT x0v = ldu_s_t<T, V>(a.x0 + foff, voff), pv = ldu_s_t<T, V>(a.p + foff, voff);
+        const VT x0v = (PFX && pre) ? pre0 : ldu_s_t<T, V>(a.x0 + foff, voff), pv = (PFX && pre) ? pre1 : ldu_s_t<T, V>(a.p + foff, voff);
         VT pn, xo;
         double e2 = 0.0;
 #pragma unroll
@@ -548,6 +559,16 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
                 e_cur = E[t];
                 if constexpr (PFN) E[t] = En[t];
                 else E[t] = (load_next && (e_le || e_re)) ? ldu1_t<T>(pn + toff, eoff) : T(0);
+            }
+            VT fx0 = zero, fx1 = zero;
+            if constexpr (PFX) {
+                const long long fo = (long long)(z - 1) * g.s_z + toff;
+                const int fb = (int)(g.s_t * (long long)sizeof(T));
+                const unsigned bo = c.ok ? voff : BUF_OOB;
+                constexpr int NTX = TV_FUSED_NT ? BUF_NT : 0;
+                if constexpr (ALG == ALG_CPOP) fx0 = buf_ld<T, V, NTX>(buf_rsrc<T>(a.p + fo, z > c.zs, fb), bo);
+                else fx0 = buf_ld<T, V, NTX>(buf_rsrc<T>(a.x0 + fo, z > c.zs, fb), bo);
+                if constexpr (ALG == ALG_CP) fx1 = buf_ld<T, V, NTX>(buf_rsrc<T>(a.p + fo, z > c.zs, fb), bo);
             }
             VT qcur[PFQ ? 4 : 1];
             if (PFQ) {
@@ -711,7 +732,7 @@ __global__ __launch_bounds__(64 * CP_NW, TV_WAVES ? TV_WAVES : 2) void k_cp_fuse
             if (z > c.zs) {
                 VT rf = lds_R[t][tid];
                 if (DN) rf = rf - qzd;
-                finalize(z - 1, t, P[t], rf);
+                finalize(z - 1, t, P[t], rf, PFX, fx0, fx1);
             }
             // ------------------------------------------------ adjoint accumulator of plane z
             VT r = zero;
