@@ -2,9 +2,13 @@
 // x-update's conjugate-gradient loop), radius-1 schemes (upwind / downwind / hybrid share D^T D = sum_a w_a^2 (bwd_a -
 // fwd_a) as long as the time weight does not vary along t), fp32, 16-byte lanes, any number of frames (windows of 8).
 //
-// Same structure as k_D_stream (tv_dstream.h): a wave covers 4 rows x 16 lanes, row neighbours are 16-lane shuffles,
-// column neighbours one-lane DPP shifts, halo rows / edge elements predicated loads; no LDS tile, no barrier; x is read
-// once, every load is issued one plane ahead of its use.  State: planes z-1, z, z+1 of the M frames in registers.
+// Same tile as k_D_stream (tv_dstream.h): a wave covers 4 rows x 16 lanes, row neighbours are 16-lane shuffles, column
+// neighbours one-lane DPP shifts, halo rows / edge elements one load each for the lanes that need them; no LDS tile; x is
+// read once, every load is issued one plane ahead of its use.  State: planes z-1, z of the M frames, the unfinished result
+// of plane z-1 and the halo rows / edge elements of plane z in registers.  Since late round 5 every access is a raw buffer
+// access through a descriptor (no branch around a memory operation), planes are loaded in place and the epilogue's operands
+// are requested a frame ahead: how and why is written where it happens (ns_epi_load_buf, the frame loop of k_normal_stream)
+// and in EXPERIMENTS.md 5.7.
 //
 // Modes (NormalArgs): b == nullptr:  out = A x,  dots = { <x, out>, <x, x> }
 //                     b != nullptr:  out = b - A x (and out2 = out when given: r and the first search direction of CG),
@@ -60,7 +64,7 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> NLDU(const T* 
 #endif
 }
 // The streamed operands of one site-vector's epilogue.  Round 5 (late): they are REQUESTED ONE FRAME AHEAD of the epilogue that consumes
-// them (ns_epi_load at the end of frame t for frame t + 1).  Loaded where they were consumed they were the youngest loads in flight, so
+// them (ns_epi_load_buf at the end of frame t for frame t + 1).  Loaded where they were consumed they were the youngest loads in flight, so
 // every frame ended in s_waitcnt vmcnt(0): a full memory round trip per frame with nothing else to do, which also drained the plane-ahead
 // requests of the stencil -- the kernel ran at the latency of memory, not its bandwidth (Chebyshev step 0.54 of peak at 8 waves per CU).
 template <typename T, int V> struct NsEpiIn { Vec<T, V> b, y, add, ref; };
