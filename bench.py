@@ -2,7 +2,8 @@
 """Benchmark of the hot path: fused Chambolle-Pock iterations (default) or ADMM outer iterations (--solver admm) on a
 synthetic (Nz, M, N, N) fp32 volume.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run, or from a plain shell -- bench.py then
+                                                             starts the launcher itself as a child, before anything touches a GPU)
     python bench.py --solver admm --workload config4-slab --scheme upwind      (BASELINE configs[4]: the per-GPU slab of the 8-GPU job)
 
 A "step" is ONE Chambolle-Pock iteration (README.md:145-157 of the reference: fidelity-dual update,
@@ -315,7 +316,17 @@ def series_summary(v):
             "max": round(max(v), 3)}
 
 
-def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, comm_name, x0, want_live):
+def _test_stall(rank, phase):
+    """TEST knob TV_BENCH_TEST_STALL="<rank>:<phase>": that rank stops making progress at that point (the watchdog test)."""
+    spec = os.environ.get("TV_BENCH_TEST_STALL", "")
+    if spec == "%d:%s" % (rank, phase):
+        sys.stderr.write("[bench] TEST: rank %d stalls before phase '%s'\n" % (rank, phase))
+        sys.stderr.flush()
+        while True:
+            time.sleep(1.0)
+
+
+def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, comm_name, x0, want_live, wd):
     """--solver admm: K outer iterations of pytv.solvers.ADMM (defaults: one-sweep dual side, Chebyshev x-solve, keep_z=True) between
     barriers; HIP events at the phase boundaries of every outer iteration (x-solve | sweep | fix-up); rank 0 prints one line."""
     import torch
@@ -342,12 +353,15 @@ def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, co
         ad.step(hist[k])
     ad.timing = []
     state_before = gpu_state(local_rank) if rank == 0 else None
+    wd.arm("timed region", 120 + 10 * K)
+    _test_stall(rank, "timed")
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
         ad.step(hist[W + k])
     barrier()
     elapsed = time.perf_counter() - t0
+    wd.arm("closing collectives", 600)
     state_after = gpu_state(local_rank) if rank == 0 else None
     marks = ad.timing[:K]
     ad.timing = None
@@ -401,6 +415,7 @@ def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, co
         out["series_ms"] = {"xsolve": series_summary(s_x), "sweep": series_summary(s_sw), "fixup": series_summary(s_fx),
                             "note": "HIP events on the launch stream at the phase boundaries of every outer iteration"}
     live, live_note = None, "--pmc off"
+    wd.arm("post-run: live PMC passes, CPU baseline on rank 0, final barrier", 1800)
     if want_live:
         del ad, x0, hist, hist_r, marks
         torch.cuda.empty_cache()
@@ -434,9 +449,124 @@ def run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, co
         out["cpu_baseline"] = cpu_baseline_admm(shape, wl["reg_z"], wl["reg_time"], args.scheme, args.rho, args.n_cg)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    wd.arm("process group teardown", 120)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    wd.disarm()
+
+
+def error_line(args, n_gpus, message, **extra):
+    """The JSON line of a run that produced no number: same leading keys as a good line, value null, the reason in `error`."""
+    out = {"metric": METRIC[args.solver], "value": None, "unit": "it/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": args.workload}}
+    out.update(extra)
+    out["error"] = message
+    return json.dumps(out)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) from a plain shell, no RANK / WORLD_SIZE in the environment: start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same arguments>` as a CHILD process, relay its
+    stdout (rank 0's JSON line) and return its exit code.  This process never imports torch and never makes a HIP call -- it is not
+    replaced either (no exec).  A child that outlives TV_BENCH_TIMEOUT seconds is killed by process group and reported as an error line;
+    a child that fails without a line gets one.  TV_BENCH_RETRY=1: a failed first attempt is repeated ONCE without the halo/compute
+    overlap (--no-overlap), and stderr says so."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    assert "torch" not in sys.modules, "the launcher must start before torch is imported"
+    n = args.gpus
+    module = os.environ.get("TV_BENCH_LAUNCH_MODULE", "torch.distributed.run")        # (tests substitute a recorder)
+    limit = float(os.environ.get("TV_BENCH_TIMEOUT", "2400"))
+    attempts = [list(argv)]
+    if os.environ.get("TV_BENCH_RETRY", "0") == "1" and "--no-overlap" not in argv:
+        attempts.append(list(argv) + ["--no-overlap"])
+    rc = 1
+    for k, av in enumerate(attempts):
+        port = os.environ.get("TV_BENCH_MASTER_PORT")
+        if port is None:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = str(sk.getsockname()[1])
+        cmd = [sys.executable, "-m", module, "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
+               os.path.abspath(__file__)] + av
+        env = dict(os.environ, TV_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        sys.stderr.write("[bench] self-launch (torch imported: %s): %s\n" % ("torch" in sys.modules, " ".join(cmd)))
+        sys.stderr.flush()
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+        got_line = [False]
+
+        def relay():
+            for ln in proc.stdout:
+                if ln.startswith("{"):
+                    got_line[0] = True
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+
+        th = threading.Thread(target=relay, daemon=True)
+        th.start()
+        try:
+            rc = proc.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)          # exactly the process group started above
+            except ProcessLookupError:
+                pass
+            proc.wait()
+            th.join(10)
+            print(error_line(args, n, "the %d-rank job did not finish within TV_BENCH_TIMEOUT = %.0f s and was killed" % (n, limit)), flush=True)
+            return 5
+        th.join(10)
+        if rc == 0 and got_line[0]:
+            return 0
+        if not got_line[0]:
+            print(error_line(args, n, "the launcher (%s) exited with code %d and rank 0 printed no line" % (module, rc)), flush=True)
+        if k + 1 < len(attempts):
+            sys.stderr.write("[bench] attempt %d failed (exit code %d); repeating once with --no-overlap\n" % (k + 1, rc))
+    return rc if rc != 0 else 1
+
+
+class Watchdog:
+    """A stuck collective / `work.wait()` / kernel must not hang the job: every rank arms a deadline per PHASE of the run
+    (communicator setup, construction + warm-up, the timed region, the per-phase pass, the closing collectives).  A rank whose deadline
+    passes writes the phase and the deadline to stderr, rank 0 prints an error JSON line, and the process ends with os._exit(4) -- the
+    launcher then takes the other ranks down.  Nothing is re-exec'ed and no GPU call is made from the watchdog thread.
+    TV_BENCH_WATCHDOG_SCALE multiplies every deadline (0 disables)."""
+
+    def __init__(self, args, rank, world):
+        import threading
+        self.args, self.rank, self.world = args, rank, world
+        self.scale = float(os.environ.get("TV_BENCH_WATCHDOG_SCALE", "1"))
+        self.lock = threading.Lock()
+        self.phase, self.deadline = None, None
+        if self.scale > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def arm(self, phase, seconds):
+        with self.lock:
+            self.phase, self.deadline = phase, time.monotonic() + seconds * self.scale
+
+    def disarm(self):
+        with self.lock:
+            self.phase, self.deadline = None, None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                phase, deadline = self.phase, self.deadline
+            if deadline is not None and time.monotonic() > deadline:
+                msg = "watchdog: rank %d of %d made no progress in phase '%s' within its deadline" % (self.rank, self.world, phase)
+                sys.stderr.write("[bench] %s\n" % msg)
+                sys.stderr.flush()
+                if self.rank == 0:
+                    print(error_line(self.args, self.world, msg), flush=True)
+                os._exit(4)
 
 
 def main():
@@ -474,15 +604,15 @@ def main():
     args = ap.parse_args()
     if args.solver is None:
         args.solver = WORKLOADS[args.workload].get("solver", "cp")
+    # N > 1 from a plain shell: this process becomes the launcher's parent BEFORE torch is imported or any HIP call is made
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     # multi-GPU workloads are refused on fewer ranks BEFORE anything touches the GPU (exit code 2, one JSON line with the reason)
     _wl, _world = WORKLOADS[args.workload], int(os.environ.get("WORLD_SIZE", "1"))
     if _world < _wl.get("min_gpus", 1) and not args.allow_single:
         if int(os.environ.get("RANK", "0")) == 0:
-            print(json.dumps({"metric": METRIC[args.solver], "value": None, "unit": "it/s", "n_gpus": _world, "steps": args.steps,
-                              "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-                              "data": "synthetic", "config": {"workload": args.workload},
-                              "error": "workload %s %s is a multi-GPU job (>= %d ranks); pass --allow-single to run it on %d"
-                                       % (args.workload, "x".join(map(str, _wl["shape"])), _wl["min_gpus"], _world)}), flush=True)
+            print(error_line(args, _world, "workload %s %s is a multi-GPU job (>= %d ranks); pass --allow-single to run it on %d"
+                             % (args.workload, "x".join(map(str, _wl["shape"])), _wl["min_gpus"], _world)), flush=True)
         sys.exit(2)
     # must be in the environment BEFORE the HIP runtime starts (the pool's driver only supports dmabuf IPC; RCCL's
     # cross-process buffer sharing fails with hipIpcGetMemHandle: invalid argument otherwise).  Round 2 set it after
@@ -505,9 +635,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    wd = Watchdog(args, rank, world)
+    wd.arm("communicator setup", 420)
     # TEST-ONLY knobs (tests / single-GPU box): several ranks on one GPU over gloo with host-staged halos
     backend = os.environ.get("TV_BENCH_BACKEND", "nccl")
     if os.environ.get("TV_BENCH_SHARE_GPU", "0") == "1":
@@ -551,17 +680,15 @@ def main():
             assert int(probe.item()) == world, "all-reduce over %d ranks returned %r" % (world, probe.item())
     except Exception as exc:              # noqa: BLE001 -- whatever the transport throws: say so in the JSON line, fail the run
         if rank == 0:
-            print(json.dumps({"metric": METRIC[args.solver], "value": None, "unit": "it/s", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-                              "data": "synthetic", "config": {"workload": args.workload}, "comm": comm_name,
-                              "error": "communicator setup failed on rank %d of %d (backend %s, comm %s): %s: %s"
-                                       % (rank, world, backend, args.comm, type(exc).__name__, str(exc)[:600])}), flush=True)
+            print(error_line(args, world, "communicator setup failed on rank %d of %d (backend %s, comm %s): %s: %s"
+                             % (rank, world, backend, args.comm, type(exc).__name__, str(exc)[:600]), comm=comm_name), flush=True)
         sys.stderr.write("[bench rank %d] communicator setup failed: %r\n" % (rank, exc))
         sys.stderr.flush()
         os._exit(3)                       # every rank that fails exits non-zero at once (no destructor tries the dead communicator)
+    wd.arm("input synthesis, solver construction, warm-up", 900)
     x0 = synth_slab(shape, slab.z0, slab.nz, device)
     if args.solver == "admm":
-        run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, comm_name, x0, want_live)
+        run_admm(args, wl, shape, slab, device, rank, world, local_rank, backend, comm_name, x0, want_live, wd)
         return
     pkw = {}
     if args.pitch == "none":
@@ -594,11 +721,14 @@ def main():
     # (sampled BEFORE the barrier: a sysfs / rocm-smi read on rank 0 between the barrier and t0 would be time the other ranks spend
     # waiting in their first halo exchange -- round-4 advice)
     state_before = gpu_state(local_rank) if rank == 0 else None
+    wd.arm("timed region", 120 + 10 * K)
+    _test_stall(rank, "timed")
     barrier()
     t0 = time.perf_counter()
     cp.run_steps(hist[W:W + K])         # K iterations; the last sweep returns the final iterate's fidelity too (TV_CP_FID_BOTH): no extra pass
     barrier()
     elapsed = time.perf_counter() - t0
+    wd.arm("per-phase pass and closing collectives", 600)
     state_after = gpu_state(local_rank) if rank == 0 else None
     ev = cp.timing[:K]
     cp.timing = None
@@ -645,7 +775,6 @@ def main():
     V_local = float(slab.nz * shape[1] * shape[2] * shape[3])
     it_s = K / elapsed
     bytes_iter_algo = 4.0 * (8 + 3 * nd) * V            # the README's un-fused iteration
-    bytes_iter_fused = 4.0 * (6 + 3 * nd) * V           # what the two fused kernels must move
     out = {
         "metric": METRIC["cp"], "value": it_s, "unit": "it/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -655,9 +784,12 @@ def main():
                    "lambda": 25.0, "sigma_D": cp.sigma_D, "sigma_A": cp.sigma_A, "tau": cp.tau,
                    "parallelism": "z-slab x%d%s" % (world, " (halo overlapped)" if (cp.overlap or getattr(cp, "overlap_fused", False)) else "")},
         "voxel_iterations_per_sec": it_s * V,
-        "hbm_gbps_iteration": {"readme_unfused_(8+3Nd)_words": bytes_iter_algo * it_s / 1e9 / world,
-                               "two_kernel_(6+3Nd)_words": bytes_iter_fused * it_s / 1e9 / world,
-                               "one_sweep_(5+2Nd)_words": 4.0 * (5 + 2 * nd) * V * it_s / 1e9 / world, "per": "GPU"},
+        # bytes the kernels of THIS run must move per iteration (one sweep: 5 + 2 Nd words; kernel pair: 6 + 3 Nd) over the wall time
+        "hbm_gbps_iteration": {"algorithmic": 4.0 * ((5 + 2 * nd) if cp.fused else (6 + 3 * nd)) * V * it_s / 1e9 / world, "per": "GPU",
+                               "words_per_voxel": (5 + 2 * nd) if cp.fused else (6 + 3 * nd)},
+        # NOT a bandwidth: the rate the reference's un-fused iteration ((8 + 3 Nd) words) would need to keep this pace
+        "equivalent_unfused_gbps": {"readme_(8+3Nd)_words": bytes_iter_algo * it_s / 1e9 / world, "per": "GPU",
+                                    "note": "effective rate of work the fused kernels do not do; may exceed the HBM peak"},
         "loss_first_last": [float(loss[W]), float(loss[-1])],
         "state_layout": state_layout,
         # solvers.ChambollePock picks the two buffers of the x ping-pong by measurement at construction (outside the timed region, like
@@ -686,6 +818,7 @@ def main():
                         "note": "kernel1 = sweep (or dual), kernel2 = fix-up (or primal), step = start of iteration k to start of k+1"}
     out["gpu_state"] = {"before": state_before, "after": state_after, "source": "sysfs (pp_dpm_*, hwmon) read by rank 0 outside the timed region"}
     cp_fused = bool(cp.fused)
+    wd.arm("post-run: live PMC passes, CPU baseline on rank 0, final barrier", 1800)
     if want_live:
         # AFTER the timed region, with this process's device memory handed back: the child passes need the HBM for the same
         # volume, and a process that starts right after another one released ~100 GB can run 5 - 7 % slower for its whole life
@@ -742,9 +875,11 @@ def main():
             out["cpu_baseline_openmp"] = {"error": str(exc)[:200]}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    wd.arm("process group teardown", 120)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    wd.disarm()
 
 
 if __name__ == "__main__":

@@ -63,3 +63,76 @@ def test_cpu_baseline_samples_are_bounded_and_say_what_they_are(monkeypatch):
     h = bench.cpu_baseline_admm((32, 16, 1024, 1024), 1.0, 1.0, "hybrid", 0.05, 5)
     assert np.prod(calls["admm"][0]) < np.prod(shp)                                      # hybrid is 3 x slower per voxel: smaller sample
     assert h["value"] > 0
+
+
+def _plain_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    env["TV_BENCH_LAUNCH_MODULE"] = "_record_launch"
+    env.update(extra)
+    return env
+
+
+def test_gpus_n_from_a_plain_shell_starts_the_launcher_as_a_child_before_torch_is_imported():
+    """Round-5 verdict item 1: `python3 bench.py --gpus 8` without RANK / WORLD_SIZE used to exit 1.  Now the process starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py <same arguments>` as a child, relays its stdout and exit
+    code, and never imports torch itself (here the launcher module is replaced by a recorder)."""
+    argv = ["--gpus", "8", "--steps", "7", "--warmup", "2", "--workload", "config3", "--comm", "cabi"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1500:]
+    assert "self-launch (torch imported: False)" in p.stderr
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    a = rec["recorded_argv"]
+    assert a[:3] == ["--nnodes=1", "--nproc-per-node", "8"] and a[3:5] == ["--master-addr", "127.0.0.1"] and a[5] == "--master-port"
+    assert int(a[6]) > 0 and os.path.samefile(a[7], os.path.join(ROOT, "bench.py")) and a[8:] == argv
+    assert rec["self_launched"] == "1" and rec["ipc_legacy"] == "0"
+    # (config3 on 8 ranks is NOT refused by the parent: the min_gpus rule is the ranks' to apply, with WORLD_SIZE set)
+
+
+def test_self_launch_relays_the_exit_code_and_always_leaves_a_line():
+    argv = ["--gpus", "2", "--workload", "small"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="7"), capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 7
+    # a launcher that dies without a line: the parent prints the error line itself
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="9", TV_FAKE_LAUNCH_SILENT="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 9
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["value"] is None and out["n_gpus"] == 2 and "printed no line" in out["error"]
+    # a launcher that hangs: killed by process group after TV_BENCH_TIMEOUT, error line, exit code 5
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv,
+                       env=_plain_env(TV_FAKE_LAUNCH_SILENT="1", TV_FAKE_LAUNCH_SLEEP="600", TV_BENCH_TIMEOUT="3"), capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 5
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["value"] is None and "did not finish within" in out["error"]
+    # TV_BENCH_RETRY=1: one more attempt, without the overlap
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="3", TV_BENCH_RETRY="1"),
+                       capture_output=True, text=True, timeout=120)
+    recs = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 3 and len(recs) == 2 and "--no-overlap" not in recs[0]["recorded_argv"] and recs[1]["recorded_argv"][-1] == "--no-overlap"
+
+
+def test_under_a_launcher_bench_does_not_launch_again():
+    """with RANK / WORLD_SIZE in the environment (torch.distributed.run, the driver's form) main() goes straight on: the refusal of a
+    multi-GPU workload on too few ranks is the first thing that can be observed without a GPU"""
+    env = _plain_env(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "config3"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 2 and "self-launch" not in p.stderr
+    assert "multi-GPU job" in json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["error"]
+
+
+def test_watchdog_ends_a_stuck_process_with_an_error_line():
+    """bench.Watchdog alone (no GPU): an armed deadline that passes prints rank 0's error line and ends the process with code 4."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench, argparse\n"
+            "a = argparse.Namespace(solver='cp', steps=3, warmup=1, workload='small')\n"
+            "w = bench.Watchdog(a, 0, 2); w.arm('first', 600); w.arm('timed region', 1.0); time.sleep(30); print('NOT REACHED')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 4 and "NOT REACHED" not in p.stdout
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["value"] is None and out["n_gpus"] == 2 and "timed region" in out["error"] and "rank 0 of 2" in out["error"]
+    code2 = code.replace("time.sleep(30)", "w.disarm(); time.sleep(3)")
+    p = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "NOT REACHED" in p.stdout

@@ -249,3 +249,56 @@ def test_bench_measures_its_hbm_traffic_live():
     assert r["traffic_source"].startswith("LIVE"), r["traffic_source"]
     assert 0.98 * r["bytes_per_launch"] <= r["traffic"] <= 1.25 * r["bytes_per_launch"], (r["traffic"], r["bytes_per_launch"])
     assert out["roofline_fixup"]["traffic"] > 0
+
+
+def _shell_env(**extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TV_BENCH_BACKEND", "TV_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+def test_gpus_2_from_a_plain_shell_launches_itself_and_matches_one_rank():
+    """Round-5 verdict item 1: `python3 bench.py --gpus 2 --workload rehearsal --nz 8` from a plain shell (no launcher, no RANK /
+    WORLD_SIZE) starts torch.distributed.run as a child before anything touches the GPU, relays rank 0's line and exit code; with the
+    TEST transport (gloo, both ranks on cuda:0) the 2-rank loss equals the 1-rank loss."""
+    common = ["--workload", "rehearsal", "--nz", "8", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--pmc", "off"]
+    one = _bench_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, _shell_env(TV_ZCHUNK="2"))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                       env=_shell_env(TV_BENCH_BACKEND="gloo", TV_BENCH_SHARE_GPU="1", TV_ZCHUNK="2"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert "self-launch (torch imported: False)" in p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["shape"] == [8, 8, 1024, 1024] and "z-slab x2" in two["config"]["parallelism"]
+    assert two["rccl_ranks"] == 0 and "phases" in two and "x_halo_wait_exposed" in two["phases"]["max_over_ranks"]
+    a, b = one["loss_first_last"], two["loss_first_last"]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1])
+    assert one["n_gpus"] == 1 and "self-launch" not in one.get("comm", "")
+
+
+def test_a_stalled_rank_ends_the_job_with_an_error_line_not_a_hang():
+    """the per-phase watchdog: rank 1 stops before the timed region (TEST knob), rank 0 sits in the barrier; every rank's deadline
+    passes, rank 0 prints the error line, all processes exit non-zero and the self-launching parent relays line and code."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--pmc", "off"],
+                       env=_shell_env(TV_BENCH_BACKEND="gloo", TV_BENCH_SHARE_GPU="1", TV_BENCH_TEST_STALL="1:timed", TV_BENCH_WATCHDOG_SCALE="0.15"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["value"] is None and out["n_gpus"] == 2 and "watchdog" in out["error"] and "timed region" in out["error"]
+
+
+def test_comm_cabi_through_the_self_launch_reports_its_setup_failure():
+    """--comm cabi needs one GPU per rank (RCCL refuses two ranks on one device): from a plain shell on this 1-GPU box the 2-rank job
+    must come back with the communicator-setup error line and a non-zero exit code -- relayed, not hung."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--pmc", "off", "--comm", "cabi"],
+                       env=_shell_env(TV_BENCH_BACKEND="gloo", TV_BENCH_SHARE_GPU="1", TV_BENCH_WATCHDOG_SCALE="0.25"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["value"] is None and out["n_gpus"] == 2
+    assert "communicator setup failed" in out["error"] or "watchdog" in out["error"]
