@@ -1,6 +1,6 @@
 // tv_subgrad2.h -- ONE-PASS TV value + sub-gradient (pytv/tv_GPU.py:47-375 of the reference), round-3 kernel.
 //
-// Same mathematics as the round-1 kernel (variants/tv_subgrad.h; the scatter form: a site hands the PRODUCTS d * 1/|Dx| of its gradient channels to
+// Same mathematics as the round-1 kernel (retired, in the history; the scatter form: a site hands the PRODUCTS d * 1/|Dx| of its gradient channels to
 // its neighbours, 1/|Dx| never leaves the chip, the result is a pure function of x), rebuilt around what an instruction
 // costs on a gfx950 SIMD (tools/archive/issue_bench.hip, profiles/r3_issue_bench.txt): a plain fp32 VALU op 2 cycles, DPP / compare
 // / select / packed / fp64 4, v_rsq 6 - 8, and ds_bpermute_b32 -- what __shfl_up/down compile to -- 18 per dword.  The
@@ -22,9 +22,6 @@
 #include "tv_device.h"
 #include "tv_stencil.h"
 #include "tv_fused.h"
-#ifdef TV_WITH_OLD_SG
-#include "variants/tv_subgrad.h"      // the round-1 kernel k_subgrad_one: variant builds only (TV_WITH_OLD_SG)
-#endif
 
 namespace tv {
 

@@ -1,9 +1,9 @@
-// tv_subgrad_host.h -- launcher shared by the two translation units that instantiate k_subgrad_one
+// tv_subgrad_host.h -- launcher shared by the translation units that instantiate k_subgrad_col
 // (tv_subgrad.hip: MODE 0, G is stored; tv_sgstep.hip: MODE 1, the descent step is applied in the epilogue).
 #pragma once
 #include "tv_host.h"
 #include "tv_stencil.h"
-#include "tv_subgrad2.h"      // (TV_WITH_OLD_SG: pulls in variants/tv_subgrad.h, the round-1 kernel)
+#include "tv_subgrad2.h"
 
 // every M <= 8 has its own instantiation; more frames run as overlapping time windows of 8 frames (tv_subgrad.h)
 inline bool sg_m_ok(int m) { return m >= 1; }
@@ -16,11 +16,7 @@ inline int sg_supported(const tv_geom* g) {
     // before, ragged Nx took the two-pass path at 0.11 - 0.17 of the roofline).  The round-1 kernel (TV_SG_KERNEL=1, frames of
     // 2^31 bytes and more) is fp32 with 16-byte lanes.
     const bool k2 = env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * (g->dtype == TV_F32 ? 4 : 8) < (1ll << 31);
-#ifdef TV_WITH_OLD_SG
-    if (!k2 && (g->dtype != TV_F32 || d.nx % 4 != 0 || d.pitched)) return 0;     // (the round-1 kernel knows no pitch)
-#else
     if (!k2) return 0;              // frames of 2^31 bytes and more: the two-pass path (the round-1 kernel that took them is a variant build now)
-#endif
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return 0;   // two-point axes: forward stencil
     if (d.s_t > (1ll << 30)) return 0;                           // 32-bit per-lane byte offsets inside a frame
     if (d.m > SG2_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
@@ -168,26 +164,6 @@ inline int sg2_launch(const tv_geom* g, const DG& d, const void* x, const void* 
     return 0;
 }
 
-#ifdef TV_WITH_OLD_SG
-// ---- round-4 EXPERIMENT (variants/tv_subgrad3.h; variant builds only: TV_WITH_OLD_SG): a lane = 2 rows x 2 columns, a wave owns 496-byte row segments --------------------
-// fp32, even Nx / pitches (a lane's two columns are inside the frame or outside together), 8-byte aligned arrays.  One translation
-// unit per MODE (tv_subgrad3.hip, tv_subgrad3_norms.hip, tv_sgstep3.hip).  OPT-IN with TV_SG_KERNEL=3: parity-green (tests/
-// test_gpu_subgrad_pair.py) and measured no faster than the round-3 kernel (profiles/r4_sgpattern.txt), which stays the default.
-int sg3_launch_g(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
-                 double* fidout, void* ws, hipStream_t st, const SgHostArgs& so);
-int sg3_launch_norms(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
-                     double* fidout, void* ws, hipStream_t st, const SgHostArgs& so);
-int sg3_launch_step(const tv_geom* g, const DG& d, const void* x, const void* x_prev, const void* x_next, void* G, double* tvout,
-                    double* fidout, void* ws, hipStream_t st, const SgHostArgs& so);
-inline bool sg3_ok(const tv_geom* g, const DG& d, std::initializer_list<const void*> ptrs) {
-    if (g->dtype != TV_F32 || env_int("TV_SG_KERNEL", 2) != 3) return false;
-    if (d.nx % 2 != 0 || d.rp % 2 != 0 || d.s_t % 2 != 0 || d.s_z % 2 != 0 || d.s_t * 4 >= (1ll << 31)) return false;
-    for (const void* p : ptrs)
-        if (p != nullptr && ((uintptr_t)p & 7) != 0) return false;
-    return true;
-}
-
-#endif
 
 // common argument checks + launch geometry; MODE 1 passes the step arguments, MODE 0 an empty struct
 template <int MODE>
@@ -208,59 +184,10 @@ inline int sg_launch(const tv_geom* g, const void* x, const void* x_prev, const 
         if (!step_ok) return fail(TV_E_ARG, "the fp64 one-pass descent step needs step * lambda >= 1e-6: use tv_subgrad + tv_subgrad_step");
         return sg2_launch<double, MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
     }
-#ifdef TV_WITH_OLD_SG
-    if (step_ok && sg3_ok(g, d, {x, x_prev, x_next, G, ha.x0, ha.x_out, ha.norms, d.wv, d.wvp, d.wvn})) {
-        if constexpr (MODE == 0) return sg3_launch_g(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
-        else if constexpr (MODE == 1) return sg3_launch_step(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
-        else return sg3_launch_norms(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
-    }
-#endif
     if (env_int("TV_SG_KERNEL", 2) != 1 && d.s_t * 4 < (1ll << 31) && step_ok)
         return sg2_launch<float, MODE>(g, d, x, x_prev, x_next, G, tvout, fidout, ws, st, ha);
-#ifndef TV_WITH_OLD_SG
     // the product library holds ONE generation of the one-pass kernel (round-4 verdict, item 7): what it cannot take goes to the two-pass
     // entry points (tv_subgrad + tv_subgrad_step), as solvers.SubgradientDescent does on its own
     (void)vec16;
     return fail(TV_E_ARG, "the one-pass sub-gradient kernel needs step * lambda >= 1e-6 and frames below 2^31 bytes: use tv_subgrad + tv_subgrad_step");
-#else
-    if (d.pitched) return fail(TV_E_ARG, "pitched arrays need the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad + tv_subgrad_step");
-    if (d.wv != nullptr) return fail(TV_E_ARG, "a weight volume needs the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad");
-    if (!vec16) return fail(TV_E_ARG, "ragged Nx / unaligned arrays need the round-3 one-pass kernel (step * lambda >= 1e-6, frames < 2^31 bytes): use tv_subgrad + tv_subgrad_step");
-    SgStepArgs sa{(const float*)ha.x0, (float*)ha.x_out, (float)ha.step, (float)ha.lambda, nullptr, (float*)ha.norms};
-    const long long nmax = max_partials(d);
-    constexpr int NW = 4, UR = 4 * NW - 2, UC = 14;
-    const long long tx = (d.nx / 4 + UC - 1) / UC, ty = (d.ny + UR - 1) / UR;
-    // planes per z-chunk: every chunk computes two extra planes of norms (and loads four), so chunks are as long as
-    // keeping >= ~2048 blocks (4 rounds of 256 CUs x 2) allows; TV_ZCHUNK overrides
-    int zc = env_int("TV_ZCHUNK", 0);
-    if (zc <= 0) {
-        const long long want = (2048 + tx * ty - 1) / (tx * ty);
-        zc = (int)(d.nz / (want > 0 ? want : 1));
-        if (zc > 32) zc = 32;
-        if (zc < 8) zc = 8;
-    }
-    if (zc > d.nz) zc = d.nz;
-    const long long nch = (d.nz + zc - 1) / zc;
-    const long long nwin = (d.m > SG_TWN) ? (d.m + SG_TWU - 1) / SG_TWU : 1;      // time windows (M > 8)
-    const long long nb = tx * ty * nch * nwin, per_xcd = (nb + 7) / 8;       // XCD-aware logical ids: see the kernel
-    const dim3 grid((unsigned)(8 * per_xcd), 1, 1), block(64, NW, 1);
-    if (nb > nmax) return fail(TV_E_ARG, "internal: partials exceed the workspace");
-    double* w0 = (double*)ws;
-    double* w1 = w0 + nmax + kStage + 16;
-    sa.part_fid = w1;
-    int rc = dispatch_sg(g->scheme, d.m > SG_TWN ? 0 : d.m, [&]<int S, int M>() -> int {
-        if constexpr (M == 0)        // M > 8: overlapping windows of 8 frames
-            hipLaunchKernelGGL((k_subgrad_one<S, SG_TWN, NW, MODE, true>), grid, block, 0, st, d, make_w<float>(g), (const float*)x,
-                               (const float*)x_prev, (const float*)x_next, (float*)G, zc, (int)nch, w0, sa);
-        else
-            hipLaunchKernelGGL((k_subgrad_one<S, M, NW, MODE>), grid, block, 0, st, d, make_w<float>(g), (const float*)x,
-                               (const float*)x_prev, (const float*)x_next, (float*)G, zc, (int)nch, w0, sa);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    });
-    if (rc) return rc;
-    if (int r2 = reduce_partials(w0, nb, nmax, tvout, st)) return r2;
-    if (MODE == 1) return reduce_partials(w1, nb, nmax, fidout, st);
-    return 0;
-#endif
 }

@@ -177,7 +177,7 @@ class _SlabProblem:
     # The time of the streaming kernels depends on where their arrays sit in physical memory (EXPERIMENTS.md section 3, round 4: the
     # "placement lottery" -- separate allocations land anywhere: 31.3 - 34.2 ms per north-star sweep from one construction to the next).
     # Carved out of ONE allocation with 24 - 48 MiB between consecutive arrays the sweep takes the SAME time construction after
-    # construction (spread 0.4 - 0.5 % against 6 - 9 %: profiles/r5_slab_placement_probe{,2,3,4}.txt, tools/slab_placement_probe.py) --
+    # construction (spread 0.4 - 0.5 % against 6 - 9 %: profiles/r5_slab_placement_probe{,2,3,4}.txt, tools/archive/slab_placement_probe.py) --
     # but WHICH time is decided by where the one big allocation lands: 31.1 ms on one box, 33.1 - 33.4 on three others, alternating
     # 31.05 / 32.1 from construction to construction on a fifth; a second arena measured beside the first (``_tune_arena``) does not
     # help where both land on the slow level (profiles/r5_bench_northstar_arena_first_command.json: 33.2 ms, 35.5 ms per iteration
@@ -293,7 +293,7 @@ class ChambollePock(_SlabProblem):
         if fused is None:
             # one-sweep kernel where supported -- except on volumes too small to fill the GPU with its blocks (8 rows x 256
             # columns x >= 8 planes x all frames each: a block holds >= 16 k x M voxels and a CU takes 8 / M of them, so
-            # 256 CUs want >= 33 Mvoxel for one full round; tools/fused_vs_pair.py: 0.5 - 0.7 x of the kernel pair at
+            # 256 CUs want >= 33 Mvoxel for one full round; tools/archive/fused_vs_pair.py: 0.5 - 0.7 x of the kernel pair at
             # 6 - 8 Mvoxel with few planes, break-even at 8 - 13 Mvoxel, 1.15 - 1.25 x faster from 16 Mvoxel on whatever
             # the plane size -- 256x1x512x512 runs 990 - 1040 it/s against 870).  Option TV_FUSED_MIN_KVOXELS (thousands of
             # voxels of this rank's slab) moves the switch.
@@ -1193,7 +1193,7 @@ class ADMM(_SlabProblem):
         # reported to (the spectrum of D^T D fills its interval); oracle.admm(x_solver="chebyshev") restates it.
         # DEFAULT since round 4 (x_solver=None): Chebyshev wherever it applies (single_reduction, n_cg > 0), CG otherwise.  Measured on
         # the configs[4] per-GPU slab, 50 outer iterations, four schemes, rho in {0.02, 0.05, 0.2}, fp32 and fp64
-        # (tools/admm_xsolve_study.py, profiles/r4_admm_xsolve_study_*.txt): with the same number of steps the two reach the same
+        # (tools/archive/admm_xsolve_study.py, profiles/r4_admm_xsolve_study_*.txt): with the same number of steps the two reach the same
         # objective to 6 - 7 digits at EVERY outer iteration, and a Chebyshev outer iteration takes 12.8 - 16.3 ms where CG takes
         # 27 - 33 (fp64: 15 - 21 against 29 - 37): 2.1 - 2.4 x less wall time to any objective level, no all-reduce in the solve.
         # ``n_cg`` keeps its meaning: steps of the x-solve per outer iteration.  x_solver="cg" is the round-1..3 behaviour.

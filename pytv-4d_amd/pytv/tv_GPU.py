@@ -11,6 +11,17 @@ G from ``img`` and those norms).  The gradient array is never stored either way.
 Conventions kept: ``mask`` zeroes the caller's array in place; the TV
 value is always a 0-d numpy array; G (and grad_norms) are numpy unless ``return_pytorch_tensor``;
 grad_norms has zeros replaced by +inf; the sub-gradient uses unit weights in the adjoint.
+
+Deliberate differences from the reference's arithmetic (all inside the 1e-5 relative fp32 tolerance of the north star and the
+reference's own ``pytv/tests.py:88-109``; fp64: ``v_rsq_f64`` refined by two Newton steps, ~1 ulp, parity at 1e-11):
+* the fp32 one-pass kernel computes 1 / |D img| with the hardware reciprocal square root (``v_rsq_f32``, 1 ulp) and multiplies, where
+  the reference takes ``sqrt`` and divides (``pytv/tv_GPU.py:86-124``; SURVEY Q12 recommends IEEE sqrt / div).  |D img| itself, where
+  it is returned (``return_grad_norms``), is ``|D img|^2 * rsq`` -- within 2 ulp of the IEEE square root;
+* a voxel whose squared norm is below the smallest NORMAL fp32 number (1.18e-38, i.e. |D img| < 1.1e-19) counts as a ZERO gradient:
+  its terms are dropped and its grad_norm is +inf, exactly like a true zero (``pytv/tv_GPU.py:86-88``).  The reference would divide
+  by the sub-normal norm instead; inputs of that magnitude do not occur in image data, and the TV value is unaffected (< 1e-19 per
+  voxel).  The fp64 kernels apply the same rule at the smallest normal fp64 number;
+* the TV value is accumulated in fp64 over per-block partial sums (the reference: NumPy / torch pairwise sums in the input dtype).
 """
 import torch
 
@@ -27,7 +38,7 @@ def _has_mask(mask):
 
 def one_pass_ok(geo, itemsize=4):
     """Use the one-pass kernel (``tv_subgrad_fused``)?  Whenever the geometry is supported: it is as fast as or
-    faster than the two-pass kernels from 512 x 512 2-D images to the north-star volume (tools/sg_small_bench.py)."""
+    faster than the two-pass kernels from 512 x 512 2-D images to the north-star volume (tools/archive/sg_small_bench.py)."""
     return bool(_nv.lib().tv_subgrad_fused_supported(geo.ref))
 
 

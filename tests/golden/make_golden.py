@@ -44,6 +44,10 @@ CASES = [
     ("4d_mask_m2", (4, 2, 5, 5), 1.0, 1.5,   True,  0.25, "f8"),
     ("4d_f32",    (3, 4, 8, 8), 1.0, 1.0,    False, 0, "f4"),
     ("4d_f32_mask", (5, 3, 8, 8), 0.5, 2.0,  True,  4, "f4"),
+    # round 6: a boolean mask_static with the reference's DEFAULT factor_reg_static=0 (pytv/tv_operators_GPU.py:134): the time
+    # differences vanish on the masked pixels (appended: the seeds 1000 + index of the cases above do not move)
+    ("4d_mask_f0", (4, 3, 6, 6), 1.0, 1.0,   True,  0, "f8"),
+    ("4d_f32_mask_f0", (3, 4, 8, 8), 2.0, 0.5, True, 0, "f4"),
 ]
 
 

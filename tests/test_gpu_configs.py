@@ -43,7 +43,7 @@ def production(tvopt):
 
 def test_default_cp_path_follows_the_voxel_count(pytv, production):
     """solvers.ChambollePock(fused=None): the one-sweep path from 16 Mvoxel per slab on, whatever the plane size (round 1's
-    plane-size rule kept BASELINE config 1 on the slower kernel pair); the kernel pair below (tools/fused_vs_pair.py)."""
+    plane-size rule kept BASELINE config 1 on the slower kernel pair); the kernel pair below (tools/archive/fused_vs_pair.py)."""
     import torch
     for shape, want in (((16, 4, 256, 256), False), ((32, 8, 256, 256), True), ((64, 1, 512, 512), True), ((8, 1, 1024, 1024), False)):
         cp = pytv.solvers.ChambollePock(torch.zeros(shape, device="cuda"), 25.0)

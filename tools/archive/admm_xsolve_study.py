@@ -2,7 +2,7 @@
 """Round 4, verdict item 7: which x-solve should ADMM default to?  50 outer iterations on the configs[4] per-GPU slab, four schemes,
 rho in {0.02, 0.05, 0.2}: the primal objective 1/2 |x - x0|^2 + lambda |D x|_{2,1} against wall time for CG(5), Chebyshev(5),
 Chebyshev(3) (and CG(3)), fp32 and -- on half the planes -- fp64.
-usage: python tools/admm_xsolve_study.py [NzxMxNyxNx=32x16x1024x1024] [n_outer=50] [--f64]"""
+usage: python tools/archive/admm_xsolve_study.py [NzxMxNyxNx=32x16x1024x1024] [n_outer=50] [--f64]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Chambolle-Pock with a data-fidelity operator (solvers.ChambollePockOperator, A = a diagonal operator written with torch):
 the TV part as one sweep (tv_cpop_fused + tv_cpop_fixup) against the kernel pair tv_cp_dual + tv_DT_axpy2.
-usage: python tools/cpop_bench.py [NzxMxNyxNx] [scheme ...]"""
+usage: python tools/archive/cpop_bench.py [NzxMxNyxNx] [scheme ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)

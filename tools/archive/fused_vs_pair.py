@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-sweep Chambolle-Pock path against the dual + primal kernel pair on small / medium volumes (where does the default switch?).
-usage: python tools/fused_vs_pair.py [NzxMxNyxNx ...]"""
+usage: python tools/archive/fused_vs_pair.py [NzxMxNyxNx ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Instruction mix of the kernels in a gfx950 assembly file (hipcc -S --cuda-device-only): totals per kernel and for the
-largest loop bodies (a loop = a label that a later branch jumps back to).  usage: tools/isa_mix.py file.s [name-regex]"""
+largest loop bodies (a loop = a label that a later branch jumps back to).  usage: tools/archive/isa_mix.py file.s [name-regex]"""
 import collections, re, sys
 
 def group(op):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # EXPERIMENT -DTV_FUSED_PFN1=1: hybrid / downwind request x(z + 1) one frame ahead (tv_fused.h); one box: the parity tests with the variant, then
-# tools/slab_placement_probe.py with the product library and libpytv4d_hip_pfn1.so interleaved (4 constructions x 2 layouts x 3 repetitions each),
+# tools/archive/slab_placement_probe.py with the product library and libpytv4d_hip_pfn1.so interleaved (4 constructions x 2 layouts x 3 repetitions each),
 # then the ADMM / CP bench lines that use the kernel
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; O=$R/gpurun_out; mkdir -p $O
 VAR=$R/pytv-4d_amd/pytv/libpytv4d_hip_pfn1.so
@@ -8,7 +8,7 @@ PYTV4D_LIB=$VAR timeout 900 python -m pytest tests/test_gpu_parity.py tests/test
 for rep in 1 2 3; do
   for lib in product pfn1; do
     if [ $lib = pfn1 ]; then export PYTV4D_LIB=$VAR; else unset PYTV4D_LIB; fi
-    echo "== $lib (rep $rep)"; python3 tools/slab_placement_probe.py 256x8x1024x1024 4 slab+32,separate 2>&1 | grep -E "^slab|^separate" | cut -c1-200
+    echo "== $lib (rep $rep)"; python3 tools/archive/slab_placement_probe.py 256x8x1024x1024 4 slab+32,separate 2>&1 | grep -E "^slab|^separate" | cut -c1-200
   done
 done
 for rep in 1 2; do

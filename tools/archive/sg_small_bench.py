@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """TV + sub-gradient: the one-pass kernel against the two-pass forms on small and mid-size volumes.
-usage: python tools/sg_small_bench.py [NzxMxNyxNx ...]"""
+usage: python tools/archive/sg_small_bench.py [NzxMxNyxNx ...]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)

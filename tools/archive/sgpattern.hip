@@ -1,4 +1,4 @@
-// tools/sgpattern.hip -- round 4, verdict item 5: what does the MEMORY PATTERN of a z-marching, ring-overlapped tile kernel cost?
+// tools/archive/sgpattern.hip -- round 4, verdict item 5: what does the MEMORY PATTERN of a z-marching, ring-overlapped tile kernel cost?
 //
 // profiles/r3_subgrad_col_pattern.txt showed that k_subgrad_col (one-pass TV + sub-gradient) costs what its loads and stores cost: a
 // build without arithmetic takes the same 1.55 ms at 64x8x1024x1024, the same bytes in ring-less 4 x 256 tiles 1.03 ms.  This program
@@ -9,7 +9,7 @@
 // whose offsets the hardware range-checks (no branches), all M frames of a plane per step, a load ring D frames ahead, one block
 // (8 or 16 waves) per CU.
 //
-// build: hipcc -O3 --offload-arch=gfx950 -o tools/sgpattern tools/sgpattern.hip        run: tools/sgpattern [nz m ny nx] [config ...]
+// build: hipcc -O3 --offload-arch=gfx950 -o tools/sgpattern tools/archive/sgpattern.hip        run: tools/sgpattern [nz m ny nx] [config ...]
 // config = LR,LC,WX,NWY,NWX,ry,rx,halo,zc,ovl,ovh,grid,xcd[,nt[,rl[,dd,dl,hd,ustride,xoff[,rg]]]]   (grid > 0: balanced mode with that many blocks, zc ignored;
 // nt: the aux (cache policy) bits of the stores -- 1 sc0, 2 nt, 16 sc1 and their sums; rl: ring columns loaded per side, the remaining ring lanes idle -- an ALIGNED tile with a narrow ring)
 #include <hip/hip_runtime.h>

@@ -5,7 +5,7 @@ DISTANCE between its streams (fast at multiples of 4 GiB + 0 and + 4 .. 32 MiB, 
 Here: N constructions per layout in ONE process; each runs 2 + 6 iterations of the north-star problem (tuner off) and reports the mean
 sweep time of the two ping-pong directions.  Layouts: "separate" = five torch allocations (the solver's default), "slab+<gap MiB>" =
 one torch.empty for everything, arrays back to back with <gap> MiB between them.
-usage: python tools/slab_placement_probe.py [NzxMxNyxNx] [constructions] [layout,layout,...]   layout = separate | slab+<gap MiB>[q|m|a]"""
+usage: python tools/archive/slab_placement_probe.py [NzxMxNyxNx] [constructions] [layout,layout,...]   layout = separate | slab+<gap MiB>[q|m|a]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
