@@ -47,11 +47,13 @@ extern "C" {
 /* Version of the binary interface declared in this header: bumped whenever tv_geom, the workspace layout or the
  * meaning of an entry point's arguments changes incompatibly (round 1: 1; round 2 added the three weight-volume
  * pointers and a second partial-sum array in the workspace: 2; round 3 added the two leading fields below: 3;
- * round 4 added row_pitch / frame_pitch at the end: 4).
+ * round 4 added row_pitch / frame_pitch at the end: 4; round 5 grew the workspace to THREE partial-sum arrays
+ * (TV_CP_FID_BOTH, tv_cheb_step(dots = NULL)), gave tv_cp_sweep its flags and changed tv_cheb_step's NULL-dots contract -- stamped as 5
+ * in round 6, together with the persistent small-volume entry points tv_small_*).
  * Every entry point that takes a tv_geom rejects a struct whose struct_size / abi_version are not the library's own
  * with TV_E_ARG -- a host built against an older header fails loudly instead of having its trailing fields read as
  * garbage.  tv_geom_init() fills the two fields in. */
-#define TV_ABI_VERSION 4
+#define TV_ABI_VERSION 5
 
 typedef struct tv_geom {
     uint32_t struct_size;       /* sizeof(tv_geom) of the header the HOST was compiled against   */

@@ -142,7 +142,9 @@ int tv_cp_fused_supported(const tv_geom* g) {
     // (the last lane of a ragged row holds pad columns: zeros in, zeros out -- round 4)
     if ((!d.pitched && d.nx % d.vl != 0) || d.nx < 64 || !fused_m_ok(d.m)) return 0;
     if (d.m > CP_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
-    if (d.s_t * (16 / d.vl) > (1ll << 32)) return 0;                          // 32-bit per-lane byte offsets inside a frame
+    // frames below 2^31 bytes: per-lane byte offsets are 32-bit, the PFX prefetch addresses x0 / p through a per-frame buffer descriptor
+    // (num_records = frame bytes as a 32-bit number: 2^32 would wrap to 0) and BUF_OOB = 0x80000000 must lie outside the frame (round-5 advice)
+    if (d.s_t * (16 / d.vl) >= (1ll << 31)) return 0;
     if (env_int("TV_NO_FUSED", 0)) return 0;
     return 1;
 }

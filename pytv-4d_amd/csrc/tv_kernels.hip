@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void k_reduce(const double* in, long long n, d
 extern "C" {
 
 const char* tv_last_error(void) { return g_err.c_str(); }
-int tv_version(void) { return 400; }
+int tv_version(void) { return 500; }
 int tv_abi_version(void) { return TV_ABI_VERSION; }
 
 int tv_set_option(const char* name, int value) {

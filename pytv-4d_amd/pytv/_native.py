@@ -40,7 +40,7 @@ class TvGeom(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 4      # TV_ABI_VERSION of include/pytv4d.h this binding was written against
+ABI_VERSION = 5      # TV_ABI_VERSION of include/pytv4d.h this binding was written against
 
 
 def new_geom():

@@ -185,6 +185,7 @@ class _SlabProblem:
     # want run-to-run reproducible timing; the default stays separate allocations + the measuring tuner.
     ARENA_GAP_BYTES = 32 << 20
     _arena = None
+    _arena_closed = False
 
     def _image_elems(self):
         nz, m, ny, nx = self.x0.shape
@@ -199,22 +200,28 @@ class _SlabProblem:
         if not enable or self.device.type != "cuda":
             return False
         gap = self.ARENA_GAP_BYTES // es
-        total = n_images * (img + gap) + n_grads * (img * self.geo.nd + gap)
+        al = 256 // es                            # every carve starts on a 256-byte boundary (round-5 advice: the C entry points want 16)
+        rnd = lambda n: -(-n // al) * al
+        total = n_images * (rnd(img) + gap) + n_grads * (rnd(img * self.geo.nd) + gap)
         try:
             self._arena = torch.empty(total, dtype=self.dtype, device=self.device)
         except RuntimeError:                      # no single block of that size: separate allocations (and the placement tuner)
             self._arena = None
             torch.cuda.empty_cache()
             return False
-        self._arena_off, self._arena_gap = 0, gap
+        self._arena_off, self._arena_gap, self._arena_align, self._arena_closed = 0, gap, al, False
         return True
+
+    def _arena_close(self):
+        """the state is carved: later new_image() / new_grad() calls allocate on their own"""
+        self._arena_closed = True
 
     def _arena_take(self, elems):
         a = self._arena
-        if a is None or self._arena_off + elems > a.numel():
+        if a is None or self._arena_closed or self._arena_off + elems > a.numel():
             return None
         v = a[self._arena_off:self._arena_off + elems]
-        self._arena_off += elems + self._arena_gap
+        self._arena_off += -(-elems // self._arena_align) * self._arena_align + self._arena_gap
         return v
 
     def new_image(self, zero=True):
@@ -377,6 +384,8 @@ class ChambollePock(_SlabProblem):
             self.x0 = self.image_copy(self._x0_src)
         self.q = self.new_grad()
         self.q_alt = self.new_grad() if (self.fused and self._q_pingpong) else None
+        if self.arena:
+            self._arena_close()
 
     def _tune_arena(self, reps=2):
         """Two arenas, measured with the real sweep, the faster one kept (round 5).  WHERE one big allocation lands decides the level
@@ -1251,7 +1260,8 @@ class ADMM(_SlabProblem):
         self.timing = None      # set to a list to collect one list of (name, HIP event) per outer iteration (bench.py --solver admm)
         self._marks = None
         self.placement = None
-        set_bytes = sum(getattr(self, k).numel() for k in self._STATE) * self.x.element_size()
+        # (u_alt is a candidate of the tuner too: count it, or `free >= set_bytes + 8 GiB` under-estimates by Nd words -- round-5 advice)
+        set_bytes = (sum(getattr(self, k).numel() for k in self._STATE) + (self.u_alt.numel() if self.u_alt is not None else 0)) * self.x.element_size()
         if tune_placement is None:
             free, _total = torch.cuda.mem_get_info(self.device) if self.device.type == "cuda" else (0, 0)
             tune_placement = (not self.slab.sharded) and set_bytes >= (16 << 30) and free >= set_bytes + (8 << 30)
@@ -1359,7 +1369,9 @@ class ADMM(_SlabProblem):
     @property
     def z(self):
         """The split variable z (single_reduction keeps t = z - u: z = t + u; the one-sweep path keeps t' = t - D x and recomputes
-        D x -- on a sharded slab that is a halo exchange, so every rank has to ask for z, not just one)."""
+        D x -- on a sharded slab that is a halo exchange, so every rank has to ask for z, not just one).
+        MEMORY: on the one-sweep path each access allocates two transient gradient-sized arrays (2 Nd words per voxel: z itself and a
+        scratch copy of the dual variable) -- 32 GiB at the config4 hybrid slab; they are released when the caller drops z."""
         if self.fused and self._have_r:
             if not self.keep_z:
                 raise RuntimeError("ADMM(..., keep_z=False) stores only the samples of z - u - D x its fix-up reads: z is not available; "

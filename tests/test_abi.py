@@ -43,7 +43,7 @@ def test_struct_layout_matches_header():
     # 2 x uint32 (struct_size, abi_version) + 6 x int64 + 2 x int32 + 3 x double + 5 pointers + 2 x int64 (row_pitch, frame_pitch:
     # interface version 4), no padding surprises
     assert ctypes.sizeof(nv.TvGeom) == 8 + 6 * 8 + 2 * 4 + 3 * 8 + 8 + 8 + 3 * 8 + 2 * 8
-    assert nv.TvGeom.row_pitch.offset == 128 and nv.TvGeom.frame_pitch.offset == 136 and nv.ABI_VERSION == 4
+    assert nv.TvGeom.row_pitch.offset == 128 and nv.TvGeom.frame_pitch.offset == 136 and nv.ABI_VERSION == 5
     assert nv.TvGeom.struct_size.offset == 0 and nv.TvGeom.abi_version.offset == 4 and nv.TvGeom.nz.offset == 8
     assert nv.TvGeom.scheme.offset == 56 and nv.TvGeom.reg_z_over_reg.offset == 64 and nv.TvGeom.mask_static.offset == 88 and nv.TvGeom.time_factor.offset == 96 and nv.TvGeom.time_weight_vol.offset == 104 and nv.TvGeom.time_weight_next.offset == 120
 
@@ -180,3 +180,18 @@ def test_auto_pitch_rule():
     assert auto_pitch(1000, 1000, f64) == (1008, 1000 * 1008)                                   # 8000-byte rows -> 8064 (128-byte multiple)
     rp, fp = auto_pitch(16, 128, f32, frame_pad_bytes=4352)                                     # experiments: a frame pad on dense rows
     assert rp == 128 and fp == 16 * 128 + 1088
+
+
+def test_one_sweep_path_refuses_frames_of_two_gib_and_more():
+    """round-5 advice: the one-sweep kernel addresses x0 / p of the lagged primal update through a per-frame buffer descriptor whose
+    size is the frame's byte count as a 32-bit number, and marks absent lanes with the offset 0x80000000: frames must stay below 2^31
+    bytes.  tv_cp_fused_supported is a host-side predicate (no device call)."""
+    from pytv import _native as nv
+    lib = nv.lib()
+    for dtype, nx_lim in ((0, 32768), (1, 16384)):          # ny = 16384 rows: 2^31 bytes per frame at this Nx
+        for nx, want in ((nx_lim, 0), (2 * nx_lim, 0), (nx_lim - 64, 1), (1024, 1)):
+            g = nv.new_geom()
+            g.nz, g.m, g.ny, g.nx, g.nz_global, g.z0 = 2, 2, 16384, nx, 2, 0
+            g.scheme, g.dtype = nv.SCHEMES["hybrid"], dtype
+            g.reg_z_over_reg, g.reg_time = 1.0, 1.0
+            assert lib.tv_cp_fused_supported(ctypes.byref(g)) == want, (dtype, nx)
