@@ -328,6 +328,31 @@ int tv_dot(const tv_geom* g, const void* a, const void* b, double* result, void*
 int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, double step, double lambda,
                     double* fid, void* ws, void* stream);
 
+/* ---- persistent small-volume loops (round 6, interface version 5) ------------------------------------------------------------------
+ * The reference's user loops (README.md:107-124 sub-gradient descent, :141-157 Chambolle-Pock) on volumes that fit the caches
+ * (its own shapes: README.md:76-79 rand(20,4,100,100), 256 x 256 / 512 x 512 images, pytv/tests.py:48 N = 100): n_iter iterations in
+ * ONE cooperative launch -- every block keeps its sites for the whole loop and waits only for the blocks that own neighbouring sites
+ * between the two phases of an iteration; arrays that neighbours read are accessed agent-coherently (csrc/tv_small.hip).
+ * Unsharded volumes only (g->nz == g->nz_global, no halos); any scheme, fp32 / fp64, any nx (16-byte lanes when nx and the pointers
+ * allow), pitched arrays, weight maps / volumes.  The stream must not run other kernels of the caller concurrently with these
+ * launches in a way that could starve them of compute units (the blocks of a launch wait for each other).
+ *   tv_small_supported       : 1 if the geometry fits (<= TV_SMALL_MAX_KVOXELS thousand voxels, default 4096; arrays below 2^31 bytes)
+ *   tv_small_workspace_bytes : bytes of the scratch buffer `ws` for n_iter iterations per launch (block flags + per-block partials)
+ *   tv_small_cp              : n_iter iterations of  p <- (p + sigma_A (x - x0)) / (1 + sigma_A);  q <- proj(q + sigma_D D x);
+ *                              x <- x - tau p - tau D^T q  exactly as tv_cp_dual + tv_cp_primal compute them, x / p / q updated in
+ *                              place; hist (device fp64, 2 * n_iter words): hist[2 k] = |D x_k|_{2,1} (the iterate the dual update of
+ *                              iteration k saw), hist[2 k + 1] = 1/2 |x_{k+1} - x0|^2
+ *   tv_small_subgrad_descent : n_iter iterations of  x <- x - step ((x - x0) + lambda G(x))  (tv_subgrad + tv_subgrad_step's
+ *                              arithmetic); the iterate is ping-ponged between x and x_alt: after an ODD n_iter the result is in
+ *                              x_alt, after an even one in x; norms_ext: (nz + 2) planes of scratch (1 / |D x|);
+ *                              hist[2 k] = TV(x_k), hist[2 k + 1] = 1/2 |x_{k+1} - x0|^2 */
+int    tv_small_supported(const tv_geom* g);
+size_t tv_small_workspace_bytes(const tv_geom* g, int64_t n_iter);
+int    tv_small_cp(const tv_geom* g, void* x, const void* x0, void* p, void* q, double sigma_D, double lambda, double tau,
+                   double sigma_A, int64_t n_iter, double* hist, void* ws, void* stream);
+int    tv_small_subgrad_descent(const tv_geom* g, void* x, void* x_alt, const void* x0, void* norms_ext, double step, double lambda,
+                                int64_t n_iter, double* hist, void* ws, void* stream);
+
 /* ---- multi-GPU: z-slab neighbours over RCCL, one process per GPU ------------------------------ */
 /* The reference is single-GPU (its README only remarks that the (Nz, M, N, N) layout "can be decomposed easily along z",
  * README.md:235).  Rank r holds the planes [z0, z0 + nz) (tv_geom::z0 / nz_global) and, per operator apply, trades the

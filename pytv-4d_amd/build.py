@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # The product library: ONE generation of the one-pass sub-gradient kernel (tv_subgrad2.h).  The kernels that lost their A/B -- the
 # round-1 kernel k_subgrad_one and the round-4 pair tile k_subgrad_pair -- were deleted in round 6 (git history: csrc/variants/).
-UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip", "tv_fused.hip", "tv_fused_f64.hip", "tv_fused_admm.hip", "tv_fused_admm_f64.hip", "tv_fused_cpop.hip", "tv_fused_cpop_f64.hip", "tv_subgrad.hip", "tv_subgrad_norms.hip", "tv_sgstep.hip", "tv_dstream.hip", "tv_comm.hip", "tv_nstream.hip"]
-HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h", "tv_fused.h", "tv_fused_launch.h", "tv_subgrad2.h", "tv_subgrad_host.h", "tv_dstream.h", "tv_nstream.h"]
+UNITS = ["tv_kernels.hip", "tv_march_D.hip", "tv_march_DT.hip", "tv_fused.hip", "tv_fused_f64.hip", "tv_fused_admm.hip", "tv_fused_admm_f64.hip", "tv_fused_cpop.hip", "tv_fused_cpop_f64.hip", "tv_subgrad.hip", "tv_subgrad_norms.hip", "tv_sgstep.hip", "tv_dstream.hip", "tv_comm.hip", "tv_nstream.hip", "tv_small.hip"]
+HEADERS = ["tv_device.h", "tv_stencil.h", "tv_host.h", "tv_march.h", "tv_fused.h", "tv_fused_launch.h", "tv_subgrad2.h", "tv_subgrad_host.h", "tv_dstream.h", "tv_nstream.h", "tv_site.h"]
 DEPS = [os.path.join(CSRC, f) for f in UNITS + HEADERS] + [os.path.join(os.path.dirname(HERE), "include", "pytv4d.h")]
 # TV_VARIANT=<name> (with TV_EXTRA_FLAGS): an experimental build next to the product library, loaded with PYTV4D_LIB=<path>
 _VAR = os.environ.get("TV_VARIANT", "")

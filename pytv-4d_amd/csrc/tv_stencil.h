@@ -25,42 +25,92 @@ template <typename T, int V> struct XN {
     int col0;
 };
 
-template <typename T, int V, bool NEXT, bool PREV>
+// How a kernel reaches an array.  PlainMem: ordinary loads / stores (every kernel whose inputs were complete before it started).
+// CohMem (tv_small.hip, the persistent small-volume kernels): the array is written by OTHER blocks of the SAME launch -- blocks that may sit
+// on another XCD with its own L2 -- so every access is an agent-coherent (sc1) raw-buffer access relative to the array's base
+// (profiles/r6_coherence_probe.txt: sc1 store + sc1 load is never stale, plain loads are; repeated sc1 loads of a line hit the L2).
+struct PlainMem {
+    template <typename T, int V> __device__ __forceinline__ Vec<T, V> ld(const T* p) const { return vload<T, V>(p); }
+    template <typename T> __device__ __forceinline__ T ld1(const T* p) const { return *p; }
+    template <typename T, int V> __device__ __forceinline__ void st(T* p, const Vec<T, V>& v) const { vstore<T, V>(p, v); }
+};
+struct CohMem {
+    __amdgpu_buffer_rsrc_t r;
+    const char* base;
+    static constexpr int AUX = 16;                   // sc1 on gfx942 / gfx950
+    template <typename T> __device__ __forceinline__ static CohMem make(const T* b, long long nbytes) {
+        CohMem m;
+        m.r = __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, (int)(nbytes > 0x7fffffffll ? 0x7fffffffll : nbytes), 0x00020000);
+        m.base = reinterpret_cast<const char*>(b);
+        return m;
+    }
+    template <typename T> __device__ __forceinline__ int off(const T* p) const { return (int)(reinterpret_cast<const char*>(p) - base); }
+    template <typename T> __device__ __forceinline__ T ld1(const T* p) const {
+        if constexpr (sizeof(T) == 4) {
+            return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, off(p), 0, AUX));
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, off(p), 0, AUX));
+        }
+    }
+    template <typename T, int V> __device__ __forceinline__ Vec<T, V> ld(const T* p) const {
+        if constexpr (V == 1) {
+            Vec<T, V> o; o.v[0] = ld1<T>(p); return o;
+        } else {
+            static_assert(sizeof(Vec<T, V>) == 16, "16-byte lanes");
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            return __builtin_bit_cast(Vec<T, V>, __builtin_amdgcn_raw_buffer_load_b128(r, off(p), 0, AUX));
+        }
+    }
+    template <typename T, int V> __device__ __forceinline__ void st(T* p, const Vec<T, V>& v) const {
+        if constexpr (V == 1 && sizeof(T) == 4) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v.v[0]), r, off(p), 0, AUX);
+        } else if constexpr (V == 1) {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, v.v[0]), r, off(p), 0, AUX);
+        } else {
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v), r, off(p), 0, AUX);
+        }
+    }
+};
+
+template <typename T, int V, bool NEXT, bool PREV, typename MP = PlainMem>
 __device__ __forceinline__ void load_xn(const DG& g, const T* plane_c, const T* plane_p, const T* plane_n,
-                                        const Coord& c, XN<T, V>& o) {
+                                        const Coord& c, XN<T, V>& o, const MP& mp = MP()) {
     const long long off = (long long)c.t * g.s_t + (long long)c.y * g.rp + c.col0;
     const T* p = plane_c + off;
-    o.c = vload<T, V>(p);
+    o.c = mp.template ld<T, V>(p);
     o.col0 = c.col0;
     const Vec<T, V> zero = vsplat<T, V>(T(0));
     o.nr = o.pr = o.nc = o.pc = o.nz = o.pz = o.nt = o.pt = zero;
     o.h_nr = o.h_pr = o.h_nz = o.h_pz = o.h_nt = o.h_pt = false;
     if (NEXT) {
         o.h_nr = (c.y + 1 < g.ny);
-        if (o.h_nr) o.nr = vload<T, V>(p + g.rp);
-        const T tail = (c.col0 + V < g.nx) ? p[V] : T(0);
+        if (o.h_nr) o.nr = mp.template ld<T, V>(p + g.rp);
+        const T tail = (c.col0 + V < g.nx) ? mp.template ld1<T>(p + V) : T(0);
         o.nc = shift_left<T, V>(o.c, tail);
         if (g.za) {
             o.h_nz = (plane_n != nullptr);
-            if (o.h_nz) o.nz = vload<T, V>(plane_n + off);
+            if (o.h_nz) o.nz = mp.template ld<T, V>(plane_n + off);
         }
         if (g.ta) {
             o.h_nt = (c.t + 1 < g.m);
-            if (o.h_nt) o.nt = vload<T, V>(p + g.s_t);
+            if (o.h_nt) o.nt = mp.template ld<T, V>(p + g.s_t);
         }
     }
     if (PREV) {
         o.h_pr = (c.y > 0);
-        if (o.h_pr) o.pr = vload<T, V>(p - g.rp);
-        const T head = (c.col0 > 0) ? p[-1] : T(0);
+        if (o.h_pr) o.pr = mp.template ld<T, V>(p - g.rp);
+        const T head = (c.col0 > 0) ? mp.template ld1<T>(p - 1) : T(0);
         o.pc = shift_right<T, V>(o.c, head);
         if (g.za) {
             o.h_pz = (plane_p != nullptr);
-            if (o.h_pz) o.pz = vload<T, V>(plane_p + off);
+            if (o.h_pz) o.pz = mp.template ld<T, V>(plane_p + off);
         }
         if (g.ta) {
             o.h_pt = (c.t > 0);
-            if (o.h_pt) o.pt = vload<T, V>(p - g.s_t);
+            if (o.h_pt) o.pt = mp.template ld<T, V>(p - g.s_t);
         }
     }
 }

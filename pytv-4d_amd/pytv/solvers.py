@@ -143,6 +143,28 @@ class _SlabProblem:
         self.geo = geo if geo is not None else self.geom(0, nz)
         self._geoms[(0, nz)] = self.geo
 
+    # ---- persistent small-volume loops (round 6; csrc/tv_small.hip) ------------------------------------------------------------------
+    SMALL_MAX_VOXELS = 2 << 20      # the automatic rule: volumes of at most 2 Mvoxel (the reference's own shapes hold 0.07 - 1) take it
+    SMALL_BLOCK = 64                # iterations per cooperative launch
+
+    def _small_ok(self, persistent):
+        """persistent: None = automatic (unsharded, <= SMALL_MAX_VOXELS, geometry supported), True = required, False = off"""
+        if persistent is False:
+            return False
+        ok = (not self.slab.sharded) and bool(self.lib.tv_small_supported(self.geo.ref))
+        if persistent is True:
+            if not ok:
+                raise ValueError("persistent=True: the persistent small-volume kernels take unsharded volumes that tv_small_supported accepts")
+            return True
+        return ok and self.x0.numel() <= self.SMALL_MAX_VOXELS
+
+    def _small_ws(self):
+        if getattr(self, "_small_ws_buf", None) is None:
+            nbytes = self.lib.tv_small_workspace_bytes(self.geo.ref, self.SMALL_BLOCK)
+            self._small_ws_buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
+            self._small_hist = torch.zeros((self.SMALL_BLOCK, 2), dtype=torch.float64, device=self.device)
+        return self._small_ws_buf
+
     def geom(self, a, b):
         """Geometry of local planes [a, b) seen as a slab of the global volume."""
         key = (a, b)
@@ -278,8 +300,10 @@ class ChambollePock(_SlabProblem):
 
     def __init__(self, x0, regularization, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0, mask_static=False,
                  factor_reg_static=0, sigma_D=0.5, sigma_A=1.0, tau=None, slab=None, overlap=True, fused=None, pitch="auto",
-                 q_pingpong=False, tune_placement=None, arena=None):
-        """fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
+                 q_pingpong=False, tune_placement=None, arena=None, persistent=None):
+        """persistent (round 6): None = volumes of at most ``SMALL_MAX_VOXELS`` on one GPU run ``run`` / ``run_steps`` as ONE launch per
+        ``SMALL_BLOCK`` iterations (tv_small_cp: the kernel pair's arithmetic inside a persistent kernel); False = never; True = required.
+        fused: None = use the one-sweep kernel (tv_cp_fused + tv_cp_fixup: q read and written once per
         iteration) whenever the geometry supports it, False = always the dual + primal kernel pair.
         pitch: see ``_SlabProblem`` ("auto", the default: padded rows where that pays; None / "dense"; (row_pitch, frame_pitch)).
         q_pingpong (one-sweep path; default off): read the dual variable from one array and write it to a second one, swapping them
@@ -307,6 +331,7 @@ class ChambollePock(_SlabProblem):
             min_vox = 1024 * _nv.get_option("TV_FUSED_MIN_KVOXELS", 16384)
             fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) and self.x0.numel() >= min_vox
         self.fused = bool(fused)
+        self.small = (not self.fused) and self._small_ok(persistent)
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
             raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry (tv_cp_fused_supported: "
                              "fp32, Nx % 4 == 0, Nx >= 64, Ny * Nx <= 2^30; any number of frames)")
@@ -762,6 +787,8 @@ class ChambollePock(_SlabProblem):
         small enough to be launch-bound and not sharded; True / False force it."""
         hist = torch.zeros((n_iter, self.SLOTS), dtype=torch.float64, device=self.device)
         use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS and not self.slab.sharded and self.timing is None and self.phase_timing is None) if graph is None else bool(graph)
+        if self._small_now() and graph is None:
+            use_graph = False                     # the persistent kernel IS the loop: nothing left to capture
         start = 0
         if use_graph and n_iter >= 2 + 2 * self.GRAPH_BLOCK and not self.slab.sharded:
             # two eager iterations (also the warm-up of the capture), then graph replays, then an eager tail
@@ -784,6 +811,8 @@ class ChambollePock(_SlabProblem):
         n = rows.shape[0]
         if n == 0:
             return
+        if self._small_now():
+            return self._run_small(rows)
         if not self.fused:
             for k in range(n):
                 self.step(rows[k])
@@ -796,6 +825,25 @@ class ChambollePock(_SlabProblem):
         finally:
             self._lag = None
             self._final = False
+
+    def _small_now(self):
+        """the persistent path runs the loop unless somebody asked for per-step events (bench.py: ``timing`` / ``phase_timing``)"""
+        return self.small and self.timing is None and self.phase_timing is None
+
+    def _run_small(self, rows):
+        """``len(rows)`` iterations in blocks of ``SMALL_BLOCK`` per cooperative launch (tv_small_cp): x, p, q updated in place; TV of the
+        iterate each dual update saw -> slot 0, 1/2 |x_new - x0|^2 -> slot F (the slots the kernel pair fills)."""
+        ws = self._small_ws()
+        n, done = rows.shape[0], 0
+        while done < n:
+            k = min(self.SMALL_BLOCK, n - done)
+            h2 = self._small_hist[:k]
+            _nv.check(self.lib.tv_small_cp(self.geo.ref, _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(self.p), _nv.ptr(self.q), self.sigma_D, self.reg,
+                                           self.tau, self.sigma_A, k, h2.data_ptr(), _nv.ptr(ws), self.stream))
+            rows[done:done + k, 0] = h2[:, 0]
+            rows[done:done + k, self.F] = h2[:, 1]
+            done += k
+            self.it += k
 
     def _run_graphed_from(self, hist, first, n_iter):
         """Capture GRAPH_BLOCK iterations (not executed during capture) and replay them over hist[first:]."""
@@ -969,10 +1017,14 @@ class SubgradientDescent(_SlabProblem):
         return h[:, 3:6].sum(axis=1) + regularization * h[:, 0:3].sum(axis=1)
 
     def __init__(self, x0, regularization, step_size, scheme="hybrid", reg_z_over_reg=1.0, reg_time=0.0,
-                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True, pitch="auto", tune_placement=None):
-        """tune_placement: None = on for one-pass problems (slabs) of >= 4 GiB per image with memory to spare (``_tune_placement``)."""
+                 mask_static=False, factor_reg_static=0, slab=None, one_pass=None, overlap=True, pitch="auto", tune_placement=None,
+                 persistent=None):
+        """tune_placement: None = on for one-pass problems (slabs) of >= 4 GiB per image with memory to spare (``_tune_placement``).
+        persistent (round 6): None = volumes of at most ``SMALL_MAX_VOXELS`` on one GPU run ``run`` as ONE launch per ``SMALL_BLOCK``
+        iterations (tv_small_subgrad_descent: tv_subgrad + tv_subgrad_step's arithmetic inside a persistent kernel); False / True."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.step_size = float(regularization), float(step_size)
+        self.small = self._small_ok(persistent)
         self.x = self.image_copy(self.x0)
         nz, m, ny, nx = self.x0.shape
         self.G = self.new_image()
@@ -985,10 +1037,12 @@ class SubgradientDescent(_SlabProblem):
         self.one_pass = bool(one_pass)
         # one pass: TV, G and the descent step in a single kernel, x ping-ponged (G is never stored); else the
         # two-pass tv_subgrad + tv_subgrad_step
-        self.norms_ext = None if self.one_pass else self.geo.new_image(nz + 2)
+        self.norms_ext = None if (self.one_pass and not self.small) else self.geo.new_image(nz + 2)
         if self.one_pass:
             self.x_alt = self.G
             self.G = None
+        elif self.small:
+            self.x_alt = self.new_image()           # the persistent loop ping-pongs the iterate
         self.ws = self.geo.workspace()
         self.plan = HaloPlan(self.slab, scheme, self.geo.z_active)
         sh = self.plan.on
@@ -1121,6 +1175,9 @@ class SubgradientDescent(_SlabProblem):
         GRAPH_BLOCK iterations from a hipGraph when the problem is small enough to be launch-bound and not sharded
         (the README's own 2-D example is), True / False force it."""
         hist = torch.zeros((n_iter, self.SLOTS), dtype=torch.float64, device=self.device)
+        if self.small and graph is None:
+            self._run_small(hist)
+            return self.loss_from_slots(hist.cpu().numpy(), self.reg)
         use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS) if graph is None else bool(graph)
         start = 0
         if use_graph and not self.slab.sharded and n_iter >= 2 + 2 * self.GRAPH_BLOCK:
@@ -1131,6 +1188,22 @@ class SubgradientDescent(_SlabProblem):
             self.step(hist[it])
         self.slab.allreduce_sum_(hist)
         return self.loss_from_slots(hist.cpu().numpy(), self.reg)
+
+    def _run_small(self, rows):
+        """``len(rows)`` descent steps in blocks of ``SMALL_BLOCK`` per cooperative launch (tv_small_subgrad_descent); TV(x_k) -> slot 0,
+        1/2 |x_{k+1} - x0|^2 -> slot 3.  The iterate is ping-ponged: after an odd block x and x_alt trade places."""
+        ws = self._small_ws()
+        n, done = rows.shape[0], 0
+        while done < n:
+            k = min(self.SMALL_BLOCK, n - done)
+            h2 = self._small_hist[:k]
+            _nv.check(self.lib.tv_small_subgrad_descent(self.geo.ref, _nv.ptr(self.x), _nv.ptr(self.x_alt), _nv.ptr(self.x0), _nv.ptr(self.norms_ext),
+                                                        self.step_size, self.reg, k, h2.data_ptr(), _nv.ptr(ws), self.stream))
+            if k & 1:
+                self.x, self.x_alt = self.x_alt, self.x
+            rows[done:done + k, 0] = h2[:, 0]
+            rows[done:done + k, 3] = h2[:, 1]
+            done += k
 
     def _run_graphed_from(self, hist, first, n_iter):
         """Capture GRAPH_BLOCK iterations (not executed during capture) and replay them over hist[first:]."""
