@@ -510,6 +510,102 @@ template <typename T> struct SmallSgArgs {
     long long x_bytes, n_bytes;
 };
 
+// register-resident descent step (upwind, downwind, hybrid: radius-1 stencils; central takes the generic kernel): x and x0 of the site stay
+// in registers; pass 1 loads the eight neighbours of x at once and stores 1 / |D x|; pass 2 loads the eight neighbours of 1 / |D x| at once
+// (the neighbours of x are still in registers), forms G with subgrad_site and stores the new x into the OTHER image buffer for the
+// neighbours (ping-pong: the blocks around me may still be reading the old one).
+template <int S, typename T, int V>
+__global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, SmallPlan sp, SmallSgArgs<T> a) {
+    static_assert(S != CENTRAL, "radius-2 stencil: generic kernel");
+    __shared__ double sm[16];
+    const int L = small_logical_id(sp);
+    if (L >= sp.nblocks) return;
+    constexpr unsigned EB = sizeof(T);
+    const int nxv = (g.nx + V - 1) / V;
+    const int dep = small_dependency_flat(g, sp, L, nxv, (int)threadIdx.x);
+    const FlatId fid = small_flat_id(g, L);
+    const int t = fid.t, zl = fid.zl;
+    const int sidx = fid.tile * (int)blockDim.x + (int)threadIdx.x;
+    const bool ok = sidx < g.ny * nxv;
+    const int y = ok ? sidx / nxv : 0, col0 = ok ? (sidx % nxv) * V : 0;
+    const long long offx = (long long)zl * g.s_z + (long long)t * g.s_t + (long long)y * g.rp + col0;
+    const CohMem mxa = CohMem::make((const T*)a.xa, a.x_bytes), mxb = CohMem::make((const T*)a.xb, a.x_bytes);
+    const CohMem mn = CohMem::make((const T*)a.norms_ext + g.s_z, a.n_bytes - g.s_z * (long long)EB);       // (local plane 0 of the extended array)
+    const Vec<T, V> zero = vsplat<T, V>(T(0));
+    XN<T, V> n, ns;
+    n.col0 = ns.col0 = col0;
+    n.h_nr = ok && (y + 1 < g.ny);
+    n.h_pr = ok && (y > 0);
+    n.h_nz = ok && g.za && (zl + 1 < g.nz);
+    n.h_pz = ok && g.za && (zl > 0);
+    n.h_nt = ok && g.ta && (t + 1 < g.m);
+    n.h_pt = ok && g.ta && (t > 0);
+    const bool has_tail = ok && (col0 + V < g.nx), has_head = ok && (col0 > 0);
+    const unsigned b0 = (unsigned)(offx * EB);
+    const int d_row = g.rp * (int)EB, d_frame = (int)(g.s_t * EB), d_plane = (int)(g.s_z * EB);
+    auto at = [&](bool valid, unsigned base, int delta) -> unsigned { return valid ? base + (unsigned)delta : kOOB; };
+    Vec<T, V> x = ok ? vload<T, V>(a.xa + offx) : zero;
+    const Vec<T, V> x0 = ok ? vload<T, V>(a.x0 + offx) : zero;
+    const Vec<T, V> mf = (ok && g.ta) ? mask_factor<T, V>(g, w.sf, y, col0) : vsplat<T, V>(T(1));
+    constexpr bool NEXT = true, PREV = true;          // the gather of pass 2 reads both sides whatever the scheme (sg_site)
+    for (int it = 0; it < a.n_iter; ++it) {
+        const CohMem& mxc = (it & 1) ? mxb : mxa;
+        const CohMem& mxo = (it & 1) ? mxa : mxb;
+        unsigned b = b0;
+        asm volatile("" : "+v"(b));
+        // ---- pass 1: 1 / |D x|, TV(x) (pytv/tv_GPU.py:84-88)
+        n.c = x;
+        n.nr = coh_ldv<T, V>(mxc, at(NEXT && n.h_nr, b, d_row)); n.pr = coh_ldv<T, V>(mxc, at(PREV && n.h_pr, b, -d_row));
+        n.nz = coh_ldv<T, V>(mxc, at(NEXT && n.h_nz, b, d_plane)); n.pz = coh_ldv<T, V>(mxc, at(PREV && n.h_pz, b, -d_plane));
+        n.nt = coh_ldv<T, V>(mxc, at(NEXT && n.h_nt, b, d_frame)); n.pt = coh_ldv<T, V>(mxc, at(PREV && n.h_pt, b, -d_frame));
+        const T x_tail = coh_ld1<T>(mxc, at(has_tail, b, V * (int)EB)), x_head = coh_ld1<T>(mxc, at(has_head, b, -(int)EB));
+        n.nc = shift_left<T, V>(x, x_tail);
+        n.pc = shift_right<T, V>(x, x_head);
+        double acc = 0.0;
+        Vec<T, V> nv;
+        {
+            Vec<T, V> o[8];
+            d_slots<S, T, V>(g, w, n, mf, o);
+            const Vec<T, V> ssq = sumsq_slots<T, V>(o);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const T r = tsqrt(ssq.v[i]);
+                acc += (double)r;
+                nv.v[i] = (ssq.v[i] >= tiny_sumsq<T>()) ? T(1) / r : T(0);
+            }
+            if (!ok) acc = 0.0;
+        }
+        coh_stv<T, V>(mn, at(ok, b, 0), nv);
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
+        small_sync(a.flags, L, dep, (unsigned)(2 * it + 1));
+        // ---- pass 2: G from x and 1 / |D x| (pytv/tv_GPU.py:91-124), x <- x - step ((x - x0) + lambda G) (README.md:122-123)
+        asm volatile("" : "+v"(b));
+        ns.c = nv;
+        ns.nr = coh_ldv<T, V>(mn, at(n.h_nr, b, d_row)); ns.pr = coh_ldv<T, V>(mn, at(n.h_pr, b, -d_row));
+        ns.nz = coh_ldv<T, V>(mn, at(n.h_nz, b, d_plane)); ns.pz = coh_ldv<T, V>(mn, at(n.h_pz, b, -d_plane));
+        ns.nt = coh_ldv<T, V>(mn, at(n.h_nt, b, d_frame)); ns.pt = coh_ldv<T, V>(mn, at(n.h_pt, b, -d_frame));
+        const T n_tail = coh_ld1<T>(mn, at(has_tail, b, V * (int)EB)), n_head = coh_ld1<T>(mn, at(has_head, b, -(int)EB));
+        ns.nc = shift_left<T, V>(nv, n_tail);
+        ns.pc = shift_right<T, V>(nv, n_head);
+        Vec<T, V> G = subgrad_site<S, T, V>(g, w, n, ns, mf);
+        zero_pad_cols<T, V>(g, col0, G);
+        acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            x.v[i] = x.v[i] - a.step * ((x.v[i] - x0.v[i]) + a.lambda * G.v[i]);
+            const double e = (double)x.v[i] - (double)x0.v[i];
+            acc += 0.5 * e * e;
+        }
+        zero_pad_cols<T, V>(g, col0, x);
+        if (!ok) acc = 0.0;
+        coh_stv<T, V>(mxo, at(ok, b, 0), x);
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
+        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, (unsigned)(2 * it + 2));
+    }
+}
+
 template <int S, typename T, int V>
 __global__ __launch_bounds__(kSmallThreads) void k_small_sg(DG g, WT<T> w, SmallPlan sp, SmallSgArgs<T> a) {
     __shared__ double sm[16];
@@ -723,10 +819,21 @@ int tv_small_subgrad_descent(const tv_geom* g, void* x, void* x_alt, const void*
     const bool vec = rows_vectorisable(g, d) && aligned16({x, x_alt, x0, norms_ext, d.wv});
     hipStream_t st = (hipStream_t)stream;
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
-        const void* kern = (const void*)k_small_sg<S, T, V>;
-        const int cap = small_capacity(kern);
-        if (cap < 8) return fail(TV_E_ARG, "tv_small_subgrad_descent: no HIP device / occupancy query failed");
-        SmallPlan sp = small_plan(d, V, cap);
+        const void* kern = nullptr;
+        SmallPlan sp;
+        int threads = kSmallThreads;
+        bool flat = false;
+        if constexpr (S != CENTRAL) {
+            kern = (const void*)k_small_sg_reg<S, T, V>;
+            flat = small_plan_flat(d, V, kern, sp, threads);
+        }
+        if (!flat) {
+            kern = (const void*)k_small_sg<S, T, V>;
+            threads = kSmallThreads;
+            const int cap = small_capacity(kern);
+            if (cap < 8) return fail(TV_E_ARG, "tv_small_subgrad_descent: no HIP device / occupancy query failed");
+            sp = small_plan(d, V, cap);
+        }
         if (sp.grid > kMaxSmallBlocks) return fail(TV_E_ARG, "internal: more blocks than the workspace holds");
         unsigned* flags = (unsigned*)ws;
         double* partials = (double*)((char*)ws + (size_t)kMaxSmallBlocks * kFlagStride * sizeof(unsigned));
@@ -736,7 +843,7 @@ int tv_small_subgrad_descent(const tv_geom* g, void* x, void* x_alt, const void*
         SmallSgArgs<T> a{(T*)x, (T*)x_alt, (const T*)x0, (T*)norms_ext, (T)step, (T)lambda, (int)n_iter, flags, partials,
                          d.s_z * d.nz * (long long)sizeof(T), d.s_z * (d.nz + 2) * (long long)sizeof(T)};
         void* args[] = {&dd, &w, &sp, &a};
-        HIP_TRY(hipLaunchCooperativeKernel(kern, dim3((unsigned)sp.grid), dim3(kSmallThreads), args, 0, st));
+        HIP_TRY(hipLaunchCooperativeKernel(kern, dim3((unsigned)sp.grid), dim3((unsigned)threads), args, 0, st));
         hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)(2 * n_iter)), dim3(256), 0, st, (const double*)partials, sp.nblocks, hist);
         HIP_TRY(hipGetLastError());
         return 0;

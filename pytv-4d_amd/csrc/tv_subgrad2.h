@@ -431,7 +431,19 @@ struct SgCol {
         const T* pc_c = zplane<T>(g, x, xp, xn, 2, z_lo);
         const T* pn_c = next_plane(z_lo);
 
+#ifdef TV_SG2_TIMELINE
+        // variant builds only (tools/sg_timeline.py): lane 0 of every wave of the first 256 blocks records the shader clock at the top of
+        // every plane step, before the LDS barrier that ends it and after that barrier -- behind the THIRD partial array of the workspace
+        // (unused by this kernel): [block][wave][step][3]
+        unsigned long long* tl_base = nullptr;
+        if (lid < 256 && lane == 0 && sa.part_fid != nullptr) tl_base = reinterpret_cast<unsigned long long*>(sa.part_fid) + ((lid * (NW * NWX) + wid) * 40ll) * 3;
+        int tl_k = 0;
+#define TV_SG2_MARK(j) do { if (tl_base != nullptr && tl_k < 40) tl_base[tl_k * 3 + (j)] = (unsigned long long)clock64(); } while (0)
+#else
+#define TV_SG2_MARK(j) do { } while (0)
+#endif
         for (int zl = z_lo; zl <= ze; ++zl) {
+            TV_SG2_MARK(0);
             const int gz = g.z0 + zl, par = zl & 1;
             const bool plane_in = (gz >= 0) && (gz < g.nzg) && (zl < ze || g.za);
             const T* pc = pc_c;                                            // carried: one zplane() per step instead of three
@@ -872,7 +884,12 @@ struct SgCol {
             }
             // LDS-only barrier: the hand-off rows must be visible, nothing else.  __syncthreads() would also drain vmcnt -- the
             // stores of this plane and the look-ahead loads of the next one, one exposed memory round trip per plane
+            TV_SG2_MARK(1);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            TV_SG2_MARK(2);
+#ifdef TV_SG2_TIMELINE
+            ++tl_k;
+#endif
         }
         acc = block_sum(acc, sh.sm);
         if (threadIdx.x == 0 && threadIdx.y == 0) partials[lid] = acc;

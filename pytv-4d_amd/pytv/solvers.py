@@ -321,6 +321,7 @@ class ChambollePock(_SlabProblem):
         self.sigma_D, self.sigma_A = float(sigma_D), float(sigma_A)
         self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time,
                                                                     self.geo.time_weight_max)
+        fused_given = fused is not None
         if fused is None:
             # one-sweep kernel where supported -- except on volumes too small to fill the GPU with its blocks (8 rows x 256
             # columns x >= 8 planes x all frames each: a block holds >= 16 k x M voxels and a CU takes 8 / M of them, so
@@ -330,8 +331,9 @@ class ChambollePock(_SlabProblem):
             # voxels of this rank's slab) moves the switch.
             min_vox = 1024 * _nv.get_option("TV_FUSED_MIN_KVOXELS", 16384)
             fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) and self.x0.numel() >= min_vox
+        # (an explicit fused=False asks for the kernel pair: the persistent loop replaces it only when it is asked for as well)
+        self.small = (not bool(fused)) and self._small_ok(False if (fused_given and persistent is None) else persistent)
         self.fused = bool(fused)
-        self.small = (not self.fused) and self._small_ok(persistent)
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):
             raise ValueError("the one-sweep Chambolle-Pock kernel does not support this geometry (tv_cp_fused_supported: "
                              "fp32, Nx % 4 == 0, Nx >= 64, Ny * Nx <= 2^30; any number of frames)")
@@ -1024,7 +1026,8 @@ class SubgradientDescent(_SlabProblem):
         iterations (tv_small_subgrad_descent: tv_subgrad + tv_subgrad_step's arithmetic inside a persistent kernel); False / True."""
         super().__init__(x0, scheme, reg_z_over_reg, reg_time, mask_static, factor_reg_static, slab, pitch=pitch)
         self.reg, self.step_size = float(regularization), float(step_size)
-        self.small = self._small_ok(persistent)
+        # (an explicit one_pass=True / False asks for that kernel family: the persistent loop replaces it only when it is asked for as well)
+        self.small = self._small_ok(False if (one_pass is not None and persistent is None) else persistent)
         self.x = self.image_copy(self.x0)
         nz, m, ny, nx = self.x0.shape
         self.G = self.new_image()

@@ -893,7 +893,7 @@ def test_no_out_of_bounds_access(pytv, scheme, shape, dtype):
 def test_full_size_config3_on_one_gpu_two_paths_agree(pytv):
     """BASELINE config 3, (512, 8, 1024, 1024) fp32 = 2^32 voxels with a 2^35-element dual variable, resident on ONE
     MI355X (192 GiB).  The one-sweep kernels and the dual / primal kernel pair are independent code: the same loss from both
-    beyond 2^32 elements is the 64-bit indexing check at the largest BASELINE size (tools/archive/big_volume_check.py)."""
+    beyond 2^32 elements is the 64-bit indexing check at the largest BASELINE size (tools/big_volume_check.py)."""
     import subprocess
     import sys
     import torch

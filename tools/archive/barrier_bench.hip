@@ -1,5 +1,5 @@
 // barrier_bench.hip -- what does a grid-wide barrier cost on MI355X (256 CUs, 8 XCDs)?  round 6, persistent small-volume solver.
-//   hipcc --offload-arch=gfx950 -O3 -o barrier_bench tools/probes/barrier_bench.hip && ./barrier_bench
+//   hipcc --offload-arch=gfx950 -O3 -o barrier_bench tools/archive/barrier_bench.hip && ./barrier_bench
 // Variants: (A) one monotonic counter, every block arrives with one agent-scope atomic and polls it;
 //           (B) two levels: one counter per XCD (blocks of an XCD arrive there), the last arriver of an XCD arrives at a top counter,
 //               everybody polls a single release flag;

@@ -2,7 +2,7 @@
 // Every iteration each block writes its span, a grid barrier follows, then it reads the span of the next block and checks it.
 // Cache policies of the raw buffer accesses (aux): 0 = plain, 16 = sc1 (agent-coherent), 17 = sc0|sc1 (system-coherent), 2 = nt.
 // A bulk agent-scope fence per wave costs ~60 - 100 us per barrier (barrier_bench.hip, variant C); this probe looks for the cheap way.
-//   hipcc --offload-arch=gfx950 -O3 -o coherence_probe tools/probes/coherence_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -o coherence_probe tools/archive/coherence_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,6 +1,6 @@
 // sc1_reuse_probe.hip -- round 6: cost model of agent-coherent (sc1) loads on MI355X.  Each iteration a block writes its span (sc1 stores), a grid
 // barrier follows, then it reads a span R times (R "stencil neighbours" touching the same lines) with plain or sc1 loads, own or foreign.
-//   hipcc --offload-arch=gfx950 -O3 -o sc1_reuse_probe tools/probes/sc1_reuse_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -o sc1_reuse_probe tools/archive/sc1_reuse_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
