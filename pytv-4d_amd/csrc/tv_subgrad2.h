@@ -434,11 +434,11 @@ struct SgCol {
 #ifdef TV_SG2_TIMELINE
         // variant builds only (tools/sg_timeline.py): lane 0 of every wave of the first 256 blocks records the shader clock at the top of
         // every plane step, before the LDS barrier that ends it and after that barrier -- behind the THIRD partial array of the workspace
-        // (unused by this kernel): [block][wave][step][3]
+        // (unused by this kernel): [block][wave][step][4]; slot 3: the 100 MHz wall clock at the top of the step
         unsigned long long* tl_base = nullptr;
-        if (lid < 256 && lane == 0 && sa.part_fid != nullptr) tl_base = reinterpret_cast<unsigned long long*>(sa.part_fid) + ((lid * (NW * NWX) + wid) * 40ll) * 3;
+        if (lid < 256 && lane == 0 && sa.part_fid != nullptr) tl_base = reinterpret_cast<unsigned long long*>(sa.part_fid) + ((lid * (NW * NWX) + wid) * 40ll) * 4;
         int tl_k = 0;
-#define TV_SG2_MARK(j) do { if (tl_base != nullptr && tl_k < 40) tl_base[tl_k * 3 + (j)] = (unsigned long long)clock64(); } while (0)
+#define TV_SG2_MARK(j) do { if (tl_base != nullptr && tl_k < 40) { tl_base[tl_k * 4 + (j)] = (unsigned long long)clock64(); if ((j) == 0) tl_base[tl_k * 4 + 3] = (unsigned long long)wall_clock64(); } } while (0)
 #else
 #define TV_SG2_MARK(j) do { } while (0)
 #endif

@@ -322,6 +322,8 @@ class ChambollePock(_SlabProblem):
         self.tau = float(tau) if tau is not None else cp_step_size(self.slab.nz_global, x0.shape[1], reg_z_over_reg, reg_time,
                                                                     self.geo.time_weight_max)
         fused_given = fused is not None
+        if fused is None and persistent is True:
+            fused = False                                 # the persistent loop was asked for: it replaces the kernel pair, not the one-sweep kernel
         if fused is None:
             # one-sweep kernel where supported -- except on volumes too small to fill the GPU with its blocks (8 rows x 256
             # columns x >= 8 planes x all frames each: a block holds >= 16 k x M voxels and a CU takes 8 / M of them, so
@@ -332,6 +334,8 @@ class ChambollePock(_SlabProblem):
             min_vox = 1024 * _nv.get_option("TV_FUSED_MIN_KVOXELS", 16384)
             fused = bool(self.lib.tv_cp_fused_supported(self.geo.ref)) and self.x0.numel() >= min_vox
         # (an explicit fused=False asks for the kernel pair: the persistent loop replaces it only when it is asked for as well)
+        if bool(fused) and persistent is True:
+            raise ValueError("fused=True and persistent=True are two different kernels: ask for one")
         self.small = (not bool(fused)) and self._small_ok(False if (fused_given and persistent is None) else persistent)
         self.fused = bool(fused)
         if self.fused and not self.lib.tv_cp_fused_supported(self.geo.ref):

@@ -38,15 +38,19 @@ ms = a.elapsed_time(b)
 third = ws.numel() // 3
 raw = ws[third:2 * third].cpu().numpy().view(np.uint64)
 NWAVES, STEPS = 8, 40
-m = raw[:256 * NWAVES * STEPS * 3].reshape(256, NWAVES, STEPS, 3).astype(np.float64)
+m = raw[:256 * NWAVES * STEPS * 4].reshape(256, NWAVES, STEPS, 4).astype(np.float64)
 used = (m[..., 0] > 0) & (m[..., 2] > 0)
 nsteps = int(used[0, 0].sum())
 m = m[:, :, :nsteps]
 work = m[..., 1] - m[..., 0]                      # top of the step -> barrier
 barr = m[..., 2] - m[..., 1]                      # inside s_waitcnt lgkmcnt(0) + s_barrier
 step = np.diff(m[..., 0], axis=2)                 # top -> next top
+wall = m[..., 3]
+ratio = (m[:, :, -1, 0] - m[:, :, 0, 0]) / np.maximum(1.0, wall[:, :, -1] - wall[:, :, 0])      # s_memtime ticks per 10 ns
+mhz = 100.0 * float(np.median(ratio))
+print("%s %s: tv_subgrad_fused %.3f ms (with the marks); %d plane steps per chunk; s_memtime runs at %.0f MHz during the kernel (against the 100 MHz wall clock)" % ("x".join(map(str, shape)), scheme, ms, nsteps, mhz))
+print("  i.e. a plane step of %.0f cycles takes %.2f us; a block's plane loop %.1f us" % (step[:, :, 1:].mean(), step[:, :, 1:].mean() / mhz, (m[:, :, -1, 2].max(axis=1) - m[:, :, 0, 0].min(axis=1)).mean() / mhz))
 dev = torch.cuda.get_device_properties(0)
-print("%s %s: tv_subgrad_fused %.3f ms (with the marks); %d plane steps per chunk; shader clock cycles (s_memtime)" % ("x".join(map(str, shape)), scheme, ms, nsteps))
 print("  per step and wave: own work %7.0f cycles (median %7.0f, p10 %7.0f, p90 %7.0f)" % (work[:, :, 1:].mean(), np.median(work[:, :, 1:]), np.percentile(work[:, :, 1:], 10), np.percentile(work[:, :, 1:], 90)))
 print("                     in the barrier %7.0f cycles (median %7.0f, p90 %7.0f) = %.1f %% of a step" % (barr[:, :, 1:].mean(), np.median(barr[:, :, 1:]), np.percentile(barr[:, :, 1:], 90), 100 * barr[:, :, 1:].mean() / step[:, :, 1:].mean()))
 print("                     step (top to top) %7.0f cycles" % step[:, :, 1:].mean())
