@@ -145,6 +145,9 @@ constexpr int SG2_TWN = 8, SG2_TWU = SG2_TWN - 2;      // time windows for M > 8
 #ifndef TV_SG2_X0_AHEAD
 #define TV_SG2_X0_AHEAD 1
 #endif
+#ifndef TV_SG2_PRIO
+#define TV_SG2_PRIO 0          // 1 .. 3: EXPERIMENT (round 6) -- alternate the issue priority of the two waves of a SIMD frame by frame
+#endif
 #ifndef TV_SG2_SCHED_BARRIER
 #define TV_SG2_SCHED_BARRIER 1
 #endif
@@ -442,6 +445,9 @@ struct SgCol {
 #else
 #define TV_SG2_MARK(j) do { } while (0)
 #endif
+#ifdef TV_SG2_PRIO_STATIC
+        if (wid >= (NW * NWX) / 2) __builtin_amdgcn_s_setprio(TV_SG2_PRIO_STATIC);       // EXPERIMENT: the younger wave of every SIMD pair always first
+#endif
         for (int zl = z_lo; zl <= ze; ++zl) {
             TV_SG2_MARK(0);
             const int gz = g.z0 + zl, par = zl & 1;
@@ -541,6 +547,13 @@ struct SgCol {
             for (int i = 0; i < R; ++i) pf_t_prev.v[i] = f_t_prev.v[i] = c_old_prev.v[i] = T(0);
 #pragma unroll
             for (int t = 0; t < M; ++t) {
+#if TV_SG2_PRIO
+                // the two waves of a SIMD leapfrog: each has the higher issue priority in every other frame.  Without it the older wave of the
+                // pair (waves 0 .. NW - 1) wins every arbitration, finishes a plane step ~3 k cycles early and sits in the barrier while the
+                // younger one finishes alone at a single wave's issue rate (profiles/r6_sg_timeline.txt)
+                if (((t + (wid >= (NW * NWX) / 2 ? 1 : 0)) & 1) != 0) __builtin_amdgcn_s_setprio(TV_SG2_PRIO);
+                else __builtin_amdgcn_s_setprio(0);
+#endif
                 const C c = Cc[t];
                 const C nx = Nq[t % SG2_D];          // x(zl+1, t)
                 C q1, q2;
