@@ -471,8 +471,10 @@ def self_launch(args, argv):
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same arguments>` as a CHILD process, relay its
     stdout (rank 0's JSON line) and return its exit code.  This process never imports torch and never makes a HIP call -- it is not
     replaced either (no exec).  A child that outlives TV_BENCH_TIMEOUT seconds is killed by process group and reported as an error line;
-    a child that fails without a line gets one.  TV_BENCH_RETRY=1: a failed first attempt is repeated ONCE without the halo/compute
-    overlap (--no-overlap), and stderr says so."""
+    a child that fails without a line gets one.  A failed attempt is repeated with a more conservative transport (TV_BENCH_RETRY=0
+    switches that off): first without the halo / compute overlap (--no-overlap), then with host-staged halos over gloo, every rank
+    still on its own GPU (TV_BENCH_BACKEND=gloo: a number that is labelled as such in `comm`, instead of none).  stderr says which
+    attempt produced the line."""
     import signal
     import socket
     import subprocess
@@ -481,11 +483,14 @@ def self_launch(args, argv):
     n = args.gpus
     module = os.environ.get("TV_BENCH_LAUNCH_MODULE", "torch.distributed.run")        # (tests substitute a recorder)
     limit = float(os.environ.get("TV_BENCH_TIMEOUT", "2400"))
-    attempts = [list(argv)]
-    if os.environ.get("TV_BENCH_RETRY", "0") == "1" and "--no-overlap" not in argv:
-        attempts.append(list(argv) + ["--no-overlap"])
+    attempts = [(list(argv), {})]
+    if os.environ.get("TV_BENCH_RETRY", "1") != "0":
+        if "--no-overlap" not in argv:
+            attempts.append((list(argv) + ["--no-overlap"], {}))
+        if os.environ.get("TV_BENCH_BACKEND", "nccl") == "nccl":
+            attempts.append(([a for a in argv if a != "--no-overlap"] + ["--no-overlap"], {"TV_BENCH_BACKEND": "gloo"}))
     rc = 1
-    for k, av in enumerate(attempts):
+    for k, (av, env_extra) in enumerate(attempts):
         port = os.environ.get("TV_BENCH_MASTER_PORT")
         if port is None:
             with socket.socket() as sk:
@@ -493,7 +498,7 @@ def self_launch(args, argv):
                 port = str(sk.getsockname()[1])
         cmd = [sys.executable, "-m", module, "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
                os.path.abspath(__file__)] + av
-        env = dict(os.environ, TV_BENCH_SELF_LAUNCHED="1")
+        env = dict(os.environ, TV_BENCH_SELF_LAUNCHED="1", **env_extra)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         sys.stderr.write("[bench] self-launch (torch imported: %s): %s\n" % ("torch" in sys.modules, " ".join(cmd)))
@@ -527,7 +532,8 @@ def self_launch(args, argv):
         if not got_line[0]:
             print(error_line(args, n, "the launcher (%s) exited with code %d and rank 0 printed no line" % (module, rc)), flush=True)
         if k + 1 < len(attempts):
-            sys.stderr.write("[bench] attempt %d failed (exit code %d); repeating once with --no-overlap\n" % (k + 1, rc))
+            nxt = attempts[k + 1]
+            sys.stderr.write("[bench] attempt %d failed (exit code %d); next attempt: %s %s\n" % (k + 1, rc, " ".join(nxt[0]), nxt[1] or ""))
     return rc if rc != 0 else 1
 
 

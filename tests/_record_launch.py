@@ -9,7 +9,7 @@ if __name__ == "__main__":
     rc = int(os.environ.get("TV_FAKE_LAUNCH_RC", "0"))
     if os.environ.get("TV_FAKE_LAUNCH_SILENT", "0") != "1":
         print(json.dumps({"recorded_argv": sys.argv[1:], "self_launched": os.environ.get("TV_BENCH_SELF_LAUNCHED"),
-                          "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "torch_in_child": "torch" in sys.modules}), flush=True)
+                          "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "backend": os.environ.get("TV_BENCH_BACKEND"), "torch_in_child": "torch" in sys.modules}), flush=True)
     if os.environ.get("TV_FAKE_LAUNCH_SLEEP"):
         import time
         time.sleep(float(os.environ["TV_FAKE_LAUNCH_SLEEP"]))

@@ -91,11 +91,11 @@ def test_gpus_n_from_a_plain_shell_starts_the_launcher_as_a_child_before_torch_i
 
 def test_self_launch_relays_the_exit_code_and_always_leaves_a_line():
     argv = ["--gpus", "2", "--workload", "small"]
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="7"), capture_output=True,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="7", TV_BENCH_RETRY="0"), capture_output=True,
                        text=True, timeout=120)
     assert p.returncode == 7
     # a launcher that dies without a line: the parent prints the error line itself
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="9", TV_FAKE_LAUNCH_SILENT="1"),
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="9", TV_FAKE_LAUNCH_SILENT="1", TV_BENCH_RETRY="0"),
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 9
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -107,11 +107,16 @@ def test_self_launch_relays_the_exit_code_and_always_leaves_a_line():
     assert p.returncode == 5
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["value"] is None and "did not finish within" in out["error"]
-    # TV_BENCH_RETRY=1: one more attempt, without the overlap
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="3", TV_BENCH_RETRY="1"),
+    # a failed attempt is repeated: without the overlap, then with host-staged halos over gloo (TV_BENCH_RETRY=0: one attempt only)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="3"),
                        capture_output=True, text=True, timeout=120)
     recs = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert p.returncode == 3 and len(recs) == 2 and "--no-overlap" not in recs[0]["recorded_argv"] and recs[1]["recorded_argv"][-1] == "--no-overlap"
+    assert p.returncode == 3 and len(recs) == 3 and "--no-overlap" not in recs[0]["recorded_argv"]
+    assert recs[1]["recorded_argv"][-1] == "--no-overlap" and recs[1]["backend"] is None
+    assert recs[2]["recorded_argv"][-1] == "--no-overlap" and recs[2]["backend"] == "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=_plain_env(TV_FAKE_LAUNCH_RC="3", TV_BENCH_RETRY="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3 and len([ln for ln in p.stdout.splitlines() if ln.startswith("{")]) == 1
 
 
 def test_under_a_launcher_bench_does_not_launch_again():

@@ -52,9 +52,25 @@ def file_has(path, token):
                 pass
     else:       # text / csv evidence: any longer decimal that rounds to the quoted one
         vals = [float(m) for m in re.findall(r"(?<![\w.])\d+\.\d+(?:[eE][-+]?\d+)?", txt)]
-        if path.endswith(".csv"):       # rocprofv3 kernel_stats.csv stores nanoseconds (averages with decimals, min / max as integers): a table
-            vals += [float(m) for m in re.findall(r"(?<![\w.])\d{4,}(?![\w.])", txt)]      # may quote them as microseconds / milliseconds
-            vals += [v * 1e-3 for v in vals] + [v * 1e-6 for v in vals]
+        if path.endswith(".csv"):
+            # rocprofv3 kernel_stats.csv stores nanoseconds; a table may quote them as microseconds / milliseconds.  Only the DURATION columns
+            # (AverageNs, MinNs, MaxNs) are rescaled -- round-5 advice: rescaling every integer of four or more digits (calls, totals, percentages)
+            # made almost any quoted number "match"
+            import csv as _csv
+            dur = []
+            try:
+                rows = list(_csv.reader(txt.splitlines()))
+                cols = [i for i, h in enumerate(rows[0]) if any(k in h for k in ("AverageNs", "MinNs", "MaxNs"))] if rows else []
+                for r in rows[1:]:
+                    for i in cols:
+                        if i < len(r):
+                            try:
+                                dur.append(float(r[i]))
+                            except ValueError:
+                                pass
+            except Exception:
+                dur = []
+            vals += [v * 1e-3 for v in dur] + [v * 1e-6 for v in dur]
     want = float(token)
     return any(abs(round(v, nd) - want) < 0.5 * 10 ** (-nd) * 1e-6 + 1e-12 or ("%.*f" % (nd, v)) == token for v in vals)
 
