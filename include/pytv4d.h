@@ -337,21 +337,24 @@ int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, do
  * allow), pitched arrays, weight maps / volumes.  The stream must not run other kernels of the caller concurrently with these
  * launches in a way that could starve them of compute units (the blocks of a launch wait for each other).
  *   tv_small_supported       : 1 if the geometry fits (<= TV_SMALL_MAX_KVOXELS thousand voxels, default 4096; arrays below 2^31 bytes)
- *   tv_small_workspace_bytes : bytes of the scratch buffer `ws` for n_iter iterations per launch (block flags + per-block partials)
+ *   tv_small_workspace_bytes : bytes of the scratch buffer `ws` for n_iter iterations per launch (block flags + per-block partials).
+ *                              `ws` must be ZERO-FILLED once before its first use (hipMemset); the calls keep it consistent afterwards
+ *                              (the blocks' phase counters continue from call to call: no reset per launch).  One `ws` per stream.
  *   tv_small_cp              : n_iter iterations of  p <- (p + sigma_A (x - x0)) / (1 + sigma_A);  q <- proj(q + sigma_D D x);
  *                              x <- x - tau p - tau D^T q  exactly as tv_cp_dual + tv_cp_primal compute them, x / p / q updated in
- *                              place; hist (device fp64, 2 * n_iter words): hist[2 k] = |D x_k|_{2,1} (the iterate the dual update of
- *                              iteration k saw), hist[2 k + 1] = 1/2 |x_{k+1} - x0|^2
+ *                              place.  hist (device fp64): hist[k * hist_stride] = |D x_k|_{2,1} (the iterate the dual update of
+ *                              iteration k saw), hist[k * hist_stride + hist_fid_offset] = 1/2 |x_{k+1} - x0|^2
+ *                              (a dense (n_iter, 2) array: stride 2, offset 1; 0 < hist_fid_offset < hist_stride)
  *   tv_small_subgrad_descent : n_iter iterations of  x <- x - step ((x - x0) + lambda G(x))  (tv_subgrad + tv_subgrad_step's
  *                              arithmetic); the iterate is ping-ponged between x and x_alt: after an ODD n_iter the result is in
  *                              x_alt, after an even one in x; norms_ext: (nz + 2) planes of scratch (1 / |D x|);
- *                              hist[2 k] = TV(x_k), hist[2 k + 1] = 1/2 |x_{k+1} - x0|^2 */
+ *                              hist as above: TV(x_k) and 1/2 |x_{k+1} - x0|^2 */
 int    tv_small_supported(const tv_geom* g);
 size_t tv_small_workspace_bytes(const tv_geom* g, int64_t n_iter);
 int    tv_small_cp(const tv_geom* g, void* x, const void* x0, void* p, void* q, double sigma_D, double lambda, double tau,
-                   double sigma_A, int64_t n_iter, double* hist, void* ws, void* stream);
+                   double sigma_A, int64_t n_iter, double* hist, int64_t hist_stride, int64_t hist_fid_offset, void* ws, void* stream);
 int    tv_small_subgrad_descent(const tv_geom* g, void* x, void* x_alt, const void* x0, void* norms_ext, double step, double lambda,
-                                int64_t n_iter, double* hist, void* ws, void* stream);
+                                int64_t n_iter, double* hist, int64_t hist_stride, int64_t hist_fid_offset, void* ws, void* stream);
 
 /* ---- multi-GPU: z-slab neighbours over RCCL, one process per GPU ------------------------------ */
 /* The reference is single-GPU (its README only remarks that the (Nz, M, N, N) layout "can be decomposed easily along z",

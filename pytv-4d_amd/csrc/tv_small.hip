@@ -44,6 +44,11 @@ struct SmallPlan {
 };
 constexpr int kFlagStride = 32;          // unsigned words per flag: one 128-byte line per block
 constexpr int kSmallThreads = 256;
+constexpr int kMaxSmallBlocks = 8192;
+// The phase counters are never reset: a launch starts from the epoch its predecessor on the same workspace left in the line behind the
+// flags (bumped by 2 n_iter by the reduction kernel that closes every call) -- no memset per launch.  The workspace is zero-filled ONCE by
+// its owner before the first call.  Comparisons are wrap-safe.
+__device__ __forceinline__ unsigned small_epoch_base(const unsigned* flags) { return flags[(long long)kMaxSmallBlocks * kFlagStride]; }
 
 // blockIdx.x -> logical block id such that ids [k * grid/8, (k+1) * grid/8) run on XCD k (consecutive blockIdx values go round-robin
 // over the eight XCDs; nothing but speed depends on that assumption -- every shared access is agent-coherent)
@@ -103,7 +108,7 @@ __device__ __forceinline__ void small_sync(unsigned* flags, int L, int dep, unsi
         if (threadIdx.x == 0) __hip_atomic_store(flags + (long long)L * kFlagStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dep >= 0) {
             const unsigned* f = flags + (long long)dep * kFlagStride;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(1);
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) __builtin_amdgcn_s_sleep(1);      // (wrap-safe)
         }
     }
     __syncthreads();
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_cp(DG g, WT<T> w, Small
     const int L = small_logical_id(sp);
     if (L >= sp.nblocks) return;
     const int dep = small_dependency(g, sp, L, (int)threadIdx.x);
+    const unsigned e0 = small_epoch_base(a.flags);
     const int vb0 = L * sp.per_block, vb1 = (vb0 + sp.per_block < sp.nvb) ? vb0 + sp.per_block : sp.nvb;
     const CohMem mx = CohMem::make(a.x, a.x_bytes), mq = CohMem::make(a.q, a.q_bytes);
     const CpDualCoh<S, T, V> dual{a.q, a.sigma_D, a.inv_lambda, mq};
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_cp(DG g, WT<T> w, Small
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
         TV_SMALL_MARK(1);
-        small_sync(a.flags, L, dep, (unsigned)(2 * it + 1));
+        small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1));
         TV_SMALL_MARK(2);
         // ---- primal: p <- (p + sigma_A (x - x0)) / (1 + sigma_A); x <- x - tau p - tau D^T q; 1/2 |x - x0|^2 (README.md:148,154,157)
         acc = 0.0;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_cp(DG g, WT<T> w, Small
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
         TV_SMALL_MARK(3);
-        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, (unsigned)(2 * it + 2));
+        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2));
         TV_SMALL_MARK(4);
     }
 }
@@ -256,7 +262,6 @@ constexpr unsigned kOOB = 0x80000000u;          // every array of these kernels 
 // phase 1.5 x slower and pace all the others through the neighbour waits; one-wave blocks spread evenly but multiply the flags and the
 // dependency chains (13.1 -> 15.8 us per iteration): profiles/r6_small_profile_v3.txt.
 constexpr int kRegMaxThreads = 1024;
-constexpr int kMaxSmallBlocks = 8192;
 
 template <typename T, int V> __device__ __forceinline__ Vec<T, V> coh_ldv(const CohMem& m, unsigned byte_off) {
     if constexpr (V == 1) {
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_cp_reg(DG g, WT<T> w, 
     constexpr unsigned EB = sizeof(T);
     const int nxv = (g.nx + V - 1) / V;
     const int dep = small_dependency_flat(g, sp, L, nxv, (int)threadIdx.x);
+    const unsigned e0 = small_epoch_base(a.flags);
     const FlatId fid = small_flat_id(g, L);
     const int tile = fid.tile, t = fid.t, zl = fid.zl;
     const int sidx = tile * (int)blockDim.x + (int)threadIdx.x;
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_cp_reg(DG g, WT<T> w, 
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
         TV_SMALL_MARK(1);
-        small_sync(a.flags, L, dep, (unsigned)(2 * it + 1));
+        small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1));
         TV_SMALL_MARK(2);
         // ---- primal: p <- (p + sigma_A (x - x0)) / (1 + sigma_A); x <- x - tau p - tau D^T q (README.md:148,154): every neighbour of q at once
         asm volatile("" : "+v"(bx), "+v"(bq));
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_cp_reg(DG g, WT<T> w, 
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
         TV_SMALL_MARK(3);
-        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, (unsigned)(2 * it + 2));
+        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2));
         TV_SMALL_MARK(4);
     }
     if (ok) vstore<T, V>(a.p + offx, p);
@@ -523,6 +529,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, 
     constexpr unsigned EB = sizeof(T);
     const int nxv = (g.nx + V - 1) / V;
     const int dep = small_dependency_flat(g, sp, L, nxv, (int)threadIdx.x);
+    const unsigned e0 = small_epoch_base(a.flags);
     const FlatId fid = small_flat_id(g, L);
     const int t = fid.t, zl = fid.zl;
     const int sidx = fid.tile * (int)blockDim.x + (int)threadIdx.x;
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, 
         coh_stv<T, V>(mn, at(ok, b, 0), nv);
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
-        small_sync(a.flags, L, dep, (unsigned)(2 * it + 1));
+        small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1));
         // ---- pass 2: G from x and 1 / |D x| (pytv/tv_GPU.py:91-124), x <- x - step ((x - x0) + lambda G) (README.md:122-123)
         asm volatile("" : "+v"(b));
         ns.c = nv;
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, 
         coh_stv<T, V>(mxo, at(ok, b, 0), x);
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
-        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, (unsigned)(2 * it + 2));
+        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2));
     }
 }
 
@@ -612,6 +619,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_sg(DG g, WT<T> w, Small
     const int L = small_logical_id(sp);
     if (L >= sp.nblocks) return;
     const int dep = small_dependency(g, sp, L, (int)threadIdx.x);
+    const unsigned e0 = small_epoch_base(a.flags);
     const int vb0 = L * sp.per_block, vb1 = (vb0 + sp.per_block < sp.nvb) ? vb0 + sp.per_block : sp.nvb;
     const CohMem mn = CohMem::make(a.norms_ext, a.n_bytes);
     const NormEpiCoh<S, T, V> nepi{a.norms_ext, mn};
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_sg(DG g, WT<T> w, Small
         }
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
-        small_sync(a.flags, L, dep, (unsigned)(2 * it + 1));
+        small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1));
         // ---- pass 2: G from x and 1 / |D x| (pytv/tv_GPU.py:91-124), x <- x - step ((x - x0) + lambda G) (README.md:122-123)
         acc = 0.0;
         for (int vb = vb0; vb < vb1; ++vb) {
@@ -651,18 +659,23 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_sg(DG g, WT<T> w, Small
         }
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
-        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, (unsigned)(2 * it + 2));
+        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2));
     }
 }
 
-// hist[row] = sum over the blocks of partials[row][*] (fixed order: deterministic)
-__global__ __launch_bounds__(256) void k_small_reduce(const double* partials, int nblocks, double* hist) {
+// hist[(row / 2) * stride + (row & 1 ? fid_offset : 0)] = sum over the blocks of partials[row][*] (fixed order: deterministic); the first
+// block also advances the workspace's epoch past this call's phases
+__global__ __launch_bounds__(256) void k_small_reduce(const double* partials, int nblocks, double* hist, long long stride, long long fid_offset,
+                                                      unsigned* flags, unsigned advance) {
     __shared__ double sm[16];
     const double* p = partials + (long long)blockIdx.x * nblocks;
     double acc = 0.0;
     for (int i = (int)threadIdx.x; i < nblocks; i += 256) acc += p[i];
     acc = block_sum(acc, sm);
-    if (threadIdx.x == 0) hist[blockIdx.x] = acc;
+    if (threadIdx.x == 0) {
+        hist[(long long)(blockIdx.x >> 1) * stride + ((blockIdx.x & 1) ? fid_offset : 0)] = acc;
+        if (blockIdx.x == 0) flags[(long long)kMaxSmallBlocks * kFlagStride] += advance;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -766,20 +779,22 @@ size_t tv_small_workspace_bytes(const tv_geom* g, int64_t n_iter) {
     if (make_dg(g, d, true) || n_iter < 1) return 0;
     // flags: one 128-byte line per launched block; partials: n_iter x 2 x blocks doubles
     const size_t blocks = kMaxSmallBlocks;
+    const size_t flag_bytes = (blocks + 1) * kFlagStride * sizeof(unsigned);      // (+ the line that holds the epoch)
 #ifdef TV_SMALL_PROFILE
-    return blocks * kFlagStride * sizeof(unsigned) + (size_t)n_iter * 7 * blocks * sizeof(double) + 256;
+    return flag_bytes + (size_t)n_iter * 7 * blocks * sizeof(double) + 256;
 #else
-    return blocks * kFlagStride * sizeof(unsigned) + (size_t)n_iter * 2 * blocks * sizeof(double) + 256;
+    return flag_bytes + (size_t)n_iter * 2 * blocks * sizeof(double) + 256;
 #endif
 }
 
 int tv_small_cp(const tv_geom* g, void* x, const void* x0, void* p, void* q, double sigma_D, double lambda, double tau, double sigma_A,
-                int64_t n_iter, double* hist, void* ws, void* stream) {
+                int64_t n_iter, double* hist, int64_t hist_stride, int64_t hist_fid_offset, void* ws, void* stream) {
     DG d;
     if (int rc = small_check(g, d, "tv_small_cp: volume too large for the persistent kernel (tv_small_supported)")) return rc;
     if (x == nullptr || x0 == nullptr || p == nullptr || q == nullptr || hist == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (!(lambda > 0.0)) return fail(TV_E_ARG, "lambda must be > 0");
     if (n_iter < 1 || n_iter > (1 << 20)) return fail(TV_E_ARG, "n_iter out of range");
+    if (hist_stride < 1 || hist_fid_offset == 0 || hist_fid_offset >= hist_stride || hist_fid_offset < 0) return fail(TV_E_ARG, "hist_stride / hist_fid_offset: 0 < fid_offset < stride");
     const bool vec = rows_vectorisable(g, d) && aligned16({x, x0, p, q, d.wv});
     hipStream_t st = (hipStream_t)stream;
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
@@ -795,27 +810,28 @@ int tv_small_cp(const tv_geom* g, void* x, const void* x0, void* p, void* q, dou
         }
         if (sp.grid > kMaxSmallBlocks) return fail(TV_E_ARG, "internal: more blocks than the workspace holds");
         unsigned* flags = (unsigned*)ws;
-        double* partials = (double*)((char*)ws + (size_t)kMaxSmallBlocks * kFlagStride * sizeof(unsigned));
-        HIP_TRY(hipMemsetAsync(flags, 0, (size_t)sp.grid * kFlagStride * sizeof(unsigned), st));
+        double* partials = (double*)((char*)ws + (size_t)(kMaxSmallBlocks + 1) * kFlagStride * sizeof(unsigned));
         DG dd = d;
         WT<T> w = make_w<T>(g);
         SmallCpArgs<T> a{(T*)x, (const T*)x0, (T*)p, (T*)q, (T)sigma_D, (T)(1.0 / lambda), (T)tau, (T)sigma_A, (T)(1.0 / (1.0 + sigma_A)), (int)n_iter,
                          flags, partials, d.s_z * d.nz * (long long)sizeof(T), d.s_dz * d.nz * (long long)sizeof(T)};
         void* args[] = {&dd, &w, &sp, &a};
         HIP_TRY(hipLaunchCooperativeKernel(kern, dim3((unsigned)sp.grid), dim3((unsigned)threads), args, 0, st));
-        hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)(2 * n_iter)), dim3(256), 0, st, (const double*)partials, sp.nblocks, hist);
+        hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)(2 * n_iter)), dim3(256), 0, st, (const double*)partials, sp.nblocks, hist, (long long)hist_stride,
+                           (long long)hist_fid_offset, flags, (unsigned)(2 * n_iter));
         HIP_TRY(hipGetLastError());
         return 0;
     });
 }
 
 int tv_small_subgrad_descent(const tv_geom* g, void* x, void* x_alt, const void* x0, void* norms_ext, double step, double lambda, int64_t n_iter,
-                             double* hist, void* ws, void* stream) {
+                             double* hist, int64_t hist_stride, int64_t hist_fid_offset, void* ws, void* stream) {
     DG d;
     if (int rc = small_check(g, d, "tv_small_subgrad_descent: volume too large for the persistent kernel (tv_small_supported)")) return rc;
     if (x == nullptr || x_alt == nullptr || x0 == nullptr || norms_ext == nullptr || hist == nullptr || ws == nullptr) return fail(TV_E_ARG, "NULL array");
     if (x == x_alt) return fail(TV_E_ARG, "x and x_alt must be different arrays (the iterate is ping-ponged)");
     if (n_iter < 1 || n_iter > (1 << 20)) return fail(TV_E_ARG, "n_iter out of range");
+    if (hist_stride < 1 || hist_fid_offset == 0 || hist_fid_offset >= hist_stride || hist_fid_offset < 0) return fail(TV_E_ARG, "hist_stride / hist_fid_offset: 0 < fid_offset < stride");
     const bool vec = rows_vectorisable(g, d) && aligned16({x, x_alt, x0, norms_ext, d.wv});
     hipStream_t st = (hipStream_t)stream;
     return dispatch(g->scheme, g->dtype, vec, [&]<int S, typename T, int V>() -> int {
@@ -836,15 +852,15 @@ int tv_small_subgrad_descent(const tv_geom* g, void* x, void* x_alt, const void*
         }
         if (sp.grid > kMaxSmallBlocks) return fail(TV_E_ARG, "internal: more blocks than the workspace holds");
         unsigned* flags = (unsigned*)ws;
-        double* partials = (double*)((char*)ws + (size_t)kMaxSmallBlocks * kFlagStride * sizeof(unsigned));
-        HIP_TRY(hipMemsetAsync(flags, 0, (size_t)sp.grid * kFlagStride * sizeof(unsigned), st));
+        double* partials = (double*)((char*)ws + (size_t)(kMaxSmallBlocks + 1) * kFlagStride * sizeof(unsigned));
         DG dd = d;
         WT<T> w = make_w<T>(g);
         SmallSgArgs<T> a{(T*)x, (T*)x_alt, (const T*)x0, (T*)norms_ext, (T)step, (T)lambda, (int)n_iter, flags, partials,
                          d.s_z * d.nz * (long long)sizeof(T), d.s_z * (d.nz + 2) * (long long)sizeof(T)};
         void* args[] = {&dd, &w, &sp, &a};
         HIP_TRY(hipLaunchCooperativeKernel(kern, dim3((unsigned)sp.grid), dim3((unsigned)threads), args, 0, st));
-        hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)(2 * n_iter)), dim3(256), 0, st, (const double*)partials, sp.nblocks, hist);
+        hipLaunchKernelGGL(k_small_reduce, dim3((unsigned)(2 * n_iter)), dim3(256), 0, st, (const double*)partials, sp.nblocks, hist, (long long)hist_stride,
+                           (long long)hist_fid_offset, flags, (unsigned)(2 * n_iter));
         HIP_TRY(hipGetLastError());
         return 0;
     });

@@ -71,8 +71,8 @@ _SIGNATURES = {
     "tv_workspace_bytes": (ctypes.c_size_t, [_G]),
     "tv_small_supported": (ctypes.c_int, [_G]),
     "tv_small_workspace_bytes": (ctypes.c_size_t, [_G, ctypes.c_int64]),
-    "tv_small_cp": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [ctypes.c_double] * 4 + [ctypes.c_int64, _c_double_p, _c_void_p, _c_void_p]),
-    "tv_small_subgrad_descent": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [ctypes.c_double] * 2 + [ctypes.c_int64, _c_double_p, _c_void_p, _c_void_p]),
+    "tv_small_cp": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [ctypes.c_double] * 4 + [ctypes.c_int64, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_void_p, _c_void_p]),
+    "tv_small_subgrad_descent": (ctypes.c_int, [_G] + [_c_void_p] * 4 + [ctypes.c_double] * 2 + [ctypes.c_int64, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_void_p, _c_void_p]),
     "tv_D": (ctypes.c_int, [_G] + [_c_void_p] * 5),
     "tv_DT": (ctypes.c_int, [_G] + [_c_void_p] * 5),
     "tv_l21": (ctypes.c_int, [_G, _c_void_p, ctypes.c_int32, _c_void_p, _c_double_p, _c_void_p, _c_void_p]),

@@ -145,7 +145,7 @@ class _SlabProblem:
 
     # ---- persistent small-volume loops (round 6; csrc/tv_small.hip) ------------------------------------------------------------------
     SMALL_MAX_VOXELS = 2 << 20      # the automatic rule: volumes of at most 2 Mvoxel (the reference's own shapes hold 0.07 - 1) take it
-    SMALL_BLOCK = 64                # iterations per cooperative launch
+    SMALL_BLOCK = 128               # iterations per cooperative launch
 
     def _small_ok(self, persistent):
         """persistent: None = automatic (unsharded, <= SMALL_MAX_VOXELS, geometry supported), True = required, False = off"""
@@ -159,10 +159,10 @@ class _SlabProblem:
         return ok and self.x0.numel() <= self.SMALL_MAX_VOXELS
 
     def _small_ws(self):
+        """scratch of the persistent kernels: block flags (zero-filled ONCE: their phase counters continue from launch to launch) + partials"""
         if getattr(self, "_small_ws_buf", None) is None:
             nbytes = self.lib.tv_small_workspace_bytes(self.geo.ref, self.SMALL_BLOCK)
-            self._small_ws_buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
-            self._small_hist = torch.zeros((self.SMALL_BLOCK, 2), dtype=torch.float64, device=self.device)
+            self._small_ws_buf = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
         return self._small_ws_buf
 
     def geom(self, a, b):
@@ -841,13 +841,13 @@ class ChambollePock(_SlabProblem):
         iterate each dual update saw -> slot 0, 1/2 |x_new - x0|^2 -> slot F (the slots the kernel pair fills)."""
         ws = self._small_ws()
         n, done = rows.shape[0], 0
+        if rows.stride(1) != 1:
+            raise ValueError("rows must be a (n, SLOTS) fp64 tensor with contiguous rows")
         while done < n:
             k = min(self.SMALL_BLOCK, n - done)
-            h2 = self._small_hist[:k]
+            # the reduction that closes the launch writes TV -> slot 0 and the fidelity -> slot F of the rows themselves
             _nv.check(self.lib.tv_small_cp(self.geo.ref, _nv.ptr(self.x), _nv.ptr(self.x0), _nv.ptr(self.p), _nv.ptr(self.q), self.sigma_D, self.reg,
-                                           self.tau, self.sigma_A, k, h2.data_ptr(), _nv.ptr(ws), self.stream))
-            rows[done:done + k, 0] = h2[:, 0]
-            rows[done:done + k, self.F] = h2[:, 1]
+                                           self.tau, self.sigma_A, k, rows[done].data_ptr(), rows.stride(0), self.F, _nv.ptr(ws), self.stream))
             done += k
             self.it += k
 
@@ -1203,13 +1203,10 @@ class SubgradientDescent(_SlabProblem):
         n, done = rows.shape[0], 0
         while done < n:
             k = min(self.SMALL_BLOCK, n - done)
-            h2 = self._small_hist[:k]
             _nv.check(self.lib.tv_small_subgrad_descent(self.geo.ref, _nv.ptr(self.x), _nv.ptr(self.x_alt), _nv.ptr(self.x0), _nv.ptr(self.norms_ext),
-                                                        self.step_size, self.reg, k, h2.data_ptr(), _nv.ptr(ws), self.stream))
+                                                        self.step_size, self.reg, k, rows[done].data_ptr(), rows.stride(0), 3, _nv.ptr(ws), self.stream))
             if k & 1:
                 self.x, self.x_alt = self.x_alt, self.x
-            rows[done:done + k, 0] = h2[:, 0]
-            rows[done:done + k, 3] = h2[:, 1]
             done += k
 
     def _run_graphed_from(self, hist, first, n_iter):

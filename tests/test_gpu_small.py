@@ -82,7 +82,7 @@ def test_persistent_descent_matches_oracle(pytv, scheme, shape, lz, mu, use_mask
 
 @pytest.mark.parametrize("scheme", SCHEMES)
 def test_persistent_cp_300_iterations_against_the_reference_golden(pytv, scheme):
-    """README.md:141-157 as the real reference ran it (tests/golden/trajectories_2d.npz); 300 iterations = five launches of SMALL_BLOCK = 64
+    """README.md:141-157 as the real reference ran it (tests/golden/trajectories_2d.npz); 300 iterations = two launches of SMALL_BLOCK = 128
     iterations and a tail of 44: the state carried from launch to launch is x, p, q in memory"""
     import torch
     z = np.load(os.path.join(GOLDEN, "trajectories_2d.npz"))
@@ -179,16 +179,17 @@ def test_c_abi_argument_checks(pytv):
     geo = nv.Geometry(tuple(x.shape), "hybrid", x.dtype, x.device, 1.0, 1.0, False, 0)
     assert lib.tv_small_supported(geo.ref) == 1
     assert lib.tv_small_workspace_bytes(geo.ref, 0) == 0 and lib.tv_small_workspace_bytes(geo.ref, 8) > 0
-    ws = torch.empty(lib.tv_small_workspace_bytes(geo.ref, 8) // 8 + 1, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(lib.tv_small_workspace_bytes(geo.ref, 8) // 8 + 1, dtype=torch.float64, device="cuda")
     h = torch.zeros(16, dtype=torch.float64, device="cuda")
     st = nv.current_stream(x.device)
-    assert lib.tv_small_cp(geo.ref, None, nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 25.0, 0.1, 1.0, 8, h.data_ptr(), nv.ptr(ws), st) == -1
-    assert lib.tv_small_cp(geo.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 0.0, 0.1, 1.0, 8, h.data_ptr(), nv.ptr(ws), st) == -1
+    assert lib.tv_small_cp(geo.ref, None, nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 25.0, 0.1, 1.0, 8, h.data_ptr(), 2, 1, nv.ptr(ws), st) == -1
+    assert lib.tv_small_cp(geo.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 0.0, 0.1, 1.0, 8, h.data_ptr(), 2, 1, nv.ptr(ws), st) == -1
     assert b"lambda" in lib.tv_last_error()
-    assert lib.tv_small_cp(geo.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 25.0, 0.1, 1.0, 0, h.data_ptr(), nv.ptr(ws), st) == -1
-    assert lib.tv_small_subgrad_descent(geo.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 1e-3, 25.0, 2, h.data_ptr(), nv.ptr(ws), st) == -1
+    assert lib.tv_small_cp(geo.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 25.0, 0.1, 1.0, 0, h.data_ptr(), 2, 1, nv.ptr(ws), st) == -1
+    assert lib.tv_small_cp(geo.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 25.0, 0.1, 1.0, 2, h.data_ptr(), 2, 2, nv.ptr(ws), st) == -1         # fid offset outside the row
+    assert lib.tv_small_subgrad_descent(geo.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 1e-3, 25.0, 2, h.data_ptr(), 2, 1, nv.ptr(ws), st) == -1
     assert b"ping-pong" in lib.tv_last_error()
     # a slab of a larger volume is refused (no halos in a persistent launch)
     slab = nv.Geometry(tuple(x.shape), "hybrid", x.dtype, x.device, 1.0, 1.0, False, 0, nz_global=6, z0=3)
     assert lib.tv_small_supported(slab.ref) == 0
-    assert lib.tv_small_cp(slab.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 25.0, 0.1, 1.0, 2, h.data_ptr(), nv.ptr(ws), st) == -1
+    assert lib.tv_small_cp(slab.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 25.0, 0.1, 1.0, 2, h.data_ptr(), 2, 1, nv.ptr(ws), st) == -1

@@ -25,7 +25,7 @@ cp.run(K)
 cp.run(K)
 torch.cuda.synchronize()
 ws = cp._small_ws().cpu().numpy()
-flags_doubles = 8192 * 32 * 4 // 8
+flags_doubles = (8192 + 1) * 32 * 4 // 8
 body = ws[flags_doubles:]
 # nblocks: the partial rows are contiguous; the marks follow them.  Find nblocks from the first clock value (> 1e6) position
 pos = int(np.argmax(body > 1e9))
