@@ -516,13 +516,12 @@ template <typename T> struct SmallSgArgs {
     long long x_bytes, n_bytes;
 };
 
-// register-resident descent step (upwind, downwind, hybrid: radius-1 stencils; central takes the generic kernel): x and x0 of the site stay
+// register-resident descent step: x and x0 of the site stay
 // in registers; pass 1 loads the eight neighbours of x at once and stores 1 / |D x|; pass 2 loads the eight neighbours of 1 / |D x| at once
 // (the neighbours of x are still in registers), forms G with subgrad_site and stores the new x into the OTHER image buffer for the
 // neighbours (ping-pong: the blocks around me may still be reading the old one).
 template <int S, typename T, int V>
 __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, SmallPlan sp, SmallSgArgs<T> a) {
-    static_assert(S != CENTRAL, "radius-2 stencil: generic kernel");
     __shared__ double sm[16];
     const int L = small_logical_id(sp);
     if (L >= sp.nblocks) return;
@@ -595,7 +594,73 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, 
         const T n_tail = coh_ld1<T>(mn, at(has_tail, b, V * (int)EB)), n_head = coh_ld1<T>(mn, at(has_head, b, -(int)EB));
         ns.nc = shift_left<T, V>(nv, n_tail);
         ns.pc = shift_right<T, V>(nv, n_head);
-        Vec<T, V> G = subgrad_site<S, T, V>(g, w, n, ns, mf);
+        Vec<T, V> G;
+        if constexpr (S != CENTRAL) {
+            G = subgrad_site<S, T, V>(g, w, n, ns, mf);
+        } else {
+            // central: G(p) = 1/2 sum_a [ g_a(p-e) - g_a(p+e) ], g_a(q) = 1/2 w_a (x(q+e) - x(q-e)) / |D x|(q) at interior q: x two steps away, 1/|Dx| one
+            // step away (the expressions of sg_site_central, tv_site.h); two-point z / t axes: the forward stencil on the neighbours of pass 1
+            const T hh = T(0.5);
+            const Vec<T, V> xm2r = coh_ldv<T, V>(mxc, at(ok && y >= 2, b, -2 * d_row)), xp2r = coh_ldv<T, V>(mxc, at(ok && y + 2 < g.ny, b, 2 * d_row));
+            const Vec<T, V> xm2z = coh_ldv<T, V>(mxc, at(ok && g.za && zl >= 2, b, -2 * d_plane)), xp2z = coh_ldv<T, V>(mxc, at(ok && g.za && zl + 2 < g.nz, b, 2 * d_plane));
+            const Vec<T, V> xm2t = coh_ldv<T, V>(mxc, at(ok && g.ta && t >= 2, b, -2 * d_frame)), xp2t = coh_ldv<T, V>(mxc, at(ok && g.ta && t + 2 < g.m, b, 2 * d_frame));
+            const T x_head2 = coh_ld1<T>(mxc, at(ok && col0 >= 2, b, -2 * (int)EB)), x_tail2 = coh_ld1<T>(mxc, at(ok && col0 + V + 1 < g.nx, b, (V + 1) * (int)EB));
+            const Vec<T, V>& xc = n.c;
+            Vec<T, V> r = zero;
+            auto cen = [&](int pos, int cnt, const Vec<T, V>& xm2, const Vec<T, V>& xp2, const Vec<T, V>& nm1, const Vec<T, V>& np1, T wa, bool weighted, bool timeax) {
+                if (pos - 1 > 0 && pos - 1 < cnt - 1) {
+                    Vec<T, V> d = xc - xm2;
+                    if (weighted) d = wa * d;
+                    if (timeax) d = d * mf;
+                    d = hh * d;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) r.v[i] += d.v[i] * nm1.v[i];
+                }
+                if (pos + 1 > 0 && pos + 1 < cnt - 1) {
+                    Vec<T, V> d = xp2 - xc;
+                    if (weighted) d = wa * d;
+                    if (timeax) d = d * mf;
+                    d = hh * d;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] * np1.v[i];
+                }
+            };
+            auto fwd = [&](int pos, int cnt, const Vec<T, V>& xm1, const Vec<T, V>& xp1, const Vec<T, V>& nm1, const Vec<T, V>& n0, T wa, bool timeax) {
+                if (pos >= 1) {
+                    Vec<T, V> d = wa * (xc - xm1);
+                    if (timeax) d = d * mf;
+                    d = hh * d;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) r.v[i] += d.v[i] * nm1.v[i];
+                }
+                if (pos <= cnt - 2) {
+                    Vec<T, V> d = wa * (xp1 - xc);
+                    if (timeax) d = d * mf;
+                    d = hh * d;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] * n0.v[i];
+                }
+            };
+            cen(y, g.ny, xm2r, xp2r, ns.pr, ns.nr, T(1), false, false);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const int col = col0 + i;
+                const T xl2 = (i >= 2) ? xc.v[(i >= 2) ? i - 2 : 0] : ((i == 1) ? x_head : x_head2);          // x(col - 2)
+                const T xr2 = (i + 2 < V) ? xc.v[(i + 2 < V) ? i + 2 : 0] : ((i + 2 == V) ? x_tail : x_tail2);   // x(col + 2)
+                const T nl = (i >= 1) ? nv.v[(i >= 1) ? i - 1 : 0] : n_head, nr_ = (i + 1 < V) ? nv.v[(i + 1 < V) ? i + 1 : 0] : n_tail;
+                if (col - 1 > 0 && col - 1 < g.nx - 1) r.v[i] += (hh * (xc.v[i] - xl2)) * nl;
+                if (col + 1 > 0 && col + 1 < g.nx - 1) r.v[i] -= (hh * (xr2 - xc.v[i])) * nr_;
+            }
+            if (g.za) {
+                if (g.z_two) fwd(zl, g.nzg, n.pz, n.nz, ns.pz, nv, w.wz, false);
+                else cen(zl, g.nzg, xm2z, xp2z, ns.pz, ns.nz, w.wz, true, false);
+            }
+            if (g.ta) {
+                if (g.t_two) fwd(t, g.m, n.pt, n.nt, ns.pt, nv, w.wt, true);
+                else cen(t, g.m, xm2t, xp2t, ns.pt, ns.nt, w.wt, true, true);
+            }
+            G = hh * r;
+        }
         zero_pad_cols<T, V>(g, col0, G);
         acc = 0.0;
 #pragma unroll
@@ -839,10 +904,8 @@ int tv_small_subgrad_descent(const tv_geom* g, void* x, void* x_alt, const void*
         SmallPlan sp;
         int threads = kSmallThreads;
         bool flat = false;
-        if constexpr (S != CENTRAL) {
-            kern = (const void*)k_small_sg_reg<S, T, V>;
-            flat = small_plan_flat(d, V, kern, sp, threads);
-        }
+        kern = (const void*)k_small_sg_reg<S, T, V>;
+        flat = small_plan_flat(d, V, kern, sp, threads);
         if (!flat) {
             kern = (const void*)k_small_sg<S, T, V>;
             threads = kSmallThreads;

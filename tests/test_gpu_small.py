@@ -61,8 +61,6 @@ def test_persistent_cp_matches_oracle(pytv, scheme, shape, lz, mu, use_mask, gen
 def test_persistent_descent_matches_oracle(pytv, scheme, shape, lz, mu, use_mask, generic):
     import torch
     from pytv import _native as nv
-    if scheme == "central" and (shape[0] == 2 or shape[1] == 2):
-        pytest.skip("central with a two-point axis: the two-pass form of the ordinary path pins it (test_gpu_parity.py)")
     rng = np.random.default_rng(4)
     mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
     kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=4.0 if use_mask else 0)
