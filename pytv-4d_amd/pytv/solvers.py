@@ -144,7 +144,8 @@ class _SlabProblem:
         self._geoms[(0, nz)] = self.geo
 
     # ---- persistent small-volume loops (round 6; csrc/tv_small.hip) ------------------------------------------------------------------
-    SMALL_MAX_VOXELS = 2 << 20      # the automatic rule: volumes of at most 2 Mvoxel (the reference's own shapes hold 0.07 - 1) take it
+    SMALL_MAX_VOXELS = 4 << 20      # the automatic rule: volumes of at most 4 Mvoxel take it (the reference's own shapes hold 0.07 - 1; measured against
+                                    # the kernel pair / one-pass kernel from hipGraphs: x 2.5 - 3.7 up to 1 Mvoxel, x 1.5 - 2.2 at 4, x 1.0 - 1.1 at 9: profiles/r6_small_volume_larger.txt)
     SMALL_BLOCK = 128               # iterations per cooperative launch
 
     def _small_ok(self, persistent):

@@ -147,7 +147,8 @@ def test_readme_shape_persistent_equals_the_kernel_pair(pytv, scheme):
 def test_automatic_rule_and_explicit_requests(pytv):
     import torch
     x_small = torch.rand((4, 2, 32, 32), device="cuda")
-    x_mid = torch.rand((9, 4, 256, 256), device="cuda")          # 2.36 Mvoxel: above SMALL_MAX_VOXELS
+    x_mid = torch.rand((20, 4, 256, 256), device="cuda")         # 5.2 Mvoxel: above SMALL_MAX_VOXELS (and above the library's TV_SMALL_MAX_KVOXELS)
+    x_2m = torch.rand((9, 4, 256, 256), device="cuda")           # 2.4 Mvoxel: the generic form of the persistent kernels
     kw = dict(reg_time=1.0)
     assert pytv.solvers.ChambollePock(x_small, 1.0, **kw).small
     assert pytv.solvers.SubgradientDescent(x_small, 1.0, 1e-3, **kw).small
@@ -156,7 +157,9 @@ def test_automatic_rule_and_explicit_requests(pytv):
     assert not pytv.solvers.ChambollePock(x_small, 1.0, fused=False, **kw).small              # an explicit kernel family is kept
     assert not pytv.solvers.SubgradientDescent(x_small, 1.0, 1e-3, one_pass=True, **kw).small
     assert not pytv.solvers.ChambollePock(x_small, 1.0, persistent=False, **kw).small
-    assert pytv.solvers.ChambollePock(x_mid, 1.0, persistent=True, **kw).small               # still inside tv_small_supported
+    assert pytv.solvers.ChambollePock(x_2m, 1.0, **kw).small and pytv.solvers.SubgradientDescent(x_2m, 1.0, 1e-3, **kw).small
+    with pytest.raises(ValueError):
+        pytv.solvers.ChambollePock(x_mid, 1.0, persistent=True, **kw)                        # outside tv_small_supported
     # run_steps and step share the state: persistent blocks and single kernel-pair steps can be mixed
     cp = pytv.solvers.ChambollePock(x_small * 100, 25.0, **kw)
     ref = pytv.solvers.ChambollePock(x_small * 100, 25.0, persistent=False, fused=False, **kw)
