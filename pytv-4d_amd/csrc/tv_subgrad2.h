@@ -114,6 +114,29 @@ __device__ __forceinline__ void sg2_st(Rsrc r, unsigned off, double v) {
     w.y = (int)(b >> 32);
     __builtin_amdgcn_raw_buffer_store_b64(w, r, (int)off, 0, SG2_AUX_S);
 }
+// A frame of a plane as the kernel addresses it: a descriptor per frame (so = 0), or -- TV_SG2_PLANE_DESC, a round-6 experiment that
+// removed 70 scalar instructions per plane step and gained nothing -- ONE descriptor per plane and stream + the frame's byte offset as the
+// instruction's scalar offset (the descriptor spans the whole plane, so it does not matter whether the hardware counts the scalar offset in
+// its range check; a lane that must not take part still has the offset 2^31 >= num_records; time windows keep a descriptor per frame).
+struct SgFrame { Rsrc r; int so; };
+__device__ __forceinline__ float sg2_ld(const SgFrame& f, unsigned off, float) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(f.r, (int)off, f.so, 0)); }
+__device__ __forceinline__ double sg2_ld(const SgFrame& f, unsigned off, double) {
+    const sg2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(f.r, (int)off, f.so, 0);
+    return __longlong_as_double(((long long)v.y << 32) | (unsigned)v.x);
+}
+__device__ __forceinline__ float sg2_ld_s(const SgFrame& f, unsigned off, float) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(f.r, (int)off, f.so, SG2_AUX_L)); }
+__device__ __forceinline__ double sg2_ld_s(const SgFrame& f, unsigned off, double) {
+    const sg2_v2i v = __builtin_amdgcn_raw_buffer_load_b64(f.r, (int)off, f.so, SG2_AUX_L);
+    return __longlong_as_double(((long long)v.y << 32) | (unsigned)v.x);
+}
+__device__ __forceinline__ void sg2_st(const SgFrame& f, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), f.r, (int)off, f.so, SG2_AUX_S); }
+__device__ __forceinline__ void sg2_st(const SgFrame& f, unsigned off, double v) {
+    const long long b = __double_as_longlong(v);
+    sg2_v2i w;
+    w.x = (int)b;
+    w.y = (int)(b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(w, f.r, (int)off, f.so, SG2_AUX_S);
+}
 template <typename T> __device__ __forceinline__ void pin1(T& a);
 template <> __device__ __forceinline__ void pin1<float>(float& a) { asm volatile("" : "+v"(a)); }
 template <> __device__ __forceinline__ void pin1<double>(double& a) { asm volatile("" : "+v"(a)); }
@@ -144,6 +167,10 @@ constexpr int SG2_TWN = 8, SG2_TWU = SG2_TWN - 2;      // time windows for M > 8
 #endif
 #ifndef TV_SG2_X0_AHEAD
 #define TV_SG2_X0_AHEAD 1
+#endif
+#ifndef TV_SG2_PLANE_DESC
+#define TV_SG2_PLANE_DESC 0    // 1: EXPERIMENT (round 6) -- one buffer descriptor per plane and stream, the frame as the scalar offset: 70 scalar instructions fewer per
+                               // plane step (1806 -> 1736) and NO gain (hybrid 1.418 -> 1.428 ms, profiles/r6_sg_plane_desc_ab.txt): scalar instructions are not what the SIMD waits for
 #endif
 #ifndef TV_SG2_PRIO
 #define TV_SG2_PRIO 0          // 1 .. 3: EXPERIMENT (round 6) -- alternate the issue priority of the two waves of a SIMD frame by frame
@@ -366,8 +393,13 @@ struct SgCol {
         const T m_hu = (wv == 0) ? T(1) : T(0), m_hd = (wv == NW - 1) ? T(1) : T(0);
         double acc = 0.0, acc_fid = 0.0;
 
-        auto frame = [&](const T* plane, int t) { return sg2_rsrc<T>(plane + foff_t(t), plane != nullptr && fvalid(t), fbytes); };
-        auto load_rows = [&](Rsrc r, C& o) {
+        // frame t of the window inside the plane that starts at `plane0` (frame 0 of the VOLUME): see SgFrame
+        auto fr = [&](const T* plane0, bool valid, int t) -> SgFrame {
+            if constexpr (TWIN || !TV_SG2_PLANE_DESC) return SgFrame{sg2_rsrc<T>(plane0 + foff_t(t), valid, fbytes), 0};
+            else return SgFrame{sg2_rsrc<T>(plane0, valid, fbytes * M), t * fbytes};
+        };
+        auto frame = [&](const T* plane, int t) { return fr(plane, plane != nullptr && fvalid(t), t); };
+        auto load_rows = [&](const SgFrame& r, C& o) {
 #pragma unroll
             for (int i = 0; i < R; ++i) o.v[i] = sg2_ld(r, roff[i], T(0));
         };
@@ -476,7 +508,7 @@ struct SgCol {
             }
             C x0q;                                  // MODE 1: x0 of the frame about to be stored, requested a frame ahead
             if (MODE == 1 && TV_SG2_X0_AHEAD) {
-                const Rsrc r0 = sg2_rsrc<T>(sa.x0 + (long long)(zl - 1) * g.s_z + foff_t(0), store && fstore(0), fbytes);
+                const SgFrame r0 = fr(sa.x0 + (long long)(zl - 1) * g.s_z, store && fstore(0), 0);
 #pragma unroll
                 for (int i = 0; i < R; ++i) x0q.v[i] = sg2_ld_s(r0, soff[i], T(0));
             }
@@ -587,7 +619,7 @@ struct SgCol {
                 }
                 C x0n;
                 if (MODE == 1 && TV_SG2_X0_AHEAD && t + 1 < M) {
-                    const Rsrc r0 = sg2_rsrc<T>(sa.x0 + (long long)(zl - 1) * g.s_z + foff_t(t + 1), store && fstore(t + 1), fbytes);
+                    const SgFrame r0 = fr(sa.x0 + (long long)(zl - 1) * g.s_z, store && fstore(t + 1), t + 1);
 #pragma unroll
                     for (int i = 0; i < R; ++i) x0n.v[i] = sg2_ld(r0, soff[i], T(0));
                 }
@@ -644,9 +676,9 @@ struct SgCol {
                 else { has_tn = fvalid(t) && (t0 + t + 1 < Mg); has_tp = fvalid(t) && (t0 + t > 0); }
                 C xtn, xtp = c_old_prev;    // x(zl, t+1), x(zl, t-1)
                 if (t + 1 < M) xtn = Cc[(t + 1 < M) ? t + 1 : t];
-                else if (TWIN) load_rows(sg2_rsrc<T>(pc + foff_t(t + 1), pc != nullptr && has_tn, fbytes), xtn);
+                else if (TWIN) load_rows(SgFrame{sg2_rsrc<T>(pc + foff_t(t + 1), pc != nullptr && has_tn, fbytes), 0}, xtn);
                 else xtn = c;
-                if (TWIN && t == 0 && (CEN || DN)) load_rows(sg2_rsrc<T>(pc + foff_t(-1), pc != nullptr && has_tp, fbytes), xtp);
+                if (TWIN && t == 0 && (CEN || DN)) load_rows(SgFrame{sg2_rsrc<T>(pc + foff_t(-1), pc != nullptr && has_tp, fbytes), 0}, xtp);
                 // per-VOXEL weight of the time channels (tv_geom::time_weight_vol; generic variant only -- with a weight volume no
                 // tile is FAST): the factor of THIS voxel scales its forward AND its backward channel, so the backward one is no
                 // longer the forward one of frame t-1 and the carry is the unweighted difference.  No volume: a descriptor with
@@ -714,8 +746,8 @@ struct SgCol {
                 {
                     const bool cnt = count && fstore(t);
                     T sum = T(0);
-                    Rsrc rn_rs;
-                    if (MODE == 2) rn_rs = sg2_rsrc<T>(sa.norms + (long long)zl * g.s_z + foff_t(t), cnt, fbytes);
+                    SgFrame rn_rs{};
+                    if (MODE == 2) rn_rs = fr(sa.norms + (long long)zl * g.s_z, cnt, t);
 #pragma unroll
                     for (int i = 0; i < R; ++i) {
                         const T rn = ss.v[i] * n.v[i];
@@ -856,13 +888,13 @@ struct SgCol {
                         if (DN || CEN) yd_n = ye[par ^ 1][(t + 1 < M) ? t + 1 : t][r_dn][lane];
                     }
                     if (MODE != 1) {
-                        const Rsrc rg = sg2_rsrc<T>(G + foff, st, fbytes);
+                        const SgFrame rg = fr(G + (long long)(zl - 1) * g.s_z, st, t);
 #pragma unroll
                         for (int i = 0; i < R; ++i) sg2_st(rg, soff[i], TV_SG2_COPYONLY ? c.v[i] : s * Gp[t].v[i]);
                     } else {
-                        const Rsrc ro = sg2_rsrc<T>(sa.x_out + foff, st, fbytes);
+                        const SgFrame ro = fr(sa.x_out + (long long)(zl - 1) * g.s_z, st, t);
                         if (!TV_SG2_X0_AHEAD) {
-                            const Rsrc r0 = sg2_rsrc<T>(sa.x0 + foff, st, fbytes);
+                            const SgFrame r0 = fr(sa.x0 + (long long)(zl - 1) * g.s_z, st, t);
 #pragma unroll
                             for (int i = 0; i < R; ++i) x0q.v[i] = sg2_ld_s(r0, soff[i], T(0));
                         }

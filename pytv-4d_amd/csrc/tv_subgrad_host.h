@@ -19,6 +19,11 @@ inline int sg_supported(const tv_geom* g) {
     if (!k2) return 0;              // frames of 2^31 bytes and more: the two-pass path (the round-1 kernel that took them is a variant build now)
     if (g->scheme == TV_CENTRAL && ((d.za && d.z_two) || (d.ta && d.t_two))) return 0;   // two-point axes: forward stencil
     if (d.s_t > (1ll << 30)) return 0;                           // 32-bit per-lane byte offsets inside a frame
+#if TV_SG2_PLANE_DESC
+    // one buffer descriptor per PLANE (experiment): the plane's M frames must stay below 2^31 bytes (num_records is 32-bit and the "not my lane" offset 2^31
+    // must lie outside it); larger planes take the two-pass kernels
+    if (d.m <= SG2_TWN && d.s_t * (long long)(g->dtype == TV_F32 ? 4 : 8) * d.m >= (1ll << 31)) return 0;
+#endif
     if (d.m > SG2_TWN && env_int("TV_NO_FUSED_TWIN", 0)) return 0;
     if (env_int("TV_NO_FUSED_SUBGRAD", 0)) return 0;
     return 1;
