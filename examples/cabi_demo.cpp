@@ -1,7 +1,7 @@
 // cabi_demo.cpp -- the drop-in boundary used WITHOUT Python or PyTorch: plain hipMalloc'd buffers, include/pytv4d.h,
 // libpytv4d_hip.so.  Checks <D x, y> == <x, D^T y> (the reference's own adjointness test, pytv/tests.py:363-404) on the
 // GPU results and runs a few Chambolle-Pock iterations (README.md:145-157) through tv_cp_dual / tv_cp_primal and through
-// the one-sweep pair tv_cp_fused / tv_cp_fixup, which must produce the same loss.
+// the one-sweep pair tv_cp_fused / tv_cp_fixup, which must produce the same loss -- and through the persistent loop tv_small_cp.
 //
 //   hipcc -O2 -Iinclude examples/cabi_demo.cpp -Lpytv-4d_amd/pytv -lpytv4d_hip -Wl,-rpath,$PWD/pytv-4d_amd/pytv -o /tmp/cabi_demo
 #include <hip/hip_runtime.h>
@@ -101,6 +101,31 @@ int main() {
     }
     for (int it = 0; it < 5; ++it)
         if (fabs(loss[0][it] - loss[1][it]) > 1e-5 * fabs(loss[0][it])) { fprintf(stderr, "the two CP paths disagree at iteration %d\n", it); return 1; }
+    // ---- the same five iterations as ONE persistent launch (round 6: tv_small_cp, volumes that fit the caches) ---------------------------
+    if (tv_small_supported(&g)) {
+        float *xs = to_device(hx0), *x0 = to_device(hx0), *p = nullptr, *q = nullptr;
+        void* wss = nullptr;
+        double* hist = nullptr;              // device: (5, 2) = TV of the iterate each iteration saw, 1/2 |x_new - x0|^2
+        const size_t wsb_small = tv_small_workspace_bytes(&g, 5);
+        HIP_OK(hipMalloc(&p, V * sizeof(float)));
+        HIP_OK(hipMalloc(&q, VD * sizeof(float)));
+        HIP_OK(hipMalloc(&wss, wsb_small));
+        HIP_OK(hipMalloc(&hist, 10 * sizeof(double)));
+        HIP_OK(hipMemset(p, 0, V * sizeof(float)));
+        HIP_OK(hipMemset(q, 0, VD * sizeof(float)));
+        HIP_OK(hipMemset(wss, 0, wsb_small));                 // ONCE: the block flags continue from call to call
+        TV_OK(tv_small_cp(&g, xs, x0, p, q, sigma_D, lambda, tau, sigma_A, 3, hist, 2, 1, wss, st));          // three iterations ...
+        TV_OK(tv_small_cp(&g, xs, x0, p, q, sigma_D, lambda, tau, sigma_A, 2, hist + 6, 2, 1, wss, st));      // ... and two more on the same state
+        double hh[10];
+        HIP_OK(hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        printf("%-22s loss: %.6e -> %.6e\n", "tv_small_cp (2 calls)", hh[1] + lambda * hh[0], hh[9] + lambda * hh[8]);
+        for (int it = 0; it < 5; ++it) {
+            const double l = hh[2 * it + 1] + lambda * hh[2 * it];
+            if (fabs(l - loss[0][it]) > 1e-5 * fabs(loss[0][it])) { fprintf(stderr, "the persistent loop disagrees with the kernel pair at iteration %d\n", it); return 1; }
+        }
+        for (void* b : {(void*)xs, (void*)x0, (void*)p, (void*)q, wss, (void*)hist}) (void)hipFree(b);
+    }
     // ---- sharding from C++: the multi-GPU surface (tv_ctx_*, RCCL underneath) ----------------------------------------------
     // A host with one process per GPU gives every rank a z-slab (tv_geom::z0 / nz_global) and trades boundary planes with
     // tv_halo_exchange.  This box has one GPU, so the one rank here plays BOTH neighbours of a two-slab split: slab A =

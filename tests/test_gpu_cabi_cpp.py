@@ -23,3 +23,4 @@ def test_cabi_demo_builds_and_runs(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "cabi_demo: OK" in out.stdout
+    assert "tv_small_cp (2 calls)" in out.stdout          # the persistent loop from C++: two calls on one workspace == five kernel-pair iterations
