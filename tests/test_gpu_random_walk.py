@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("tool,n,last", [
     ("stress_ops.py", "160", "cases 160, mismatches 0"),           # every entry point against the oracle
     ("stress_subgrad.py", "80", "mismatches 0"),                   # one-pass sub-gradient against the two-pass kernels, twice (bitwise determinism)
+    ("stress_small.py", "96", "mismatches 0"),                     # persistent small-volume loops (round 6) against the per-iteration kernels, twice
 ])
 def test_random_walk_over_the_dispatch_matches_the_oracle(tool, n, last):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "pytv-4d_amd"), ROOT, os.environ.get("PYTHONPATH", "")]))
