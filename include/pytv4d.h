@@ -340,6 +340,9 @@ int tv_subgrad_step(const tv_geom* g, void* x, const void* x0, const void* G, do
  *   tv_small_workspace_bytes : bytes of the scratch buffer `ws` for n_iter iterations per launch (block flags + per-block partials).
  *                              `ws` must be ZERO-FILLED once before its first use (hipMemset); the calls keep it consistent afterwards
  *                              (the blocks' phase counters continue from call to call: no reset per launch).  One `ws` per stream.
+ *                              Safety net: should the blocks of a launch not all become resident (they wait for each other), the launch
+ *                              abandons itself after ~2 s of polling instead of hanging: every hist entry of the call is NaN, the state
+ *                              arrays are undefined and `ws` must be zero-filled again.
  *   tv_small_cp              : n_iter iterations of  p <- (p + sigma_A (x - x0)) / (1 + sigma_A);  q <- proj(q + sigma_D D x);
  *                              x <- x - tau p - tau D^T q  exactly as tv_cp_dual + tv_cp_primal compute them, x / p / q updated in
  *                              place.  hist (device fp64): hist[k * hist_stride] = |D x_k|_{2,1} (the iterate the dual update of

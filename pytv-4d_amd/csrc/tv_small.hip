@@ -100,18 +100,34 @@ __device__ __forceinline__ int small_dependency(const DG& g, const SmallPlan& sp
     return owner == L ? -1 : owner;
 }
 
-// end of a phase: my stores are performed, my flag says so, my neighbours' flags say the same
-__device__ __forceinline__ void small_sync(unsigned* flags, int L, int dep, unsigned epoch) {
+// end of a phase: my stores are performed, my flag says so, my neighbours' flags say the same.
+// SAFETY NET: the blocks of a launch wait for each other, so all of them must be resident at once.  The launch is cooperative and the
+// grid is kept to half the wave slots of the chip (small_capacity: hipLaunchCooperativeKernel accepted 7 blocks of 256 threads per CU that
+// the hardware then did not keep resident together -- a hang, round 6); should a wait still not end within ~2 s of polling, the block
+// raises the ABORT word of the workspace, every block that sees it leaves its iteration loop, the closing reduction turns the whole
+// history into NaN and the host fails loudly instead of hanging the GPU.  Returns true when the launch is being abandoned.
+constexpr unsigned kSmallSpinLimit = 1u << 21;
+__device__ __forceinline__ unsigned* small_abort_word(unsigned* flags) { return flags + (long long)kMaxSmallBlocks * kFlagStride + 1; }
+__device__ __forceinline__ bool small_sync(unsigned* flags, int L, int dep, unsigned epoch, int* sh_abort) {
     __builtin_amdgcn_s_waitcnt(0);              // vmcnt(0): this wave's (write-through) stores have been acknowledged
     __syncthreads();
     if (threadIdx.x < 64) {
         if (threadIdx.x == 0) __hip_atomic_store(flags + (long long)L * kFlagStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dep >= 0) {
             const unsigned* f = flags + (long long)dep * kFlagStride;
-            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) __builtin_amdgcn_s_sleep(1);      // (wrap-safe)
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {      // (wrap-safe)
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0 && (spins >= kSmallSpinLimit || __hip_atomic_load(small_abort_word(flags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(small_abort_word(flags), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *sh_abort = 1;
+                    break;
+                }
+            }
         }
     }
     __syncthreads();
+    return *sh_abort != 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -197,6 +213,8 @@ template <typename T> struct SmallCpArgs {
 template <int S, typename T, int V>
 __global__ __launch_bounds__(kSmallThreads) void k_small_cp(DG g, WT<T> w, SmallPlan sp, SmallCpArgs<T> a) {
     __shared__ double sm[16];
+    __shared__ int sh_abort;
+    if (threadIdx.x == 0) sh_abort = 0;
     const int L = small_logical_id(sp);
     if (L >= sp.nblocks) return;
     const int dep = small_dependency(g, sp, L, (int)threadIdx.x);
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_cp(DG g, WT<T> w, Small
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
         TV_SMALL_MARK(1);
-        small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1));
+        if (small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1), &sh_abort)) break;
         TV_SMALL_MARK(2);
         // ---- primal: p <- (p + sigma_A (x - x0)) / (1 + sigma_A); x <- x - tau p - tau D^T q; 1/2 |x - x0|^2 (README.md:148,154,157)
         acc = 0.0;
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_cp(DG g, WT<T> w, Small
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
         TV_SMALL_MARK(3);
-        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2));
+        if (it + 1 < a.n_iter && small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2), &sh_abort)) break;
         TV_SMALL_MARK(4);
     }
 }
@@ -326,6 +344,8 @@ __device__ __forceinline__ int small_dependency_flat(const DG& g, const SmallPla
 template <int S, typename T, int V>
 __global__ __launch_bounds__(kRegMaxThreads) void k_small_cp_reg(DG g, WT<T> w, SmallPlan sp, SmallCpArgs<T> a) {
     __shared__ double sm[16];
+    __shared__ int sh_abort;
+    if (threadIdx.x == 0) sh_abort = 0;
     const int L = small_logical_id(sp);
     if (L >= sp.nblocks) return;
     constexpr int NS = (S == HYBRID) ? 8 : 4;
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_cp_reg(DG g, WT<T> w, 
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
         TV_SMALL_MARK(1);
-        small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1));
+        if (small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1), &sh_abort)) break;
         TV_SMALL_MARK(2);
         // ---- primal: p <- (p + sigma_A (x - x0)) / (1 + sigma_A); x <- x - tau p - tau D^T q (README.md:148,154): every neighbour of q at once
         asm volatile("" : "+v"(bx), "+v"(bq));
@@ -498,7 +518,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_cp_reg(DG g, WT<T> w, 
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
         TV_SMALL_MARK(3);
-        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2));
+        if (it + 1 < a.n_iter && small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2), &sh_abort)) break;
         TV_SMALL_MARK(4);
     }
     if (ok) vstore<T, V>(a.p + offx, p);
@@ -523,6 +543,8 @@ template <typename T> struct SmallSgArgs {
 template <int S, typename T, int V>
 __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, SmallPlan sp, SmallSgArgs<T> a) {
     __shared__ double sm[16];
+    __shared__ int sh_abort;
+    if (threadIdx.x == 0) sh_abort = 0;
     const int L = small_logical_id(sp);
     if (L >= sp.nblocks) return;
     constexpr unsigned EB = sizeof(T);
@@ -584,7 +606,7 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, 
         coh_stv<T, V>(mn, at(ok, b, 0), nv);
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
-        small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1));
+        if (small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1), &sh_abort)) break;
         // ---- pass 2: G from x and 1 / |D x| (pytv/tv_GPU.py:91-124), x <- x - step ((x - x0) + lambda G) (README.md:122-123)
         asm volatile("" : "+v"(b));
         ns.c = nv;
@@ -674,13 +696,15 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, 
         coh_stv<T, V>(mxo, at(ok, b, 0), x);
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
-        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2));
+        if (it + 1 < a.n_iter && small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2), &sh_abort)) break;
     }
 }
 
 template <int S, typename T, int V>
 __global__ __launch_bounds__(kSmallThreads) void k_small_sg(DG g, WT<T> w, SmallPlan sp, SmallSgArgs<T> a) {
     __shared__ double sm[16];
+    __shared__ int sh_abort;
+    if (threadIdx.x == 0) sh_abort = 0;
     const int L = small_logical_id(sp);
     if (L >= sp.nblocks) return;
     const int dep = small_dependency(g, sp, L, (int)threadIdx.x);
@@ -700,7 +724,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_sg(DG g, WT<T> w, Small
         }
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
-        small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1));
+        if (small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1), &sh_abort)) break;
         // ---- pass 2: G from x and 1 / |D x| (pytv/tv_GPU.py:91-124), x <- x - step ((x - x0) + lambda G) (README.md:122-123)
         acc = 0.0;
         for (int vb = vb0; vb < vb1; ++vb) {
@@ -724,7 +748,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_sg(DG g, WT<T> w, Small
         }
         acc = block_sum(acc, sm);
         if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
-        if (it + 1 < a.n_iter) small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2));
+        if (it + 1 < a.n_iter && small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2), &sh_abort)) break;
     }
 }
 
@@ -738,6 +762,7 @@ __global__ __launch_bounds__(256) void k_small_reduce(const double* partials, in
     for (int i = (int)threadIdx.x; i < nblocks; i += 256) acc += p[i];
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) {
+        if (*small_abort_word(flags) != 0) acc = __builtin_nan("");          // the launch was abandoned (small_sync): no number is valid
         hist[(long long)(blockIdx.x >> 1) * stride + ((blockIdx.x & 1) ? fid_offset : 0)] = acc;
         if (blockIdx.x == 0) flags[(long long)kMaxSmallBlocks * kFlagStride] += advance;
     }
@@ -749,7 +774,10 @@ static int small_capacity(const void* kernel) {
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kSmallThreads, 0) != hipSuccess) return 0;
-    const int cap_opt = env_int("TV_SMALL_BLOCKS_PER_CU", 8);
+    // at most 4 blocks of 256 threads per CU = 16 waves, half of a CU's wave slots (the register-resident plans keep the same bound): the occupancy
+    // query allows 7 - 8 for the scalar-lane instantiations and hipLaunchCooperativeKernel accepts them, but 7 per CU were observed NOT to be resident
+    // together (1764 blocks: the launch hung; 6 per CU ran) -- and more blocks per CU buy nothing here (profiles/r6_small_volume_v2: 8 = 4)
+    const int cap_opt = env_int("TV_SMALL_BLOCKS_PER_CU", 4);
     if (per_cu > cap_opt) per_cu = cap_opt;
     return per_cu * cus;
 }

@@ -166,6 +166,15 @@ class _SlabProblem:
             self._small_ws_buf = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
         return self._small_ws_buf
 
+    def _small_check(self, loss):
+        """the persistent kernels abandon a launch whose blocks cannot all run at once instead of hanging (csrc/tv_small.hip, small_sync): NaN history"""
+        import numpy as _np
+        if not _np.all(_np.isfinite(loss)):
+            self._small_ws_buf = None
+            raise RuntimeError("the persistent small-volume kernel returned a non-finite loss: either the iteration diverged or the launch was abandoned "
+                               "(its blocks were not resident together); construct the solver with persistent=False or lower TV_SMALL_BLOCKS_PER_CU")
+        return loss
+
     def geom(self, a, b):
         """Geometry of local planes [a, b) seen as a slab of the global volume."""
         key = (a, b)
@@ -807,7 +816,8 @@ class ChambollePock(_SlabProblem):
         if not record_loss:
             return None
         self.slab.allreduce_sum_(hist)
-        return self.loss_from_slots(hist.cpu().numpy(), self.reg)
+        loss = self.loss_from_slots(hist.cpu().numpy(), self.reg)
+        return self._small_check(loss) if self.small else loss
 
     def run_steps(self, rows):
         """Enqueue ``len(rows)`` iterations, row k of the (n, SLOTS) fp64 device tensor ``rows`` receiving the scalars of iteration k.
@@ -1185,7 +1195,7 @@ class SubgradientDescent(_SlabProblem):
         hist = torch.zeros((n_iter, self.SLOTS), dtype=torch.float64, device=self.device)
         if self.small and graph is None:
             self._run_small(hist)
-            return self.loss_from_slots(hist.cpu().numpy(), self.reg)
+            return self._small_check(self.loss_from_slots(hist.cpu().numpy(), self.reg))
         use_graph = (self.x0.numel() <= self.GRAPH_MAX_VOXELS) if graph is None else bool(graph)
         start = 0
         if use_graph and not self.slab.sharded and n_iter >= 2 + 2 * self.GRAPH_BLOCK:

@@ -24,6 +24,8 @@ for case in range(n_cases):
     generic = bool(rng.random() < 0.35)
     n_it = int(rng.choice([1, 2, 7, 16, 33]))
     x0 = torch.as_tensor((rng.standard_normal((nz, m, ny, nx)) * 30 + 50).astype(dtype)).cuda()
+    if os.environ.get("STRESS_VERBOSE"):
+        print("case", case, scheme, tuple(x0.shape), dtype.__name__, lz, mu, use_mask, pitch, "generic" if generic else "registers", n_it, flush=True)
     nv.set_option("TV_SMALL_GENERIC", 1 if generic else None)
     try:
         tol = 1e-9 if dtype == np.float64 else 2e-5
