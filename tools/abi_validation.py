@@ -8,7 +8,12 @@ import itertools
 import os
 import sys
 
+import re
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the interface version of the header in the tree (a struct stamped with another number is refused by every entry point: the checks
+# below would then "pass" for the wrong reason -- round 6 found this file still stamping 4 after the bump to 5)
+ABI_VERSION = int(re.search(r"#define TV_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "pytv4d.h")).read()).group(1))
 LIB = os.environ.get("PYTV4D_LIB") or os.path.join(ROOT, "pytv-4d_amd", "pytv", "libpytv4d_hip.so")
 
 
@@ -23,7 +28,7 @@ class TvGeom(ctypes.Structure):
 
 def geom(nz=4, m=3, ny=8, nx=16, scheme=3, dtype=0, nzg=None, z0=0, lz=1.0, mu=1.0, factor=0.0):
     g = TvGeom()
-    g.struct_size, g.abi_version = ctypes.sizeof(TvGeom), 4
+    g.struct_size, g.abi_version = ctypes.sizeof(TvGeom), ABI_VERSION
     g.nz, g.m, g.ny, g.nx, g.nz_global, g.z0 = nz, m, ny, nx, (nz if nzg is None else nzg), z0
     g.scheme, g.dtype, g.reg_z_over_reg, g.reg_time, g.factor_reg_static = scheme, dtype, lz, mu, factor
     return g
@@ -43,7 +48,7 @@ def main():
         assert rc < 0, "%s: expected an argument error, got %d" % (what, rc)
         assert msg and len(msg) > 3, what
 
-    assert lib.tv_version() >= 300 and lib.tv_abi_version() == 4
+    assert lib.tv_version() >= 300 and lib.tv_abi_version() == ABI_VERSION
     # ---- geometry rules: channel counts and workspace for many shapes / schemes / weights
     for nz, m, ny, nx, scheme, dtype, lz, mu in itertools.product((1, 2, 7, 300), (1, 2, 9, 16), (1, 5, 1024), (2, 64, 1028),
                                                                   range(4), (0, 1), (0.0, 1.5), (0.0, 0.3)):
@@ -103,6 +108,10 @@ def main():
         "tv_cg_step1": lambda G, x: lib.tv_cg_step1(G, x, x, x, x, dp if x else N, dp, dp, x, N),
         "tv_cg_step2": lambda G, x: lib.tv_cg_step2(G, x, x, dp if x else N, dp, N),
         "tv_dot": lambda G, x: lib.tv_dot(G, x, x, dp if x else N, x, N),
+        "tv_small_cp": lambda G, x: lib.tv_small_cp(G, x, x, x, x, ctypes.c_double(.5), ctypes.c_double(25.), ctypes.c_double(.1), ctypes.c_double(1.), ctypes.c_int64(4),
+                                                    dp if x else N, ctypes.c_int64(2), ctypes.c_int64(1), x, N),
+        "tv_small_subgrad_descent": lambda G, x: lib.tv_small_subgrad_descent(G, x, N, x, x, ctypes.c_double(.01), ctypes.c_double(25.), ctypes.c_int64(4), dp if x else N,
+                                                                              ctypes.c_int64(2), ctypes.c_int64(1), x, N),
         "tv_subgrad_step": lambda G, x: lib.tv_subgrad_step(G, x, x, x, ctypes.c_double(.1), ctypes.c_double(1.), dp if x else N, x, N),
     }
     halo_ops = ("tv_D", "tv_DT", "tv_DT_axpy", "tv_subgrad", "tv_subgrad_fused", "tv_subgrad_fused_norms", "tv_cp_dual", "tv_cp_primal",
@@ -115,6 +124,22 @@ def main():
         if name in halo_ops:
             rc = call(ctypes.byref(gs), a)
             expect_neg(rc, name + "(interior slab without halos)")
+    # the persistent small-volume loops: unsharded volumes only, sane history layout, volume bound (all before any HIP call)
+    lib.tv_small_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.tv_small_supported(ctypes.byref(g)) == 1 and lib.tv_small_supported(ctypes.byref(gs)) == 0 and lib.tv_small_supported(None) == 0
+    assert lib.tv_small_workspace_bytes(ctypes.byref(g), ctypes.c_int64(0)) == 0 and lib.tv_small_workspace_bytes(ctypes.byref(g), ctypes.c_int64(16)) > (1 << 20)
+    big = geom(nz=64, m=8, ny=1024, nx=1024)
+    assert lib.tv_small_supported(ctypes.byref(big)) == 0
+    for gg, what in ((gs, "a z-slab"), (big, "a volume beyond TV_SMALL_MAX_KVOXELS")):
+        expect_neg(lib.tv_small_cp(ctypes.byref(gg), a, a, a, a, ctypes.c_double(.5), ctypes.c_double(25.), ctypes.c_double(.1), ctypes.c_double(1.), ctypes.c_int64(4), dp,
+                                   ctypes.c_int64(2), ctypes.c_int64(1), a, N), "tv_small_cp(%s)" % what)
+    for stride, off in ((0, 1), (2, 0), (2, 2), (2, -1)):
+        expect_neg(lib.tv_small_cp(ctypes.byref(g), a, a, a, a, ctypes.c_double(.5), ctypes.c_double(25.), ctypes.c_double(.1), ctypes.c_double(1.), ctypes.c_int64(4), dp,
+                                   ctypes.c_int64(stride), ctypes.c_int64(off), a, N), "tv_small_cp(history layout %d, %d)" % (stride, off))
+    expect_neg(lib.tv_small_cp(ctypes.byref(g), a, a, a, a, ctypes.c_double(.5), ctypes.c_double(25.), ctypes.c_double(.1), ctypes.c_double(1.), ctypes.c_int64(0), dp,
+                               ctypes.c_int64(2), ctypes.c_int64(1), a, N), "tv_small_cp(n_iter = 0)")
+    expect_neg(lib.tv_small_subgrad_descent(ctypes.byref(g), a, a, a, a, ctypes.c_double(.01), ctypes.c_double(25.), ctypes.c_int64(4), dp, ctypes.c_int64(2), ctypes.c_int64(1), a, N),
+               "tv_small_subgrad_descent(x == x_alt)")
     expect_neg(lib.tv_cp_dual(ctypes.byref(g), a, N, N, a, ctypes.c_double(.5), ctypes.c_double(0.0), dp, a, N), "lambda = 0")
     expect_neg(lib.tv_cp_fused(ctypes.byref(g), a, N, N, a, a, a, a, ctypes.c_double(.5), ctypes.c_double(25.), ctypes.c_double(.1),
                                ctypes.c_double(1.), ctypes.c_int64(0), ctypes.c_int64(-1), dp, dp, a, N), "x_in == x_out")
