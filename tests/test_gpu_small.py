@@ -145,7 +145,19 @@ def test_readme_shape_persistent_equals_the_kernel_pair(pytv, scheme):
 
 
 def test_automatic_rule_and_explicit_requests(pytv):
+    """(other GPU test modules lower TV_FUSED_MIN_KVOXELS to 0 for the whole process so that small volumes take the one-sweep kernel: the
+    rule is tested with the product's threshold)"""
     import torch
+    from pytv import _native as nv
+    saved = nv.get_option("TV_FUSED_MIN_KVOXELS", -1)
+    nv.set_option("TV_FUSED_MIN_KVOXELS", 16384)
+    try:
+        _automatic_rule(pytv, torch)
+    finally:
+        nv.set_option("TV_FUSED_MIN_KVOXELS", None if saved < 0 else saved)
+
+
+def _automatic_rule(pytv, torch):
     x_small = torch.rand((4, 2, 32, 32), device="cuda")
     x_mid = torch.rand((20, 4, 256, 256), device="cuda")         # 5.2 Mvoxel: above SMALL_MAX_VOXELS (and above the library's TV_SMALL_MAX_KVOXELS)
     x_2m = torch.rand((9, 4, 256, 256), device="cuda")           # 2.4 Mvoxel: the generic form of the persistent kernels
