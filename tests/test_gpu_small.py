@@ -206,3 +206,39 @@ def test_c_abi_argument_checks(pytv):
     slab = nv.Geometry(tuple(x.shape), "hybrid", x.dtype, x.device, 1.0, 1.0, False, 0, nz_global=6, z0=3)
     assert lib.tv_small_supported(slab.ref) == 0
     assert lib.tv_small_cp(slab.ref, nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 0.5, 25.0, 0.1, 1.0, 2, h.data_ptr(), 2, 1, nv.ptr(ws), st) == -1
+
+
+def test_a_launch_whose_blocks_are_not_resident_together_fails_loudly_instead_of_hanging():
+    """The blocks of a persistent launch wait for each other.  With 7 blocks of 256 threads per CU (TV_SMALL_BLOCKS_PER_CU=7; the product bound is 4)
+    hipLaunchCooperativeKernel accepted a 1764-block launch of the scalar-lane instantiation that the hardware did not keep resident together:
+    the random walk hung on it.  The kernels now abandon such a launch after ~2 s of polling: NaN history, RuntimeError -- in a child process
+    with a hard timeout, so that a regression shows as a failure, not as a hung suite.  (Where the hardware does keep them resident, the
+    run must simply be correct.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%r, "pytv-4d_amd")); sys.path.insert(0, %r)
+import numpy as np, torch, pytv
+rng = np.random.default_rng(1)
+x0 = torch.as_tensor((rng.standard_normal((7, 9, 55, 102)) * 30 + 50).astype(np.float32)).cuda()
+kw = dict(reg_z_over_reg=0.3, reg_time=1.7)
+ref = pytv.solvers.ChambollePock(x0, 25.0, scheme="central", fused=False, pitch=None, **kw).run(2, graph=False)
+try:
+    got = pytv.solvers.ChambollePock(x0, 25.0, scheme="central", persistent=True, pitch=None, **kw).run(2)
+    assert np.allclose(got, ref, rtol=2e-5), (got, ref)
+    print("RESIDENT_AND_CORRECT")
+except RuntimeError as e:
+    assert "abandoned" in str(e)
+    print("ABANDONED_LOUDLY")
+torch.cuda.synchronize()
+""" % (ROOT, ROOT)
+    env = dict(os.environ, TV_SMALL_BLOCKS_PER_CU="7")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.stdout[-800:], p.stderr[-1500:])
+    assert "RESIDENT_AND_CORRECT" in p.stdout or "ABANDONED_LOUDLY" in p.stdout
+    # and with the product's bound the same volume runs
+    env = {k: v for k, v in os.environ.items() if k != "TV_SMALL_BLOCKS_PER_CU"}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "RESIDENT_AND_CORRECT" in p.stdout, (p.stdout[-800:], p.stderr[-1500:])
