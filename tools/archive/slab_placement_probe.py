@@ -7,7 +7,7 @@ sweep time of the two ping-pong directions.  Layouts: "separate" = five torch al
 one torch.empty for everything, arrays back to back with <gap> MiB between them.
 usage: python tools/archive/slab_placement_probe.py [NzxMxNyxNx] [constructions] [layout,layout,...]   layout = separate | slab+<gap MiB>[q|m|a]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch, pytv
 from bench import synth_slab
