@@ -317,7 +317,7 @@ __device__ __forceinline__ FlatId small_flat_id(const DG& g, int J) {
     return FlatId{J / per_tile, rest % g.m, rest / g.m};
 }
 __device__ __forceinline__ int small_dependency_flat(const DG& g, const SmallPlan& sp, int J, int nxv, int i) {
-    const int bs = (int)blockDim.x;
+    const int bs = (int)blockDim.x * sp.per_block;          // site-vectors per tile (per_block: site-vectors per thread, 1 in the resident kernels)
     const FlatId id = small_flat_id(g, J);
     if (i < 12) {
         const int which = i >> 2, sign = (i & 2) ? -1 : 1, end = i & 1;
@@ -700,6 +700,387 @@ __global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_reg(DG g, WT<T> w, 
     }
 }
 
+// =================================================================================================================================
+// STREAMED flat form: the layout, the flags and the "every neighbour load of a phase at once" structure of the register-resident kernels, but a
+// thread walks over sp.per_block (2 .. 4) site-vectors and re-loads a site's own state in each phase instead of keeping it: for volumes with
+// more site-vectors than 16 waves per CU hold -- fp64 at the README shape (20,4,100,100: its native dtype), fp32 between 1 and 4 Mvoxel --
+// where the generic form (the per-site bodies of the one-site kernels) walks through four to five dependent memory round trips per phase.
+constexpr int kFlatMaxSites = 4;
+
+template <int S, typename T, int V>
+__global__ __launch_bounds__(kRegMaxThreads) void k_small_cp_flat(DG g, WT<T> w, SmallPlan sp, SmallCpArgs<T> a) {
+    __shared__ double sm[16];
+    __shared__ int sh_abort;
+    if (threadIdx.x == 0) sh_abort = 0;
+    const int L = small_logical_id(sp);
+    if (L >= sp.nblocks) return;
+    constexpr int NS = (S == HYBRID) ? 8 : 4;
+    constexpr unsigned EB = sizeof(T);
+    const int nxv = (g.nx + V - 1) / V, ns = sp.per_block;
+    const int dep = small_dependency_flat(g, sp, L, nxv, (int)threadIdx.x);
+    const unsigned e0 = small_epoch_base(a.flags);
+    const FlatId fid = small_flat_id(g, L);
+    const int t = fid.t, zl = fid.zl;
+    const CohMem mx = CohMem::make(a.x, a.x_bytes), mq = CohMem::make(a.q, a.q_bytes);
+    const Vec<T, V> zero = vsplat<T, V>(T(0));
+    const int d_row = g.rp * (int)EB, d_frame = (int)(g.s_t * EB), d_plane = (int)(g.s_z * EB), d_qplane = (int)(g.s_dz * EB);
+    int dq[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) dq[k] = -1;
+    for_each_channel<S>(g, [&](auto slot, int ch) {
+        if constexpr (decltype(slot)::value < NS) dq[decltype(slot)::value] = (int)((long long)ch * g.s_z * EB);
+    });
+    auto at = [&](bool valid, unsigned base, int delta) -> unsigned { return valid ? base + (unsigned)delta : kOOB; };
+    constexpr int U_R = 0, U_C = 1, U_Z = (S == HYBRID) ? 4 : 2, U_T = (S == HYBRID) ? 6 : 3;
+    constexpr int D_R = (S == HYBRID) ? 2 : 0, D_C = (S == HYBRID) ? 3 : 1, D_Z = (S == HYBRID) ? 5 : 2, D_T = (S == HYBRID) ? 7 : 3;
+    constexpr bool LO = (S != DOWNWIND), HI = (S != UPWIND), NEXT = (S != DOWNWIND), PREV = (S != UPWIND);
+    // per-pixel factor of the time channels of my sites, once (a mask load per phase would be a dependent round trip)
+    Vec<T, V> mfs[kFlatMaxSites];
+#pragma unroll
+    for (int j = 0; j < kFlatMaxSites; ++j) {
+        mfs[j] = vsplat<T, V>(T(1));
+        const int sidx = (fid.tile * ns + j) * (int)blockDim.x + (int)threadIdx.x;
+        if (j < ns && g.ta && sidx < g.ny * nxv) mfs[j] = mask_factor<T, V>(g, w.sf, sidx / nxv, (sidx % nxv) * V);
+    }
+    // what a phase needs to know about site j
+    struct Site { bool ok, has_tail, has_head; int y, col0; unsigned bx, bq; };
+    auto site = [&](int j, XN<T, V>& n) -> Site {
+        Site s;
+        const int sidx = (fid.tile * ns + j) * (int)blockDim.x + (int)threadIdx.x;
+        s.ok = sidx < g.ny * nxv;
+        s.y = s.ok ? sidx / nxv : 0;
+        s.col0 = s.ok ? (sidx % nxv) * V : 0;
+        const long long inpl = (long long)t * g.s_t + (long long)s.y * g.rp + s.col0;
+        s.bx = (unsigned)(((long long)zl * g.s_z + inpl) * EB);
+        s.bq = (unsigned)(((long long)zl * g.s_dz + inpl) * EB);
+        n.col0 = s.col0;
+        n.h_nr = s.ok && (s.y + 1 < g.ny);
+        n.h_pr = s.ok && (s.y > 0);
+        n.h_nz = s.ok && g.za && (zl + 1 < g.nz);
+        n.h_pz = s.ok && g.za && (zl > 0);
+        n.h_nt = s.ok && g.ta && (t + 1 < g.m);
+        n.h_pt = s.ok && g.ta && (t > 0);
+        s.has_tail = s.ok && (s.col0 + V < g.nx);
+        s.has_head = s.ok && (s.col0 > 0);
+        return s;
+    };
+    const int gz = zl;
+    for (int it = 0; it < a.n_iter; ++it) {
+        // ---- dual
+        double acc = 0.0;
+        for (int j = 0; j < ns; ++j) {
+            XN<T, V> n;
+            const Site s = site(j, n);
+            const Vec<T, V> mf = mfs[j < kFlatMaxSites ? j : 0];
+            n.c = coh_ldv<T, V>(mx, at(s.ok, s.bx, 0));
+            n.nr = coh_ldv<T, V>(mx, at(NEXT && n.h_nr, s.bx, d_row)); n.pr = coh_ldv<T, V>(mx, at(PREV && n.h_pr, s.bx, -d_row));
+            n.nz = coh_ldv<T, V>(mx, at(NEXT && n.h_nz, s.bx, d_plane)); n.pz = coh_ldv<T, V>(mx, at(PREV && n.h_pz, s.bx, -d_plane));
+            n.nt = coh_ldv<T, V>(mx, at(NEXT && n.h_nt, s.bx, d_frame)); n.pt = coh_ldv<T, V>(mx, at(PREV && n.h_pt, s.bx, -d_frame));
+            const T x_tail = coh_ld1<T>(mx, at(NEXT && s.has_tail, s.bx, V * (int)EB)), x_head = coh_ld1<T>(mx, at(PREV && s.has_head, s.bx, -(int)EB));
+            Vec<T, V> q[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) q[k] = coh_ldv<T, V>(mq, at(s.ok && dq[k] >= 0, s.bq, dq[k]));
+            n.nc = NEXT ? shift_left<T, V>(n.c, x_tail) : zero;
+            n.pc = PREV ? shift_right<T, V>(n.c, x_head) : zero;
+            Vec<T, V> o[8];
+            d_slots<S, T, V>(g, w, n, mf, o);
+            Vec<T, V> vs = zero;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                q[k] = q[k] + a.sigma_D * o[k];
+                vs = vs + q[k] * q[k];
+            }
+            const Vec<T, V> ds = sumsq_slots<T, V>(o);
+            Vec<T, V> scale;
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                part += (double)tsqrt(ds.v[i]);
+                scale.v[i] = T(1) / tmax(T(1), tsqrt(vs.v[i]) * a.inv_lambda);
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) coh_stv<T, V>(mq, at(s.ok && dq[k] >= 0, s.bq, dq[k]), q[k] * scale);
+            if (s.ok) acc += part;
+        }
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
+        if (small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1), &sh_abort)) break;
+        // ---- primal
+        acc = 0.0;
+        for (int j = 0; j < ns; ++j) {
+            XN<T, V> n;
+            const Site s = site(j, n);
+            const Vec<T, V> mf = mfs[j < kFlatMaxSites ? j : 0];
+            const int y = s.y, col0 = s.col0;
+            Vec<T, V> q[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) q[k] = coh_ldv<T, V>(mq, at(s.ok && dq[k] >= 0, s.bq, dq[k]));
+            const Vec<T, V> lo_r = coh_ldv<T, V>(mq, at(LO && n.h_pr, s.bq, dq[U_R] - d_row)), hi_r = coh_ldv<T, V>(mq, at(HI && n.h_nr, s.bq, dq[D_R] + d_row));
+            const Vec<T, V> lo_z = coh_ldv<T, V>(mq, at(LO && n.h_pz, s.bq, dq[U_Z] - d_qplane)), hi_z = coh_ldv<T, V>(mq, at(HI && n.h_nz, s.bq, dq[D_Z] + d_qplane));
+            const Vec<T, V> lo_t = coh_ldv<T, V>(mq, at(LO && n.h_pt, s.bq, dq[U_T] - d_frame)), hi_t = coh_ldv<T, V>(mq, at(HI && n.h_nt, s.bq, dq[D_T] + d_frame));
+            const T q_head = coh_ld1<T>(mq, at(LO && s.has_head, s.bq, dq[U_C] - (int)EB)), q_tail = coh_ld1<T>(mq, at(HI && s.has_tail, s.bq, dq[D_C] + V * (int)EB));
+            Vec<T, V> x = coh_ldv<T, V>(mx, at(s.ok, s.bx, 0));
+            const long long offx = (long long)(s.bx / EB);
+            const Vec<T, V> x0 = s.ok ? vload<T, V>(a.x0 + offx) : zero;
+            Vec<T, V> p = s.ok ? vload<T, V>(a.p + offx) : zero;
+            Vec<T, V> r = zero, rt = zero;
+            auto rows = [&](auto mode, const Vec<T, V>& ce_q) {
+                constexpr int M = decltype(mode)::value;
+                r = r + adj_axis<M, T, V>(y, g.ny, (M != 1) ? lo_r : zero, (M != 2) ? ce_q : zero, (M != 0) ? hi_r : zero);
+            };
+            auto cols = [&](auto mode, const Vec<T, V>& ce) {
+                constexpr int M = decltype(mode)::value;
+                const Vec<T, V> lo = shift_right<T, V>(ce, q_head), hi = shift_left<T, V>(ce, q_tail);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const int col = col0 + i;
+                    T u, v;
+                    if (M == 0) { u = (col >= 1) ? lo.v[i] : T(0); v = (col <= g.nx - 2) ? ce.v[i] : T(0); }
+                    else if (M == 1) { u = (col >= 1) ? ce.v[i] : T(0); v = (col <= g.nx - 2) ? hi.v[i] : T(0); }
+                    else { u = (col >= 2) ? lo.v[i] : T(0); v = (col <= g.nx - 3) ? hi.v[i] : T(0); }
+                    r.v[i] += u - v;
+                }
+            };
+            auto zax = [&](auto mode, const Vec<T, V>& ce_q) {
+                constexpr int M = decltype(mode)::value;
+                r = r + w.wz * adj_axis<M, T, V>(gz, g.nzg, (M != 1) ? lo_z : zero, (M != 2) ? ce_q : zero, (M != 0) ? hi_z : zero);
+            };
+            auto tax = [&](auto mode, const Vec<T, V>& ce_q) {
+                constexpr int M = decltype(mode)::value;
+                rt = rt + w.wt * adj_axis<M, T, V>(t, g.m, (M != 1) ? lo_t : zero, (M != 2) ? ce_q : zero, (M != 0) ? hi_t : zero);
+            };
+            if constexpr (S == UPWIND) {
+                rows(IC<0>{}, q[0]); cols(IC<0>{}, q[1]);
+                if (g.za) zax(IC<0>{}, q[2]);
+                if (g.ta) tax(IC<0>{}, q[3]);
+            } else if constexpr (S == DOWNWIND) {
+                rows(IC<1>{}, q[0]); cols(IC<1>{}, q[1]);
+                if (g.za) zax(IC<1>{}, q[2]);
+                if (g.ta) tax(IC<1>{}, q[3]);
+            } else if constexpr (S == CENTRAL) {
+                rows(IC<2>{}, q[0]); cols(IC<2>{}, q[1]);
+                if (g.za) { if (g.z_two) zax(IC<0>{}, q[2]); else zax(IC<2>{}, q[2]); }
+                if (g.ta) { if (g.t_two) tax(IC<0>{}, q[3]); else tax(IC<2>{}, q[3]); }
+            } else {
+                rows(IC<0>{}, q[0]);
+                { const Vec<T, V> ce = q[1], lo = shift_right<T, V>(ce, q_head);
+#pragma unroll
+                  for (int i = 0; i < V; ++i) { const int col = col0 + i; r.v[i] += ((col >= 1) ? lo.v[i] : T(0)) - ((col <= g.nx - 2) ? ce.v[i] : T(0)); } }
+                rows(IC<1>{}, q[2]);
+                { const Vec<T, V> ce = q[3], hi = shift_left<T, V>(ce, q_tail);
+#pragma unroll
+                  for (int i = 0; i < V; ++i) { const int col = col0 + i; r.v[i] += ((col >= 1) ? ce.v[i] : T(0)) - ((col <= g.nx - 2) ? hi.v[i] : T(0)); } }
+                if (g.za) { zax(IC<0>{}, q[4]); zax(IC<1>{}, q[5]); }
+                if (g.ta) { tax(IC<0>{}, q[6]); tax(IC<1>{}, q[7]); }
+            }
+            if (g.ta) r = r + rt * mf;
+            if (S == HYBRID) r = Consts<T>::inv_sqrt2() * r;
+            if (S == CENTRAL) r = T(0.5) * r;
+            zero_pad_cols<T, V>(g, col0, r);
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                p.v[i] = (p.v[i] + a.sigma_A * (x.v[i] - x0.v[i])) * a.inv_1p_sigma_A;
+                x.v[i] = (x.v[i] - a.tau * p.v[i]) - a.tau * r.v[i];
+                const double e = (double)x.v[i] - (double)x0.v[i];
+                part += 0.5 * e * e;
+            }
+            coh_stv<T, V>(mx, at(s.ok, s.bx, 0), x);
+            if (s.ok) { vstore<T, V>(a.p + offx, p); acc += part; }
+        }
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
+        if (it + 1 < a.n_iter && small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2), &sh_abort)) break;
+    }
+}
+
+template <int S, typename T, int V>
+__global__ __launch_bounds__(kRegMaxThreads) void k_small_sg_flat(DG g, WT<T> w, SmallPlan sp, SmallSgArgs<T> a) {
+    __shared__ double sm[16];
+    __shared__ int sh_abort;
+    if (threadIdx.x == 0) sh_abort = 0;
+    const int L = small_logical_id(sp);
+    if (L >= sp.nblocks) return;
+    constexpr unsigned EB = sizeof(T);
+    const int nxv = (g.nx + V - 1) / V, ns = sp.per_block;
+    const int dep = small_dependency_flat(g, sp, L, nxv, (int)threadIdx.x);
+    const unsigned e0 = small_epoch_base(a.flags);
+    const FlatId fid = small_flat_id(g, L);
+    const int t = fid.t, zl = fid.zl;
+    const CohMem mxa = CohMem::make((const T*)a.xa, a.x_bytes), mxb = CohMem::make((const T*)a.xb, a.x_bytes);
+    const CohMem mn = CohMem::make((const T*)a.norms_ext + g.s_z, a.n_bytes - g.s_z * (long long)EB);
+    const Vec<T, V> zero = vsplat<T, V>(T(0));
+    const int d_row = g.rp * (int)EB, d_frame = (int)(g.s_t * EB), d_plane = (int)(g.s_z * EB);
+    auto at = [&](bool valid, unsigned base, int delta) -> unsigned { return valid ? base + (unsigned)delta : kOOB; };
+    Vec<T, V> mfs[kFlatMaxSites];
+#pragma unroll
+    for (int j = 0; j < kFlatMaxSites; ++j) {
+        mfs[j] = vsplat<T, V>(T(1));
+        const int sidx = (fid.tile * ns + j) * (int)blockDim.x + (int)threadIdx.x;
+        if (j < ns && g.ta && sidx < g.ny * nxv) mfs[j] = mask_factor<T, V>(g, w.sf, sidx / nxv, (sidx % nxv) * V);
+    }
+    struct Site { bool ok, has_tail, has_head; int y, col0; unsigned b; };
+    auto site = [&](int j, XN<T, V>& n) -> Site {
+        Site s;
+        const int sidx = (fid.tile * ns + j) * (int)blockDim.x + (int)threadIdx.x;
+        s.ok = sidx < g.ny * nxv;
+        s.y = s.ok ? sidx / nxv : 0;
+        s.col0 = s.ok ? (sidx % nxv) * V : 0;
+        s.b = (unsigned)(((long long)zl * g.s_z + (long long)t * g.s_t + (long long)s.y * g.rp + s.col0) * EB);
+        n.col0 = s.col0;
+        n.h_nr = s.ok && (s.y + 1 < g.ny);
+        n.h_pr = s.ok && (s.y > 0);
+        n.h_nz = s.ok && g.za && (zl + 1 < g.nz);
+        n.h_pz = s.ok && g.za && (zl > 0);
+        n.h_nt = s.ok && g.ta && (t + 1 < g.m);
+        n.h_pt = s.ok && g.ta && (t > 0);
+        s.has_tail = s.ok && (s.col0 + V < g.nx);
+        s.has_head = s.ok && (s.col0 > 0);
+        return s;
+    };
+    // the eight neighbours of an image-like array around site s (absent ones: out of range -> 0)
+    auto neighbours = [&](const CohMem& m, const Site& s, XN<T, V>& n, const Vec<T, V>& c, T& head, T& tail) {
+        n.c = c;
+        n.nr = coh_ldv<T, V>(m, at(n.h_nr, s.b, d_row)); n.pr = coh_ldv<T, V>(m, at(n.h_pr, s.b, -d_row));
+        n.nz = coh_ldv<T, V>(m, at(n.h_nz, s.b, d_plane)); n.pz = coh_ldv<T, V>(m, at(n.h_pz, s.b, -d_plane));
+        n.nt = coh_ldv<T, V>(m, at(n.h_nt, s.b, d_frame)); n.pt = coh_ldv<T, V>(m, at(n.h_pt, s.b, -d_frame));
+        tail = coh_ld1<T>(m, at(s.has_tail, s.b, V * (int)EB));
+        head = coh_ld1<T>(m, at(s.has_head, s.b, -(int)EB));
+    };
+    for (int it = 0; it < a.n_iter; ++it) {
+        const CohMem& mxc = (it & 1) ? mxb : mxa;
+        const CohMem& mxo = (it & 1) ? mxa : mxb;
+        // ---- pass 1
+        double acc = 0.0;
+        for (int j = 0; j < ns; ++j) {
+            XN<T, V> n;
+            const Site s = site(j, n);
+            const Vec<T, V> mf = mfs[j < kFlatMaxSites ? j : 0];
+            const Vec<T, V> x = coh_ldv<T, V>(mxc, at(s.ok, s.b, 0));
+            T x_head, x_tail;
+            neighbours(mxc, s, n, x, x_head, x_tail);
+            n.nc = shift_left<T, V>(x, x_tail);
+            n.pc = shift_right<T, V>(x, x_head);
+            Vec<T, V> o[8], nv;
+            d_slots<S, T, V>(g, w, n, mf, o);
+            const Vec<T, V> ssq = sumsq_slots<T, V>(o);
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const T r = tsqrt(ssq.v[i]);
+                part += (double)r;
+                nv.v[i] = (ssq.v[i] >= tiny_sumsq<T>()) ? T(1) / r : T(0);
+            }
+            coh_stv<T, V>(mn, at(s.ok, s.b, 0), nv);
+            if (s.ok) acc += part;
+        }
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) a.partials[((long long)it * 2 + 0) * sp.nblocks + L] = acc;
+        if (small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 1), &sh_abort)) break;
+        // ---- pass 2
+        acc = 0.0;
+        for (int j = 0; j < ns; ++j) {
+            XN<T, V> n, nn;
+            const Site s = site(j, n);
+            nn = n;
+            const Vec<T, V> mf = mfs[j < kFlatMaxSites ? j : 0];
+            const int y = s.y, col0 = s.col0;
+            const unsigned b = s.b;
+            const bool ok = s.ok;
+            Vec<T, V> x = coh_ldv<T, V>(mxc, at(ok, b, 0));
+            const Vec<T, V> nv = coh_ldv<T, V>(mn, at(ok, b, 0));
+            T x_head, x_tail, n_head, n_tail;
+            neighbours(mxc, s, n, x, x_head, x_tail);
+            neighbours(mn, s, nn, nv, n_head, n_tail);
+            const Vec<T, V> x0 = ok ? vload<T, V>(a.x0 + (long long)(b / EB)) : zero;
+            n.nc = shift_left<T, V>(x, x_tail);
+            n.pc = shift_right<T, V>(x, x_head);
+            nn.nc = shift_left<T, V>(nv, n_tail);
+            nn.pc = shift_right<T, V>(nv, n_head);
+            const XN<T, V>& ns_ = nn;
+            Vec<T, V> G;
+            if constexpr (S != CENTRAL) {
+                G = subgrad_site<S, T, V>(g, w, n, ns_, mf);
+            } else {
+                const T hh = T(0.5);
+                const Vec<T, V> xm2r = coh_ldv<T, V>(mxc, at(ok && y >= 2, b, -2 * d_row)), xp2r = coh_ldv<T, V>(mxc, at(ok && y + 2 < g.ny, b, 2 * d_row));
+                const Vec<T, V> xm2z = coh_ldv<T, V>(mxc, at(ok && g.za && zl >= 2, b, -2 * d_plane)), xp2z = coh_ldv<T, V>(mxc, at(ok && g.za && zl + 2 < g.nz, b, 2 * d_plane));
+                const Vec<T, V> xm2t = coh_ldv<T, V>(mxc, at(ok && g.ta && t >= 2, b, -2 * d_frame)), xp2t = coh_ldv<T, V>(mxc, at(ok && g.ta && t + 2 < g.m, b, 2 * d_frame));
+                const T x_head2 = coh_ld1<T>(mxc, at(ok && col0 >= 2, b, -2 * (int)EB)), x_tail2 = coh_ld1<T>(mxc, at(ok && col0 + V + 1 < g.nx, b, (V + 1) * (int)EB));
+                const Vec<T, V>& xc = n.c;
+                Vec<T, V> r = zero;
+                auto cen = [&](int pos, int cnt, const Vec<T, V>& xm2, const Vec<T, V>& xp2, const Vec<T, V>& nm1, const Vec<T, V>& np1, T wa, bool weighted, bool timeax) {
+                    if (pos - 1 > 0 && pos - 1 < cnt - 1) {
+                        Vec<T, V> d = xc - xm2;
+                        if (weighted) d = wa * d;
+                        if (timeax) d = d * mf;
+                        d = hh * d;
+#pragma unroll
+                        for (int i = 0; i < V; ++i) r.v[i] += d.v[i] * nm1.v[i];
+                    }
+                    if (pos + 1 > 0 && pos + 1 < cnt - 1) {
+                        Vec<T, V> d = xp2 - xc;
+                        if (weighted) d = wa * d;
+                        if (timeax) d = d * mf;
+                        d = hh * d;
+#pragma unroll
+                        for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] * np1.v[i];
+                    }
+                };
+                auto fwd = [&](int pos, int cnt, const Vec<T, V>& xm1, const Vec<T, V>& xp1, const Vec<T, V>& nm1, const Vec<T, V>& n0, T wa, bool timeax) {
+                    if (pos >= 1) {
+                        Vec<T, V> d = wa * (xc - xm1);
+                        if (timeax) d = d * mf;
+                        d = hh * d;
+#pragma unroll
+                        for (int i = 0; i < V; ++i) r.v[i] += d.v[i] * nm1.v[i];
+                    }
+                    if (pos <= cnt - 2) {
+                        Vec<T, V> d = wa * (xp1 - xc);
+                        if (timeax) d = d * mf;
+                        d = hh * d;
+#pragma unroll
+                        for (int i = 0; i < V; ++i) r.v[i] -= d.v[i] * n0.v[i];
+                    }
+                };
+                cen(y, g.ny, xm2r, xp2r, ns_.pr, ns_.nr, T(1), false, false);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const int col = col0 + i;
+                    const T xl2 = (i >= 2) ? xc.v[(i >= 2) ? i - 2 : 0] : ((i == 1) ? x_head : x_head2);
+                    const T xr2 = (i + 2 < V) ? xc.v[(i + 2 < V) ? i + 2 : 0] : ((i + 2 == V) ? x_tail : x_tail2);
+                    const T nl = (i >= 1) ? nv.v[(i >= 1) ? i - 1 : 0] : n_head, nr_ = (i + 1 < V) ? nv.v[(i + 1 < V) ? i + 1 : 0] : n_tail;
+                    if (col - 1 > 0 && col - 1 < g.nx - 1) r.v[i] += (hh * (xc.v[i] - xl2)) * nl;
+                    if (col + 1 > 0 && col + 1 < g.nx - 1) r.v[i] -= (hh * (xr2 - xc.v[i])) * nr_;
+                }
+                if (g.za) {
+                    if (g.z_two) fwd(zl, g.nzg, n.pz, n.nz, ns_.pz, nv, w.wz, false);
+                    else cen(zl, g.nzg, xm2z, xp2z, ns_.pz, ns_.nz, w.wz, true, false);
+                }
+                if (g.ta) {
+                    if (g.t_two) fwd(t, g.m, n.pt, n.nt, ns_.pt, nv, w.wt, true);
+                    else cen(t, g.m, xm2t, xp2t, ns_.pt, ns_.nt, w.wt, true, true);
+                }
+                G = hh * r;
+            }
+            zero_pad_cols<T, V>(g, col0, G);
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                x.v[i] = x.v[i] - a.step * ((x.v[i] - x0.v[i]) + a.lambda * G.v[i]);
+                const double e = (double)x.v[i] - (double)x0.v[i];
+                part += 0.5 * e * e;
+            }
+            zero_pad_cols<T, V>(g, col0, x);
+            coh_stv<T, V>(mxo, at(ok, b, 0), x);
+            if (ok) acc += part;
+        }
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) a.partials[((long long)it * 2 + 1) * sp.nblocks + L] = acc;
+        if (it + 1 < a.n_iter && small_sync(a.flags, L, dep, e0 + (unsigned)(2 * it + 2), &sh_abort)) break;
+    }
+}
+
 template <int S, typename T, int V>
 __global__ __launch_bounds__(kSmallThreads) void k_small_sg(DG g, WT<T> w, SmallPlan sp, SmallSgArgs<T> a) {
     __shared__ double sm[16];
@@ -801,19 +1182,20 @@ static SmallPlan small_plan(const DG& d, int V, int capacity) {
 }
 
 // the register-resident kernels: flat site numbering, ONE block per 256 site-vectors of a frame; usable iff the launch can hold them all
-static bool small_plan_flat(const DG& d, int V, const void* kernel, SmallPlan& sp, int& threads) {
+static bool small_plan_flat(const DG& d, int V, const void* kernel, SmallPlan& sp, int& threads, int sites = 1) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) return false;
     if (d.wv != nullptr || env_int("TV_SMALL_GENERIC", 0)) return false;
     const long long nxv = (d.nx + V - 1) / V, sf = (long long)d.ny * nxv, frames = (long long)d.m * d.nz;
-    // T tiles per frame, blocks of roundup64(ceil(sf / T)) threads.  Cost of a choice = waves on the most loaded CU (<= 16: 128 registers per
-    // thread) + blocks on it (every co-resident block adds flags and dependency chains).  Measured on (20,4,100,100) hybrid, us per iteration:
-    // T = 3 (240 blocks x 896 threads) 12.0, T = 5 (400 x 512) 12.7, T = 10 (800 x 256) 13.1, T = 40 (3200 x 64) 15.8 -- the cost orders them
-    // the same way (15, 18, 20, 26): profiles/r6_small_volume_tiles.txt.  Ties: the smaller block.
+    // T tiles per frame, blocks of roundup64(ceil(sf / (T sites))) threads, `sites` site-vectors per thread (1: the register-resident kernels).
+    // Cost of a choice = waves on the most loaded CU (<= 16: 128 registers per thread, and the residency bound of small_capacity) + blocks on it
+    // (every co-resident block adds flags and dependency chains).  Measured on (20,4,100,100) hybrid, us per iteration: T = 3 (240 blocks x 896
+    // threads) 12.0, T = 5 (400 x 512) 12.7, T = 10 (800 x 256) 13.1, T = 40 (3200 x 64) 15.8 -- the cost orders them the same way (15, 18, 20,
+    // 26): profiles/r6_small_volume_tiles.txt.  Ties: the smaller block.
     const int force = env_int("TV_SMALL_TILES", 0);
     long long best_T = 0, best_cost = 1ll << 60, best_bs = 0;
     for (long long T = 1; T <= sf; ++T) {
-        long long bs = ((sf + T - 1) / T + 63) / 64 * 64;
+        long long bs = ((sf + T * sites - 1) / (T * sites) + 63) / 64 * 64;
         if (bs < 64) bs = 64;
         if (bs > kRegMaxThreads || (force > 0 && T != force)) { if (bs == 64) break; continue; }
         const long long nb = T * frames, per_cu = (nb + cus - 1) / cus, waves = per_cu * (bs / 64);
@@ -833,7 +1215,7 @@ static bool small_plan_flat(const DG& d, int V, const void* kernel, SmallPlan& s
     sp.tiles_x = (int)best_T; sp.tiles_y = 1;
     sp.T = (int)best_T;
     sp.nvb = (int)nvb;
-    sp.per_block = 1;
+    sp.per_block = sites;            // flat kernels: site-vectors per thread
     sp.nblocks = (int)nvb;
     sp.grid = (sp.nblocks + 7) / 8 * 8;
     threads = (int)best_bs;
@@ -894,7 +1276,14 @@ int tv_small_cp(const tv_geom* g, void* x, const void* x0, void* p, void* q, dou
         const void* kern = (const void*)k_small_cp_reg<S, T, V>;
         SmallPlan sp;
         int threads = kSmallThreads;
-        if (!small_plan_flat(d, V, kern, sp, threads)) {
+        // TV_SMALL_SITES: 0 = resident form first, then the streamed form with 2 .. 4 site-vectors per thread; 1 = resident only; 2 .. 4 = streamed from there
+        const int s0 = env_int("TV_SMALL_SITES", 0);
+        bool flat = s0 <= 1 && small_plan_flat(d, V, kern, sp, threads);
+        for (int sites = s0 > 2 ? s0 : 2; !flat && sites <= kFlatMaxSites && s0 != 1; ++sites) {
+            kern = (const void*)k_small_cp_flat<S, T, V>;
+            flat = small_plan_flat(d, V, kern, sp, threads, sites);
+        }
+        if (!flat) {
             kern = (const void*)k_small_cp<S, T, V>;
             threads = kSmallThreads;
             const int cap = small_capacity(kern);
@@ -933,7 +1322,12 @@ int tv_small_subgrad_descent(const tv_geom* g, void* x, void* x_alt, const void*
         int threads = kSmallThreads;
         bool flat = false;
         kern = (const void*)k_small_sg_reg<S, T, V>;
-        flat = small_plan_flat(d, V, kern, sp, threads);
+        const int s0 = env_int("TV_SMALL_SITES", 0);
+        flat = s0 <= 1 && small_plan_flat(d, V, kern, sp, threads);
+        for (int sites = s0 > 2 ? s0 : 2; !flat && sites <= kFlatMaxSites && s0 != 1; ++sites) {
+            kern = (const void*)k_small_sg_flat<S, T, V>;
+            flat = small_plan_flat(d, V, kern, sp, threads, sites);
+        }
         if (!flat) {
             kern = (const void*)k_small_sg<S, T, V>;
             threads = kSmallThreads;

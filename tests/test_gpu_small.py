@@ -26,22 +26,30 @@ def _noisy(shape, seed, dtype):
     return (truth + 100.0 * rng.rand(*shape)).astype(dtype)
 
 
+FORMS = ["registers", "streamed2", "streamed3", "streamed4", "generic"]
+
+
+def _set_form(nv, form):
+    nv.set_option("TV_SMALL_GENERIC", 1 if form == "generic" else None)
+    nv.set_option("TV_SMALL_SITES", int(form[-1]) if form and form.startswith("streamed") else None)
+
+
 CASES = [((1, 1, 16, 16), 1.0, 0.0, False), ((6, 1, 16, 16), 1.0, 0.0, False), ((5, 3, 12, 16), 1.0, 1.0, False), ((4, 4, 9, 10), 2.5, 0.5, True),
          ((3, 2, 7, 13), 1.0, 1.0, False), ((2, 5, 33, 20), 0.0, 1.0, False), ((7, 2, 5, 70), 1.5, 0.25, True)]
 
 
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("shape,lz,mu,use_mask", CASES)
-def test_persistent_cp_matches_oracle(pytv, scheme, shape, lz, mu, use_mask, generic):
-    """both forms of the kernel: register-resident (one site-vector per thread) and generic (TV_SMALL_GENERIC: the per-site bodies of the
-    kernel pair in a loop); 16-byte lanes where Nx allows, scalar lanes otherwise (Nx = 10, 13: ragged rows)"""
+def test_persistent_cp_matches_oracle(pytv, scheme, shape, lz, mu, use_mask, form):
+    """the forms of the kernel: register-resident (one site-vector per thread), streamed (TV_SMALL_SITES: 2 .. 4 site-vectors per thread,
+    state re-read every phase) and generic (TV_SMALL_GENERIC: the per-site bodies of the kernel pair in a loop); 16-byte lanes where Nx allows, scalar lanes otherwise (Nx = 10, 13: ragged rows)"""
     import torch
     from pytv import _native as nv
     rng = np.random.default_rng(4)
     mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
     kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=4.0 if use_mask else 0)
-    nv.set_option("TV_SMALL_GENERIC", 1 if generic else None)
+    _set_form(nv, form)
     try:
         for dtype, rtol, atol in ((np.float64, 1e-10, 1e-9), (np.float32, 1e-5, 2e-3)):
             x0 = _noisy(shape, 5, dtype)
@@ -52,19 +60,19 @@ def test_persistent_cp_matches_oracle(pytv, scheme, shape, lz, mu, use_mask, gen
             np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s" % (scheme, shape))
             np.testing.assert_allclose(cp.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
     finally:
-        nv.set_option("TV_SMALL_GENERIC", None)
+        _set_form(nv, None)
 
 
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("shape,lz,mu,use_mask", CASES)
-def test_persistent_descent_matches_oracle(pytv, scheme, shape, lz, mu, use_mask, generic):
+def test_persistent_descent_matches_oracle(pytv, scheme, shape, lz, mu, use_mask, form):
     import torch
     from pytv import _native as nv
     rng = np.random.default_rng(4)
     mask = (rng.random((1, 1) + shape[2:]) > 0.5) if use_mask else False
     kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=mask, factor_reg_static=4.0 if use_mask else 0)
-    nv.set_option("TV_SMALL_GENERIC", 1 if generic else None)
+    _set_form(nv, form)
     try:
         for dtype, rtol, atol in ((np.float64, 1e-9, 1e-8), (np.float32, 2e-5, 5e-3)):
             x0 = _noisy(shape, 5, dtype)
@@ -75,7 +83,7 @@ def test_persistent_descent_matches_oracle(pytv, scheme, shape, lz, mu, use_mask
             np.testing.assert_allclose(loss, wloss, rtol=rtol, err_msg="%s %s" % (scheme, shape))
             np.testing.assert_allclose(sg.result().cpu().numpy(), wx, rtol=rtol, atol=atol)
     finally:
-        nv.set_option("TV_SMALL_GENERIC", None)
+        _set_form(nv, None)
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak test of the persistent small-volume loops (tv_small_cp / tv_small_subgrad_descent): random shapes / schemes / dtypes / weights /
-masks / pitches / iteration counts, the register-resident and the generic form, against the ordinary per-iteration kernels (kernel pair;
+masks / pitches / iteration counts, the register-resident, streamed and generic forms, against the ordinary per-iteration kernels (kernel pair;
 two-pass sub-gradient + step) on the same state, and run twice for determinism.  usage: python tools/stress_small.py [n_cases]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,12 +21,14 @@ for case in range(n_cases):
     kw = dict(reg_z_over_reg=lz, reg_time=mu, mask_static=(rng.random((ny, nx)) < 0.4) if use_mask else False, factor_reg_static=2.3 if use_mask else 0)
     dtype = np.float64 if case % 5 == 0 else np.float32
     pitch = [None, "auto"][int(rng.integers(0, 2))]
-    generic = bool(rng.random() < 0.35)
+    form = str(rng.choice(["registers", "registers", "generic", "generic", "streamed2", "streamed3", "streamed4"]))
+    generic = form == "generic"
     n_it = int(rng.choice([1, 2, 7, 16, 33]))
     x0 = torch.as_tensor((rng.standard_normal((nz, m, ny, nx)) * 30 + 50).astype(dtype)).cuda()
     if os.environ.get("STRESS_VERBOSE"):
-        print("case", case, scheme, tuple(x0.shape), dtype.__name__, lz, mu, use_mask, pitch, "generic" if generic else "registers", n_it, flush=True)
+        print("case", case, scheme, tuple(x0.shape), dtype.__name__, lz, mu, use_mask, pitch, form, n_it, flush=True)
     nv.set_option("TV_SMALL_GENERIC", 1 if generic else None)
+    nv.set_option("TV_SMALL_SITES", int(form[-1]) if form.startswith("streamed") else None)
     try:
         tol = 1e-9 if dtype == np.float64 else 2e-5
         a = pytv.solvers.ChambollePock(x0, 25.0, scheme=scheme, persistent=True, pitch=pitch, **kw)
@@ -44,10 +46,11 @@ for case in range(n_cases):
         ok2 = np.array_equal(ls, ls2) and torch.equal(s.result(), s2.result()) and np.allclose(ls[:h], lt[:h], rtol=tol) and np.allclose(ls, lt, rtol=max(tol, 1e-4 if dtype == np.float32 else 1e-8))
     finally:
         nv.set_option("TV_SMALL_GENERIC", None)
+        nv.set_option("TV_SMALL_SITES", None)
     done += 1
     if not (ok and ok2):
         bad += 1
-        print("MISMATCH", scheme, tuple(x0.shape), dtype.__name__, lz, mu, use_mask, pitch, "generic" if generic else "registers", n_it, "CP" if not ok else "", "SG" if not ok2 else "",
+        print("MISMATCH", scheme, tuple(x0.shape), dtype.__name__, lz, mu, use_mask, pitch, form, n_it, "CP" if not ok else "", "SG" if not ok2 else "",
               float(np.max(np.abs(la - lb) / np.abs(lb))), float(np.max(np.abs(ls - lt) / np.abs(lt))))
 print("cases run %d, mismatches %d" % (done, bad))
 sys.exit(1 if bad else 0)
