@@ -176,7 +176,7 @@ inline TvOption g_options[] = {
     {"TV_NO_MARCH_SUBGRAD", 0, 0}, {"TV_NO_MARCH_NORMAL", 0, 0}, {"TV_SCALAR_GATHER", 0, 0}, {"TV_NO_FUSED", 0, 0},
     {"TV_NO_FUSED_TWIN", 0, 0}, {"TV_FUSED_XW", 0, 0}, {"TV_FUSED_FORCE_TWIN", 0, 0}, {"TV_NO_FUSED_SUBGRAD", 0, 0},
     {"TV_NORMAL_KERNEL", 0, 0}, {"TV_D_KERNEL", 0, 0}, {"TV_DT_KERNEL", 0, 0}, {"TV_FUSED_MIN_KVOXELS", 0, 0}, {"TV_SG_KERNEL", 0, 0}, {"TV_SPARE", 0, 0}, {"TV_SG_ALIGNED", 0, 0},
-    {"TV_SMALL_MAX_KVOXELS", 0, 0}, {"TV_NO_SMALL", 0, 0}, {"TV_SMALL_BLOCKS_PER_CU", 0, 0}, {"TV_SMALL_GENERIC", 0, 0}, {"TV_SMALL_TILES", 0, 0}, {"TV_SMALL_SITES", 0, 0},
+    {"TV_SMALL_MAX_KVOXELS", 0, 0}, {"TV_NO_SMALL", 0, 0}, {"TV_SMALL_BLOCKS_PER_CU", 0, 0}, {"TV_SMALL_GENERIC", 0, 0}, {"TV_SMALL_TILES", 0, 0}, {"TV_SMALL_SITES", 0, 0}, {"TV_NS_NO_FIRST", 0, 0},
 };
 inline std::once_flag g_options_once;
 inline TvOption* find_option(const char* name) {

@@ -72,10 +72,15 @@ template <typename T, int V> struct NsEpiIn { Vec<T, V> b, y, add, ref; };
 // bytes, 0 for an absent stream or plane) + the frame's byte offset as the instruction's scalar offset (`soff`): the four loads are
 // unconditional, the frame loop is straight-line code, and a frame costs no descriptor arithmetic.
 // po: element offset of the plane, valid: the plane's epilogue will run
-template <typename T, int V, bool CHEB>
+template <typename T, int V, int CHEB>
 __device__ __forceinline__ void ns_epi_load_buf(const NormalArgsT<T>& a, long long po, bool valid, int pbytes, unsigned boff, int soff, NsEpiIn<T, V>& in) {
     constexpr int NT = TV_NSTREAM_NT ? BUF_NT : 0;
-    if constexpr (CHEB) {
+    // CHEB == 2 (round 6): the first step of a Chebyshev solve as its own instantiation -- b == x, no y / add / ref: NO operand loads at all.
+    // In the general form the four loads of that step go to absent streams and cost no memory traffic, but they sit in the in-order queue
+    // BEHIND the plane-ahead loads of the frame before, and the epilogue's wait for them (vmcnt(6 .. 3) per frame) is therefore a wait for
+    // stencil loads issued two frames ago: ~ 2 KB per wave in flight, 4 TB/s.  Without them a frame waits only for what was requested a
+    // whole plane step ago.
+    if constexpr (CHEB == 1) {
         // b == x (the first step of a Chebyshev solve: e_2 from r alone, x = b = r): the value is in registers already -- one stream less
         in.b = buf_ld<T, V, NT>(buf_rsrc<T>(a.b + po, valid && a.b != a.x, pbytes), boff, soff);
         in.y = buf_ld<T, V, NT>(buf_rsrc<T>(a.y + po, valid && a.y != nullptr, pbytes), boff, soff);
@@ -87,13 +92,13 @@ __device__ __forceinline__ void ns_epi_load_buf(const NormalArgsT<T>& a, long lo
 }
 // BUF: the stores go through descriptors too (plane offset po, plane bytes, frame offset soff; voff = the lane's offset or BUF_OOB: lanes
 // outside the frame drop their store); otherwise fo = po + the frame's element offset and plain global accesses
-template <typename T, int V, bool CHEB, bool BUF = false>
+template <typename T, int V, int CHEB, bool BUF = false>
 __device__ __forceinline__ void ns_epilogue(const NormalArgsT<T>& a, long long fo, unsigned voff, const Vec<T, V>& xm, const Vec<T, V>& ax,
                                             const NsEpiIn<T, V>& in, double& acc0, double& acc1, int pbytes = 0, int soff = 0) {
     constexpr int NT = TV_NSTREAM_NT ? BUF_NT : 0;
     Vec<T, V> o;
-    if constexpr (CHEB) {
-        const Vec<T, V> bv = (a.b == a.x) ? xm : in.b;
+    if constexpr (CHEB != 0) {
+        const Vec<T, V> bv = (CHEB == 2 || a.b == a.x) ? xm : in.b;
         // no y: y = yscale * b (0 after e_0 = 0).  An absent stream reads as 0 and yscale is 0 next to a real y (tv_cheb_step checks), so one
         // fma covers both cases without a select; `add` likewise needs none
         Vec<T, V> res;
@@ -175,7 +180,7 @@ template <typename T, int V> __device__ __forceinline__ Vec<T, V> ns_sub(const V
 }
 
 // RAGGED (windows only): the frame count of the volume is not a multiple of 8, the last window is short (see the frame loop)
-template <int M, bool TWIN, typename T = float, bool CHEB = false, bool RAGGED = false>
+template <int M, bool TWIN, typename T = float, int CHEB = 0, bool RAGGED = false>
 __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3)) void k_normal_stream(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
     static_assert(TWIN || !RAGGED, "only windows can be ragged");
     constexpr int V = 16 / (int)sizeof(T);          // columns per 16-byte lane: 4 floats / 2 doubles (round 3)
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                 // in-order and these are needed a frame from now, the plane loads below a step from now ------------------------------------
                 {
                     const bool more = (t + 1 < M) && fvalid((t + 1 < M) ? t + 1 : t);
-                    if constexpr (CHEB)
+                    if constexpr (CHEB != 0)
                         ns_epi_load_buf<T, V, CHEB>(a, (long long)(more ? z - 1 : z) * g.s_z, more ? !FIRST : (z < ze), pbytes, boff,
                                                     __builtin_amdgcn_readfirstlane(soff(more ? t + 1 : 0)), ein);      // (uniform; said so, or the compiler loops over its values)
                 }
@@ -416,7 +421,7 @@ template <typename T> __device__ __forceinline__ E2<T> buf_ld_e2(Rsrc r, unsigne
 }
 
 // T: float (4 columns per 16-byte lane) or -- round 4 -- double (2 columns: the +-2 column neighbours are then whole neighbour lanes)
-template <int M, bool TWIN, bool CHEB = false, typename T = float, bool RAGGED = false>
+template <int M, bool TWIN, int CHEB = 0, typename T = float, bool RAGGED = false>
 __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3)) void k_normal_stream_cen(DG g, WT<T> w, NormalArgsT<T> a, int zchunk, int nchunks) {
     constexpr int V = 16 / (int)sizeof(T);
     using VT = Vec<T, V>;
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(ST_THREADS, TV_WAVES ? TV_WAVES : (M >= 6 ? 2 : 3))
                     {
                         const bool more = (t + 1 < M) && fvalid((t + 1 < M) ? t + 1 : t);
                         const long long fo_n = more ? (long long)(z - 2) * g.s_z + foff(t + 1) : (long long)z * g.s_z + foff(0);
-                        if constexpr (CHEB) if constexpr (CHEB) ns_epi_load_buf<T, V, CHEB>(a, fo_n, more ? !FIRST : (z < ze), fbytes, boff, 0, ein);
+                        if constexpr (CHEB != 0) ns_epi_load_buf<T, V, CHEB>(a, fo_n, more ? !FIRST : (z < ze), fbytes, boff, 0, ein);
                     }
                     {
                         Pp[t] = buf_ld<T, V>(frame(pn, t, true), boff);

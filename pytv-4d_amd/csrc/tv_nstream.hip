@@ -70,11 +70,13 @@ int N_stream(const tv_geom* g, const DG& d, const void* x, const void* xp, const
         else if (g->dtype == TV_F64) hipLaunchKernelGGL((k_normal_stream<MM, TW, double, CH>), grid, block, 0, st, d, make_w<double>(g), ad, zc, (int)nch); \
         else hipLaunchKernelGGL((k_normal_stream<MM, TW, float, CH>), grid, block, 0, st, d, w, a, zc, (int)nch);       \
     } while (0)
-    // the Chebyshev epilogue is its own instantiation (tv_nstream.h, ns_epilogue)
+    // the Chebyshev epilogue is its own instantiation (tv_nstream.h, ns_epilogue), and so is the first step of a solve (no operand streams)
+    const bool cheb_first = cheb != nullptr && b == x && c.y == nullptr && c.add == nullptr && c.ref == nullptr && !env_int("TV_NS_NO_FIRST", 0);
 #define TV_NS_LAUNCH(MM, TW)                                                                                            \
     do {                                                                                                               \
-        if (cheb) TV_NS_LAUNCH1(MM, TW, true);                                                                         \
-        else TV_NS_LAUNCH1(MM, TW, false);                                                                             \
+        if (cheb_first) TV_NS_LAUNCH1(MM, TW, 2);                                                                      \
+        else if (cheb) TV_NS_LAUNCH1(MM, TW, 1);                                                                       \
+        else TV_NS_LAUNCH1(MM, TW, 0);                                                                                 \
     } while (0)
     switch (d.m > NS_TWN ? 0 : d.m) {
         case 0: TV_NS_LAUNCH(NS_TWN, true); break;
