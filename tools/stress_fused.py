@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "pytv-4d_amd")); sys.path.insert(0, ROOT)
 os.environ["TV_MARCH_MIN_PLANE_KB"] = "0"
 os.environ["TV_FUSED_MIN_KVOXELS"] = "0"
 import torch, pytv
-rng = np.random.default_rng(0)
+rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "0")))
 shapes = [(7, 8, 9, 320), (5, 3, 13, 260), (33, 8, 64, 512), (4, 4, 6, 1028), (9, 2, 31, 68),
           (6, 16, 10, 256), (5, 12, 7, 132), (4, 9, 5, 64), (3, 7, 6, 68), (17, 24, 8, 128)]        # M > 8: time windows
 bad = 0

@@ -9,7 +9,7 @@ import test_gpu_multirank as T
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "17")))
     bad = 0
     for case in range(n):
         world = int(rng.integers(2, 5))
