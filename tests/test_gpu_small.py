@@ -86,6 +86,33 @@ def test_persistent_descent_matches_oracle(pytv, scheme, shape, lz, mu, use_mask
         _set_form(nv, None)
 
 
+TINY = [(1, 1, 1, 1), (1, 1, 2, 2), (1, 1, 1, 7), (1, 1, 9, 1), (3, 1, 1, 1), (1, 5, 1, 3), (2, 2, 2, 2), (1, 1, 3, 130), (2, 3, 1, 4)]
+
+
+@pytest.mark.parametrize("form", ["registers", "streamed2", "generic"])
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_persistent_loops_on_degenerate_shapes(pytv, scheme, form):
+    """one-voxel images, single rows / columns, two-point axes (central falls back to the forward stencil there): the shapes the reference's
+    slicing handles implicitly (pytv/tv_GPU.py:47-139) and a persistent kernel has to get right at its borders"""
+    import torch
+    from pytv import _native as nv
+    _set_form(nv, form)
+    try:
+        for shape in TINY:
+            x0 = _noisy(shape, 11, np.float64)
+            kw = dict(reg_z_over_reg=0.7, reg_time=1.3 if shape[1] > 1 else 0.0)
+            wx, wloss = orc.chambolle_pock(x0, 9, 25.0, scheme=scheme, **kw)
+            cp = pytv.solvers.ChambollePock(torch.as_tensor(x0).cuda(), 25.0, scheme=scheme, persistent=True, pitch=None, **kw)
+            np.testing.assert_allclose(cp.run(9), wloss, rtol=1e-10, atol=1e-9, err_msg="CP %s %s" % (scheme, shape))
+            np.testing.assert_allclose(cp.result().cpu().numpy(), wx, rtol=1e-10, atol=1e-9)
+            wx, wloss = orc.subgradient_descent(x0, 6, 25.0, 5e-3, scheme=scheme, **kw)
+            sg = pytv.solvers.SubgradientDescent(torch.as_tensor(x0).cuda(), 25.0, 5e-3, scheme=scheme, persistent=True, pitch=None, **kw)
+            np.testing.assert_allclose(sg.run(6), wloss, rtol=1e-9, atol=1e-9, err_msg="SG %s %s" % (scheme, shape))
+            np.testing.assert_allclose(sg.result().cpu().numpy(), wx, rtol=1e-9, atol=1e-8)
+    finally:
+        _set_form(nv, None)
+
+
 @pytest.mark.parametrize("scheme", SCHEMES)
 def test_persistent_cp_300_iterations_against_the_reference_golden(pytv, scheme):
     """README.md:141-157 as the real reference ran it (tests/golden/trajectories_2d.npz); 300 iterations = two launches of SMALL_BLOCK = 128
